@@ -1,0 +1,285 @@
+/*
+ * msfm.h — C ABI of the MI355X-native bundle-adjustment + feature-matching core.
+ *
+ * Every entry point replaces one inline third-party call (or one short loop) of the
+ * reference's SfM/src hot path; the reference file:line each one stands in for is cited
+ * on the declaration.  Plain pointers and sizes only: no C++ types, no torch types.
+ *
+ * Conventions
+ *   - All buffers are caller-owned HOST memory unless the name ends in `_dev`.
+ *     The library never retains a host pointer past return.
+ *   - Return value: MSFM_OK (0) or a negative MSFM_E_* code; msfm_last_error(ctx)
+ *     gives the text.  No C++ exception crosses this boundary.
+ *   - One msfm_ctx per GPU (one process per GPU).  A ctx is not re-entrant; the
+ *     reference's OpenMP-parallel kNN loop (fine_matching_graph.cc:87-100) is hoisted
+ *     into the one batched call msfm_match_pairs().
+ *   - Bundle adjustment arithmetic is IEEE binary64 throughout; matching takes
+ *     binary32 descriptors as the reference does (database.cc:412-418).
+ */
+#ifndef MSFM_H_
+#define MSFM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSFM_VERSION 100 /* 0.1.0 */
+
+/* ---- error codes ------------------------------------------------------------------ */
+#define MSFM_OK 0
+#define MSFM_E_INVAL (-1)   /* bad argument / inconsistent sizes                         */
+#define MSFM_E_NOMEM (-2)   /* host or device allocation failed                          */
+#define MSFM_E_DEVICE (-3)  /* HIP runtime error (no GPU, launch failure, ...)           */
+#define MSFM_E_NUMERIC (-4) /* unrecoverable numeric failure (Ceres: FAILURE)            */
+
+typedef struct msfm_ctx msfm_ctx;
+
+int msfm_version(void);
+/* device < 0: use the current HIP device.  Fails with MSFM_E_DEVICE when no GPU is
+ * visible — there is no CPU fallback behind this ABI. */
+int msfm_ctx_create(int device, msfm_ctx** out);
+void msfm_ctx_destroy(msfm_ctx* ctx);
+const char* msfm_last_error(const msfm_ctx* ctx);
+/* The HIP stream (hipStream_t) every kernel of this ctx is launched on. */
+void* msfm_ctx_stream(msfm_ctx* ctx);
+int msfm_ctx_synchronize(msfm_ctx* ctx);
+
+/* Per-kernel-class device time accumulated with HIP events on the ctx stream since the
+ * last reset (used by bench.py for the live roofline figure).  Off by default. */
+#define MSFM_MAX_KERNEL_STATS 32
+typedef struct msfm_kernel_stat {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+} msfm_kernel_stat;
+int msfm_ctx_profile_enable(msfm_ctx* ctx, int enable);
+int msfm_ctx_profile_reset(msfm_ctx* ctx);
+int msfm_ctx_profile_get(msfm_ctx* ctx, msfm_kernel_stat* stats, int cap, int* n_out);
+
+/* ==================================================================================== *
+ *  Matching  
+ * ==================================================================================== */
+
+/* Exact 2-nearest-neighbour search, squared L2, of every query descriptor among the
+ * train descriptors.  Replaces the FLANN pair
+ *     flann_build_index(...)                   SfM/src/graph/fine_matching_graph.cc:72-81
+ *     flann_find_nearest_neighbors_index(...)  SfM/src/graph/fine_matching_graph.cc:99
+ * (twin call site SfM/src/slam_gps.cc:438-447,463) and fills the same two arrays FLANN
+ * fills (`knn_id[j]`, `knn_dis[j]`, fine_matching_graph.cc:96-99):
+ *     ids     [n_query][2]  index into train, nearest first
+ *     sqdists [n_query][2]  squared L2 distance, ascending
+ * Unlike the kd-tree (8 trees, 64 checks — approximate) the result is the exact 2-NN;
+ * equal distances are ordered by lower train index.  n_train >= 2 is required (the
+ * reference divides dists[0]/dists[1]).  dim must be a multiple of 16 and <= 256
+ * (SIFT: 128).
+ */
+int msfm_knn2_f32(msfm_ctx* ctx, const float* train, int n_train, const float* query, int n_query,
+                  int dim, int* ids, float* sqdists);
+
+/* Device-resident descriptor store: one entry per image, uploaded once and reused by
+ * every pair that touches the image (the reference re-reads `<idx2>_feature` from disk
+ * per pair, fine_matching_graph.cc:91). */
+typedef struct msfm_descset msfm_descset;
+int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_descset** out);
+int msfm_descset_upload(msfm_descset* set, int image, const float* desc, int count);
+int msfm_descset_count(const msfm_descset* set, int image);
+void msfm_descset_destroy(msfm_descset* set);
+
+/* Batched pair matching with the ratio tests fused in
+ * (fine_matching_graph.cc:87-133; SLAM variant slam_gps.cc:469-477).
+ * pairs[p] = {idx1 (train image), idx2 (query image)}.
+ * For pair p and query feature m of image idx2 (in feature order, which is the order of
+ * the reference loop fine_matching_graph.cc:116-133):
+ *     ratio = sqdist0 / sqdist1
+ *     code  = -1                                   if !(ratio < ratio_all)
+ *           = id0 | (ratio < ratio_good ? MSFM_MATCH_GOOD : 0)   otherwise
+ * The codes live in device memory inside the result object; fetch copies one pair to
+ * the host.  n_all / n_good are the sizes of the reference's matches_all / matches_good.
+ */
+#define MSFM_MATCH_GOOD 0x40000000
+typedef struct msfm_match_result msfm_match_result;
+int msfm_match_pairs(msfm_descset* set, const int* pairs /*[n_pairs][2]*/, int n_pairs,
+                     float ratio_good, float ratio_all, int keep_knn, msfm_match_result** out);
+int msfm_match_result_counts(msfm_match_result* res, int* n_all /*[n_pairs]*/,
+                             int* n_good /*[n_pairs]*/);
+/* code[count(idx2)]; ids/sqdists may be NULL, and are only available with keep_knn. */
+int msfm_match_result_fetch(msfm_match_result* res, int pair, int32_t* code, int* ids,
+                            float* sqdists);
+void msfm_match_result_destroy(msfm_match_result* res);
+/* Re-run the same pair list into an existing result object (steady-state bench loop:
+ * no allocation, no host transfer). */
+int msfm_match_pairs_rerun(msfm_descset* set, msfm_match_result* res);
+
+/* ==================================================================================== *
+ *  Bundle adjustment  
+ * ==================================================================================== */
+
+/* The problem BundleAdjuster::RunOptimizetion assembles (SfM/src/optimizer.cc:59-129)
+ * gathered into flat arrays.  Gather order = point index ascending, then std::map key
+ * order of the point's observations (optimizer.cc:62,80-82); bad points
+ * (is_bad_estimated_, :64) are simply not gathered.
+ *
+ * Which reference functor an observation becomes follows optimizer.cc:86-125:
+ *   pt_mutable & cam_mutable & model_mutable -> ReprojectionErrorPoseCamXYZ (2;6,3,3)
+ *   pt_mutable & cam_mutable & !model_mutable-> ReprojectionErrorPoseXYZ    (2;6,3)
+ *   pt_mutable & !cam_mutable                -> ReprojectionErrorXYZ        (2;3)
+ *   !pt_mutable & cam_mutable & model_mutable-> ReprojectionErrorPoseCam    (2;6,3)
+ *   !pt_mutable & cam_mutable & !model_mut.  -> ReprojectionErrorPose       (2;6)
+ *   !pt_mutable & !cam_mutable               -> no residual
+ */
+typedef struct msfm_ba_problem {
+  int n_cams, n_models, n_points, n_obs;
+  double* cam_pose;            /* [n_cams][6] angle-axis, t (camera.cc:89-99)      in/out */
+  double* cam_model;           /* [n_models][3] f, k1, k2 (basic_structs.h:83-90)  in/out */
+  const int32_t* cam_model_of_cam; /* [n_cams]                                            */
+  double* point;               /* [n_points][3] (structure.h:64)                   in/out */
+  const int32_t* obs_cam;      /* [n_obs]                                                 */
+  const int32_t* obs_pt;       /* [n_obs] non-decreasing                                  */
+  const double* obs_xy;        /* [n_obs][2] centred pixels (database.cc:522-527)         */
+  const double* pt_weight;     /* [n_points] residual weight (optimizer.cc:69-78)         */
+  const uint8_t* cam_mutable;  /* [n_cams]   NULL = all mutable                           */
+  const uint8_t* model_mutable;/* [n_models] NULL = all mutable (basic_structs.h:64)      */
+  const uint8_t* pt_mutable;   /* [n_points] NULL = all mutable                           */
+  /* Absolute GPS residual per camera (gps_error_pose_absolute.h:31-44, wiring
+   * slam_gps.cc:818-830): r = [w|tx-x|, w|ty-y|, (w/5)|tz-z|] on pose[3:6], Huber(1).
+   * NULL = none.  */
+  const double* gps_xyz;       /* [n_cams][3] */
+  double gps_weight;
+} msfm_ba_problem;
+
+/* Only the fields the reference sets (optimizer.cc:42-48; slam_gps.cc:681-684) plus the
+ * Ceres 1.13 defaults it inherits, spelled out so that tests can vary them.
+ * msfm_ba_options_default() fills the Ceres defaults. */
+typedef struct msfm_ba_options {
+  int max_num_iterations;        /* 200 (basic_structs.h:232); 100 in test_sfm.cc:35-36   */
+  int num_threads;               /* passed through; the GPU path ignores it               */
+  int progress_to_stdout;        /* minimizer_progress_to_stdout                          */
+  double huber_delta;            /* 1.0 (optimizer.cc:84)                                 */
+  double function_tolerance;     /* 1e-6                                                  */
+  double gradient_tolerance;     /* 1e-10                                                 */
+  double parameter_tolerance;    /* 1e-8                                                  */
+  double initial_trust_region_radius; /* 1e4                                              */
+  double max_trust_region_radius;     /* 1e16                                             */
+  double min_trust_region_radius;     /* 1e-32                                            */
+  double min_relative_decrease;       /* 1e-3                                             */
+  double min_lm_diagonal;             /* 1e-6                                             */
+  double max_lm_diagonal;             /* 1e32                                             */
+  int max_num_consecutive_invalid_steps; /* 5                                             */
+  int jacobi_scaling;                 /* 1                                                */
+} msfm_ba_options;
+void msfm_ba_options_default(msfm_ba_options* opt);
+
+/* Termination (ceres::TerminationType + which test fired). */
+#define MSFM_BA_CONVERGENCE_FUNCTION 1
+#define MSFM_BA_CONVERGENCE_GRADIENT 2
+#define MSFM_BA_CONVERGENCE_PARAMETER 3
+#define MSFM_BA_NO_CONVERGENCE 4 /* iteration cap */
+#define MSFM_BA_FAILURE 5        /* too many consecutive invalid steps */
+#define MSFM_BA_MIN_RADIUS 6
+
+/* One row of the Ceres progress table per iteration (row 0 = iteration 0). */
+typedef struct msfm_ba_iteration {
+  double cost;              /* after the iteration                                        */
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease; /* tr_ratio                                                   */
+  double trust_region_radius;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+} msfm_ba_iteration;
+
+typedef struct msfm_ba_summary {
+  int termination;
+  int num_iterations;       /* rows written to `iterations` minus 1                       */
+  int num_successful_steps;
+  int num_unsuccessful_steps;
+  double initial_cost, final_cost;
+  int num_residuals;        /* scalar residual count                                      */
+  int num_reduced_params;   /* order of the reduced camera system                         */
+  msfm_ba_iteration* iterations; /* caller-provided, may be NULL                          */
+  int iterations_capacity;
+  double solve_ms;          /* device time of the LM loop, problem already resident       */
+  double setup_ms;          /* upload + symbolic set-up (block-pair lists)                */
+} msfm_ba_summary;
+
+/* Replaces `ceres::Solve(options_, &problem_, &summary_)` at SfM/src/optimizer.cc:133 and
+ * SfM/src/slam_gps.cc:841: trust-region Levenberg–Marquardt, Huber(1) loss, Jacobi
+ * scaling, dense Schur complement on the points, dense Cholesky of the reduced camera
+ * system, with the Ceres 1.13 control flow (step acceptance, radius update, stopping
+ * rules).  Updates cam_pose / cam_model / point in place, like Ceres does through the
+ * `data` blocks. */
+int msfm_ba_solve(msfm_ctx* ctx, msfm_ba_problem* problem, const msfm_ba_options* options,
+                  msfm_ba_summary* summary);
+
+/* Split form, for callers that keep a problem resident across solves (bench loop,
+ * windowed BA re-solves): create = upload + symbolic set-up, run = LM loop on the
+ * resident state, download = copy parameters back, reset = re-upload parameters only. */
+typedef struct msfm_ba msfm_ba;
+int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* problem, msfm_ba** out);
+int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* options, msfm_ba_summary* summary);
+int msfm_ba_upload_params(msfm_ba* ba, const double* cam_pose, const double* cam_model,
+                          const double* point);
+int msfm_ba_download_params(msfm_ba* ba, double* cam_pose, double* cam_model, double* point);
+void msfm_ba_destroy(msfm_ba* ba);
+
+/* Multi-GPU: points (with all their observations) are sharded over ranks, cameras and
+ * intrinsics are replicated; once per linear solve the partial reduced system
+ * [S | rhs | scalars] of `count` doubles at `buf_dev` must be summed over ranks in place.
+ * The host supplies the collective (RCCL all-reduce through torch.distributed in the
+ * Python host, ncclAllReduce in a C++ host); it is called on the host thread that runs
+ * the solve, after the producing kernels have been enqueued on `stream`, and must leave
+ * the reduced data visible to work enqueued on `stream` afterwards.
+ * The reference has no counterpart (no collective anywhere in SfM/src). */
+typedef int (*msfm_allreduce_fn)(void* user, double* buf_dev, size_t count, void* stream);
+int msfm_ctx_set_allreduce(msfm_ctx* ctx, msfm_allreduce_fn fn, void* user, int rank,
+                           int world_size);
+
+/* ==================================================================================== *
+ *  Triangulation / reprojection  
+ * ==================================================================================== */
+
+/* Tracks in CSR form; cameras as the reference keeps them (camera.h:60-75):
+ *   cam_R [n_cams][9] row-major R, cam_t [n_cams][3], cam_c [n_cams][3] centre,
+ *   cam_fk [n_cams][3] = f, k1, k2 of the camera's CameraModel. */
+typedef struct msfm_tracks {
+  int n_tracks, n_cams;
+  const int32_t* track_off; /* [n_tracks+1] */
+  const int32_t* track_cam; /* [track_off[n_tracks]] */
+  const double* track_xy;   /* [..][2] centred pixels */
+  const double* cam_R;
+  const double* cam_t;
+  const double* cam_c;
+  const double* cam_fk;
+} msfm_tracks;
+
+/* Point3D::Trianglate2 (SfM/src/structure.cc:211-265): ray-midpoint normal equations
+ * solved by 4x4 LLT, then Reprojection() (:267-300) and
+ * SufficientTriangulationAngle() (:325-355).
+ *   X [n][3]; mse [n] (1e5 on negative depth, :280-284); ok [n] = return value.
+ * A failed LLT leaves X untouched and ok = 0 (:248-251); X must therefore be
+ * initialised by the caller. th_angle in radians. */
+int msfm_triangulate_midpoint_batch(msfm_ctx* ctx, const msfm_tracks* tracks, double th_error,
+                                    double th_angle, double* X, double* mse, uint8_t* ok);
+/* Point3D::Trianglate (SfM/src/structure.cc:163-209): DLT rows :179-182, last right
+ * singular vector (:187), same acceptance test.  Tracks with < 2 views return ok = 0. */
+int msfm_triangulate_dlt_batch(msfm_ctx* ctx, const msfm_tracks* tracks, double th_error,
+                               double th_angle, double* X, double* mse, uint8_t* ok);
+/* Point3D::Reprojection (SfM/src/structure.cc:267-300) for given X; this is what
+ * IncrementalSfM::RemovePointOutliers recomputes per point (sfm_incremental.cc:1831-1863). */
+int msfm_reproject_mse_batch(msfm_ctx* ctx, const msfm_tracks* tracks, const double* X,
+                             double* mse);
+
+/* Closed-form fundamental-matrix filter (SfM/src/utils/geo_verification.cc:60-79):
+ * l = F*[x1,y1,1]; l /= hypot(l0,l1); inlier iff |l . [x2,y2,1]| < th (3.0).
+ * pt1/pt2 are float pixel pairs as cv::Point2f; inlier[n] gets 0/1. */
+int msfm_epipolar_filter(msfm_ctx* ctx, const float* pt1, const float* pt2, int n,
+                         const double F[9], double th, uint8_t* inlier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSFM_H_ */

@@ -1,0 +1,180 @@
+"""ctypes front end of the CPU oracle (oracle/msfm_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY — PARITY UNPINNED (see the header of msfm_oracle.cpp).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from metricsfm_amd import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmsfm_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "msfm_oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "msfm.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_ba_solve.argtypes = [C.POINTER(A.BaProblem), C.POINTER(A.BaOptions), C.POINTER(A.BaSummary)]
+        _lib.orc_ba_options_default.argtypes = [C.POINTER(A.BaOptions)]
+        _lib.orc_ba_reduced_system.argtypes = [C.POINTER(A.BaProblem), C.POINTER(A.BaOptions), C.c_double,
+                                               A.c_double_p, A.c_double_p, C.c_int, A.c_double_p, A.c_double_p]
+        for f in (_lib.orc_triangulate_midpoint_batch, _lib.orc_triangulate_dlt_batch):
+            f.argtypes = [C.POINTER(A.Tracks), C.c_double, C.c_double, A.c_double_p, A.c_double_p, A.c_u8_p]
+        _lib.orc_reproject_mse_batch.argtypes = [C.POINTER(A.Tracks), A.c_double_p, A.c_double_p]
+        _lib.orc_epipolar_filter.argtypes = [A.c_float_p, A.c_float_p, C.c_int, A.c_double_p, C.c_double, A.c_u8_p]
+        for f in (_lib.orc_knn2_f32, _lib.orc_knn2_f32_fast):
+            f.argtypes = [A.c_float_p, C.c_int, A.c_float_p, C.c_int, C.c_int, A.c_int_p, A.c_float_p]
+        _lib.orc_ratio_codes.argtypes = [A.c_int_p, A.c_float_p, C.c_int, C.c_float, C.c_float, A.c_int_p,
+                                         A.c_int_p, A.c_int_p]
+        for f in (_lib.orc_reproj_dual, _lib.orc_reproj_analytic):
+            f.argtypes = [A.c_double_p] * 4 + [C.c_double, A.c_double_p, A.c_double_p]
+            f.restype = None
+        _lib.orc_huber.argtypes = [C.c_double, C.c_double, A.c_double_p]
+        _lib.orc_huber.restype = None
+        for f in (_lib.orc_angle_axis_to_R, _lib.orc_R_to_angle_axis):
+            f.argtypes = [A.c_double_p, A.c_double_p]
+            f.restype = None
+        _lib.orc_angle_axis_rotate_point.argtypes = [A.c_double_p] * 3
+        _lib.orc_angle_axis_rotate_point.restype = None
+    return _lib
+
+
+def default_options(**kw):
+    o = A.BaOptions()
+    lib().orc_ba_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def ba_solve(arrays: A.BaArrays, options=None, capacity=512):
+    """Runs the LM on `arrays` IN PLACE (like Ceres on the data blocks); returns the summary dict."""
+    options = options or default_options()
+    buf = A.SummaryBuf(capacity)
+    rc = lib().orc_ba_solve(C.byref(arrays.struct), C.byref(options), C.byref(buf.struct))
+    if rc != 0:
+        raise RuntimeError("orc_ba_solve failed: %d" % rc)
+    return buf.result()
+
+
+def ba_reduced_system(arrays: A.BaArrays, radius=1e4, options=None):
+    options = options or default_options()
+    n = 6 * arrays.struct.n_cams + 3 * arrays.struct.n_models
+    S = np.zeros((n, n))
+    rhs = np.zeros(n)
+    cost, gmax = C.c_double(), C.c_double()
+    m = lib().orc_ba_reduced_system(C.byref(arrays.struct), C.byref(options), radius, A.ptr(S, A.c_double_p),
+                                    A.ptr(rhs, A.c_double_p), n, C.byref(cost), C.byref(gmax))
+    if m < 0:
+        raise RuntimeError("capacity")
+    S = S.reshape(-1)[: m * m].reshape(m, m)
+    return S, rhs[:m], cost.value, gmax.value
+
+
+def reproj(pose, cam, xyz, obs, weight=1.0, dual=False):
+    pose, cam, xyz, obs = (np.ascontiguousarray(v, dtype=np.float64) for v in (pose, cam, xyz, obs))
+    r, J = np.zeros(2), np.zeros((2, 12))
+    f = lib().orc_reproj_dual if dual else lib().orc_reproj_analytic
+    f(A.ptr(pose, A.c_double_p), A.ptr(cam, A.c_double_p), A.ptr(xyz, A.c_double_p), A.ptr(obs, A.c_double_p),
+      weight, A.ptr(r, A.c_double_p), A.ptr(J, A.c_double_p))
+    return r, J
+
+
+def huber(a, s):
+    rho = np.zeros(3)
+    lib().orc_huber(a, s, A.ptr(rho, A.c_double_p))
+    return rho
+
+
+def angle_axis_to_R(aa):
+    aa = np.ascontiguousarray(aa, dtype=np.float64)
+    R = np.zeros(9)
+    lib().orc_angle_axis_to_R(A.ptr(aa, A.c_double_p), A.ptr(R, A.c_double_p))
+    return R.reshape(3, 3)
+
+
+def R_to_angle_axis(R):
+    R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+    aa = np.zeros(3)
+    lib().orc_R_to_angle_axis(A.ptr(R, A.c_double_p), A.ptr(aa, A.c_double_p))
+    return aa
+
+
+def rotate_point(aa, pt):
+    aa, pt = np.ascontiguousarray(aa, dtype=np.float64), np.ascontiguousarray(pt, dtype=np.float64)
+    out = np.zeros(3)
+    lib().orc_angle_axis_rotate_point(A.ptr(aa, A.c_double_p), A.ptr(pt, A.c_double_p), A.ptr(out, A.c_double_p))
+    return out
+
+
+def _tri(fn, tracks: A.TrackArrays, th_error, th_angle, X0=None):
+    n = tracks.struct.n_tracks
+    X = np.zeros((n, 3)) if X0 is None else np.array(X0, dtype=np.float64, order="C")
+    mse, ok = np.zeros(n), np.zeros(n, dtype=np.uint8)
+    fn(C.byref(tracks.struct), th_error, th_angle, A.ptr(X, A.c_double_p), A.ptr(mse, A.c_double_p), A.ptr(ok, A.c_u8_p))
+    return X, mse, ok
+
+
+def triangulate_midpoint(tracks, th_error, th_angle, X0=None):
+    return _tri(lib().orc_triangulate_midpoint_batch, tracks, th_error, th_angle, X0)
+
+
+def triangulate_dlt(tracks, th_error, th_angle, X0=None):
+    return _tri(lib().orc_triangulate_dlt_batch, tracks, th_error, th_angle, X0)
+
+
+def reproject_mse(tracks, X):
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    mse = np.zeros(tracks.struct.n_tracks)
+    lib().orc_reproject_mse_batch(C.byref(tracks.struct), A.ptr(X, A.c_double_p), A.ptr(mse, A.c_double_p))
+    return mse
+
+
+def epipolar_filter(pt1, pt2, F, th=3.0):
+    pt1, pt2 = np.ascontiguousarray(pt1, dtype=np.float32), np.ascontiguousarray(pt2, dtype=np.float32)
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    out = np.zeros(len(pt1), dtype=np.uint8)
+    lib().orc_epipolar_filter(A.ptr(pt1, A.c_float_p), A.ptr(pt2, A.c_float_p), len(pt1), A.ptr(F, A.c_double_p), th,
+                              A.ptr(out, A.c_u8_p))
+    return out
+
+
+def knn2(train, query, fast=False):
+    train, query = np.ascontiguousarray(train, dtype=np.float32), np.ascontiguousarray(query, dtype=np.float32)
+    ids = np.zeros((len(query), 2), dtype=np.int32)
+    d = np.zeros((len(query), 2), dtype=np.float32)
+    f = lib().orc_knn2_f32_fast if fast else lib().orc_knn2_f32
+    rc = f(A.ptr(train, A.c_float_p), len(train), A.ptr(query, A.c_float_p), len(query), train.shape[1],
+           A.ptr(ids, A.c_int_p), A.ptr(d, A.c_float_p))
+    if rc != 0:
+        raise ValueError("orc_knn2 rc=%d" % rc)
+    return ids, d
+
+
+def ratio_codes(ids, sqd, ratio_good=0.6, ratio_all=0.85):
+    ids, sqd = np.ascontiguousarray(ids, dtype=np.int32), np.ascontiguousarray(sqd, dtype=np.float32)
+    code = np.zeros(len(ids), dtype=np.int32)
+    na, ng = C.c_int32(), C.c_int32()
+    lib().orc_ratio_codes(A.ptr(ids, A.c_int_p), A.ptr(sqd, A.c_float_p), len(ids), ratio_good, ratio_all,
+                          A.ptr(code, A.c_int_p), C.byref(na), C.byref(ng))
+    return code, na.value, ng.value
