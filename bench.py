@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — BA iterations/s (+ Mmatches/s) on BASELINE.json's headline configuration.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one Levenberg–Marquardt iteration (linearise if the last step was accepted, build the
+Schur complement, factor + solve the reduced camera system, back-substitute, evaluate the trial
+cost) of the 500-camera / 200k-point / 1.2M-observation synthetic scene (BASELINE config 3), with the
+problem already resident in HBM.  Rank 0 prints ONE JSON line.  The matching leg (exhaustive 2-NN +
+ratio tests over ordered image pairs of the same scene) is reported inside the same line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from metricsfm_amd import _abi as A  # noqa: E402
+from metricsfm_amd import capi, scene, shard  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FP64_PEAK_TFLOPS = 78.6        # vendor FP64 vector = matrix figure (not in the micro-arch guide)
+
+
+def fixed_iteration_options(steps):
+    """Exactly `steps` LM iterations: stopping rules off (negative tolerances can never fire)."""
+    return capi.default_options(max_num_iterations=steps, function_tolerance=-1.0, gradient_tolerance=-1.0,
+                                parameter_tolerance=-1.0, max_num_consecutive_invalid_steps=1 << 30,
+                                min_trust_region_radius=0.0)
+
+
+def ba_algorithmic_bytes(n_obs, n_pts, n_cams, n_models):
+    """SURVEY.md §8d per-LM-iteration algorithmic HBM bytes."""
+    n = 6 * n_cams + 3 * n_models
+    jac = n_obs * (16 + 8) + n_pts * (24 + 24 + 8) + n_cams * 96
+    trial = n_obs * 24 + n_pts * 24
+    return jac + trial + 2 * n * n * 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE config number (3 = headline)")
+    ap.add_argument("--match-images", type=int, default=48, help="images of the scene used by the matching leg")
+    ap.add_argument("--feats", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-matching", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = args.backend or "nccl"
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+
+    ctx = capi.Context(local_rank)
+    if world > 1:
+        ctx.set_allreduce(shard.TorchAllReduce(dist, local_rank), rank, world)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ scene (seeded, identical on every rank)
+    t0 = time.time()
+    sc = scene.config_scene(args.config)
+    gen_s = time.time() - t0
+    full = A.BaArrays.from_scene(sc)
+    mine = shard.shard_ba_arrays(full, rank, world)  # points (+ their observations) of this rank; cameras replicated
+    ba = ctx.ba(mine)
+    start = (mine.cam_pose.copy(), mine.cam_model.copy(), mine.point.copy())
+
+    # ------------------------------------------------------------------ BA: warmup, then exactly K iterations
+    if args.warmup > 0:
+        ba.run(fixed_iteration_options(args.warmup))
+    ba.upload(*start)
+    barrier()
+    t0 = time.perf_counter()
+    res = ba.run(fixed_iteration_options(args.steps))
+    barrier()
+    ba_s = max_over_ranks(time.perf_counter() - t0)
+    assert res["num_iterations"] == args.steps, res["termination"]
+
+    # profiled pass (HIP events per kernel class on the ctx stream) for the roofline figures
+    ba.upload(*start)
+    ctx.profile(True)
+    ctx.profile_reset()
+    res_p = ba.run(fixed_iteration_options(args.steps))
+    ba_stats = ctx.profile_get()
+    ctx.profile(False)
+
+    n_red = res["num_reduced_params"]
+    it_s = args.steps / ba_s
+    alg_bytes = ba_algorithmic_bytes(sc.n_obs, sc.n_points, sc.n_cams, len(sc.cam_model))
+    chol_flops = n_red ** 3 / 3.0 + 2.0 * n_red ** 2
+    kernels = []
+    for name, st in sorted(ba_stats.items(), key=lambda kv: -kv[1]["total_ms"]):
+        kernels.append(dict(kernel=name, launches=st["launches"], ms_per_step=st["total_ms"] / args.steps,
+                            avg_launch_us=1e3 * st["total_ms"] / max(1, st["launches"])))
+    # dominant kernel of the BA step and its roofline
+    dom = kernels[0]
+    syrk = ba_stats.get("chol_syrk64_mfma")
+    rooflines = {}
+    if syrk:
+        # the SYRK trailing updates carry n^3/3 of the factorisation's flops
+        fl = n_red ** 3 / 3.0 * (res_p["num_iterations"])
+        ach = fl / (syrk["total_ms"] * 1e-3) / 1e12
+        rooflines["chol_syrk64_mfma"] = dict(bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
+                                             frac=ach / FP64_PEAK_TFLOPS, traffic=None,
+                                             note="n^3/3 flops of the dense Cholesky / time in v_mfma_f64_16x16x4 SYRK tiles")
+    for kname, bytes_per_step in (("ba_linearize", sc.n_obs * (24 + 16 + 46 * 8)), ("ba_schur_pairs", None)):
+        st = ba_stats.get(kname)
+        if st and bytes_per_step:
+            ach = bytes_per_step * st["launches"] / (st["total_ms"] * 1e-3) / 1e9
+            rooflines[kname] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
+    step_bw = alg_bytes / (ba_s / args.steps) / 1e9
+    roofline = dict(bound="hbm", achieved=step_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=step_bw / HBM_PEAK_GBS, traffic=None,
+                    kernel="lm_iteration (all kernels)", dominant_kernel=dom["kernel"],
+                    note="algorithmic bytes of one LM iteration (SURVEY 8d: %.0f MB) / measured time per iteration; "
+                         "FP64 side: %.2f GFLOP Cholesky per iteration" % (alg_bytes / 1e6, chol_flops / 1e9))
+    if dom["kernel"] in rooflines:
+        roofline = dict(rooflines[dom["kernel"]], kernel=dom["kernel"])
+
+    out = dict(metric="ba_lm_iterations_per_sec", value=it_s, unit="iterations/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=1e3 * ba_s / args.steps, higher_is_better=True, scaling="strong",
+               vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload="BASELINE config %d: %d cameras / %d points / %d observations, dense-Schur LM, Huber(1)" %
+                           (args.config, sc.n_cams, sc.n_points, sc.n_obs), reduced_system_order=n_red,
+                           parallelism="points sharded over %d rank(s), camera block all-reduced" % world,
+                           successful_steps=res["num_successful_steps"], unsuccessful_steps=res["num_unsuccessful_steps"],
+                           setup_ms=res["setup_ms"], scene_gen_s=gen_s),
+               roofline=roofline, kernel_rooflines=rooflines, ba_kernels=kernels,
+               ba_cost=dict(initial=res["initial_cost"], final=res["final_cost"]))
+
+    # ------------------------------------------------------------------ matching leg
+    if not args.no_matching:
+        n_img = min(args.match_images, sc.n_cams)
+        scene.add_features(sc, args.feats, images=range(n_img))
+        descs = [sc.desc[i] for i in range(n_img)]
+        pairs = scene.all_pairs(n_img)
+        my_pairs = shard.shard_pairs(pairs, rank, world)
+        ds = ctx.descset(descs)
+        mres = ds.match_pairs(my_pairs, 0.6, 0.85, keep_knn=False)
+        for _ in range(max(0, args.warmup - 1)):
+            mres.rerun()
+        msteps = max(1, args.steps)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(msteps):
+            mres.rerun()
+        barrier()
+        m_s = max_over_ranks(time.perf_counter() - t0)
+        ctx.profile(True)
+        ctx.profile_reset()
+        mres.rerun()
+        ctx.synchronize()
+        mstats = ctx.profile_get()
+        ctx.profile(False)
+        counts = np.array([len(d) for d in descs], dtype=np.int64)
+        queries = int(counts[pairs[:, 1]].sum())
+        flops = float(2 * 128 * (counts[pairs[:, 0]] * counts[pairs[:, 1]]).sum())
+        my_flops = float(2 * 128 * (counts[my_pairs[:, 0]] * counts[my_pairs[:, 1]]).sum())
+        na, ng = mres.counts()
+        kst = mstats.get("knn2_bf16_mfma") or mstats.get("knn2_exact_f64")
+        kern_tf = my_flops / (kst["total_ms"] * 1e-3) / 1e12 if kst else None
+        out["matching"] = dict(metric="Mmatches_per_sec", value=1e-6 * queries * msteps / m_s, unit="Mmatches/s",
+                               images=n_img, pairs=int(len(pairs)), feats_per_image=args.feats, steps=msteps,
+                               ms_per_step=1e3 * m_s / msteps, tflops=flops * msteps / m_s / 1e12,
+                               matches_all=int(na.sum()), matches_good=int(ng.sum()),
+                               roofline=dict(bound="mfma", achieved=kern_tf, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                                             frac=(kern_tf / BF16_PEAK_TFLOPS) if kern_tf else None, traffic=None,
+                                             kernel="knn2_bf16_mfma", avg_launch_ms=kst["total_ms"] if kst else None))
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        cpu_iters = 1
+        ref = A.BaArrays.from_scene(sc)
+        t0 = time.perf_counter()
+        r = O.ba_solve(ref, O.default_options(max_num_iterations=cpu_iters, function_tolerance=-1.0,
+                                              gradient_tolerance=-1.0, parameter_tolerance=-1.0))
+        cpu_s = time.perf_counter() - t0
+        cpu = dict(value=r["num_iterations"] / (r["solve_ms"] * 1e-3), unit="iterations/s", cores=1, kind="port",
+                   sample="%d LM iteration(s) of the same config-%d problem by the CPU oracle (restated reference path, "
+                          "num_threads = 1 as basic_structs.h:234), %.1f s wall" % (r["num_iterations"], args.config, cpu_s))
+        if not args.no_matching:
+            t0 = time.perf_counter()
+            O.knn2(sc.desc[0], sc.desc[1][:1024], fast=True)
+            ks = time.perf_counter() - t0
+            cpu["matching"] = dict(value=1e-6 * 1024 / ks, unit="Mmatches/s", cores=1,
+                                   sample="1024 queries x %d train descriptors, brute force float32 (FLANN-L2 arithmetic)" % len(sc.desc[0]))
+        out["cpu_baseline"] = cpu
+        out["speedup_vs_cpu_port"] = it_s / cpu["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    ba.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -227,14 +227,17 @@ int msfm_ba_download_params(msfm_ba* ba, double* cam_pose, double* cam_model, do
 void msfm_ba_destroy(msfm_ba* ba);
 
 /* Multi-GPU: points (with all their observations) are sharded over ranks, cameras and
- * intrinsics are replicated; once per linear solve the partial reduced system
- * [S | rhs | scalars] of `count` doubles at `buf_dev` must be summed over ranks in place.
+ * intrinsics are replicated; a few times per LM iteration `count` doubles at `buf_dev` (the per-camera J^T J sums, the
+ * partial reduced system [S | rhs], a handful of scalars) must be reduced over ranks in place
+ * with `op` (sum or max).
  * The host supplies the collective (RCCL all-reduce through torch.distributed in the
  * Python host, ncclAllReduce in a C++ host); it is called on the host thread that runs
  * the solve, after the producing kernels have been enqueued on `stream`, and must leave
  * the reduced data visible to work enqueued on `stream` afterwards.
  * The reference has no counterpart (no collective anywhere in SfM/src). */
-typedef int (*msfm_allreduce_fn)(void* user, double* buf_dev, size_t count, void* stream);
+#define MSFM_REDUCE_SUM 0
+#define MSFM_REDUCE_MAX 1
+typedef int (*msfm_allreduce_fn)(void* user, double* buf_dev, size_t count, int op, void* stream);
 int msfm_ctx_set_allreduce(msfm_ctx* ctx, msfm_allreduce_fn fn, void* user, int rank,
                            int world_size);
 

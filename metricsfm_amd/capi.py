@@ -1,0 +1,321 @@
+"""ctypes binding of libmsfm.so (include/msfm.h).  There is no CPU fallback: if the HIP
+library is missing or no GPU is visible, every entry point fails loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsfm.so")
+_lib = None
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+# every symbol include/msfm.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "msfm_version", "msfm_ctx_create", "msfm_ctx_destroy", "msfm_last_error", "msfm_ctx_stream",
+    "msfm_ctx_synchronize", "msfm_ctx_profile_enable", "msfm_ctx_profile_reset", "msfm_ctx_profile_get",
+    "msfm_knn2_f32", "msfm_descset_create", "msfm_descset_upload", "msfm_descset_count", "msfm_descset_destroy",
+    "msfm_match_pairs", "msfm_match_result_counts", "msfm_match_result_fetch", "msfm_match_result_destroy",
+    "msfm_match_pairs_rerun", "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
+    "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ctx_set_allreduce",
+    "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
+    "msfm_epipolar_filter",
+]
+
+
+class MsfmError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libmsfm error %d: %s" % (code, text))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                          "`make -C metricsfm_amd/csrc` (no CPU fallback exists)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, d, f = C.c_void_p, C.c_int, C.c_double, C.c_float
+    L.msfm_version.restype = i
+    L.msfm_ctx_create.argtypes = [i, C.POINTER(vp)]
+    L.msfm_ctx_destroy.argtypes = [vp]
+    L.msfm_ctx_destroy.restype = None
+    L.msfm_last_error.argtypes = [vp]
+    L.msfm_last_error.restype = C.c_char_p
+    L.msfm_ctx_stream.argtypes = [vp]
+    L.msfm_ctx_stream.restype = vp
+    L.msfm_ctx_synchronize.argtypes = [vp]
+    L.msfm_ctx_profile_enable.argtypes = [vp, i]
+    L.msfm_ctx_profile_reset.argtypes = [vp]
+    L.msfm_ctx_profile_get.argtypes = [vp, C.POINTER(A.KernelStat), i, C.POINTER(i)]
+    L.msfm_knn2_f32.argtypes = [vp, A.c_float_p, i, A.c_float_p, i, i, A.c_int_p, A.c_float_p]
+    L.msfm_descset_create.argtypes = [vp, i, i, C.POINTER(vp)]
+    L.msfm_descset_upload.argtypes = [vp, i, A.c_float_p, i]
+    L.msfm_descset_count.argtypes = [vp, i]
+    L.msfm_descset_destroy.argtypes = [vp]
+    L.msfm_descset_destroy.restype = None
+    L.msfm_match_pairs.argtypes = [vp, A.c_int_p, i, f, f, i, C.POINTER(vp)]
+    L.msfm_match_pairs_rerun.argtypes = [vp, vp]
+    L.msfm_match_result_counts.argtypes = [vp, A.c_int_p, A.c_int_p]
+    L.msfm_match_result_fetch.argtypes = [vp, i, A.c_int_p, A.c_int_p, A.c_float_p]
+    L.msfm_match_result_destroy.argtypes = [vp]
+    L.msfm_match_result_destroy.restype = None
+    L.msfm_ba_options_default.argtypes = [C.POINTER(A.BaOptions)]
+    L.msfm_ba_options_default.restype = None
+    L.msfm_ba_solve.argtypes = [vp, C.POINTER(A.BaProblem), C.POINTER(A.BaOptions), C.POINTER(A.BaSummary)]
+    L.msfm_ba_create.argtypes = [vp, C.POINTER(A.BaProblem), C.POINTER(vp)]
+    L.msfm_ba_run.argtypes = [vp, C.POINTER(A.BaOptions), C.POINTER(A.BaSummary)]
+    L.msfm_ba_upload_params.argtypes = [vp, A.c_double_p, A.c_double_p, A.c_double_p]
+    L.msfm_ba_download_params.argtypes = [vp, A.c_double_p, A.c_double_p, A.c_double_p]
+    L.msfm_ba_destroy.argtypes = [vp]
+    L.msfm_ba_destroy.restype = None
+    L.msfm_ctx_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp, i, i]
+    for fn in (L.msfm_triangulate_midpoint_batch, L.msfm_triangulate_dlt_batch):
+        fn.argtypes = [vp, C.POINTER(A.Tracks), d, d, A.c_double_p, A.c_double_p, A.c_u8_p]
+    L.msfm_reproject_mse_batch.argtypes = [vp, C.POINTER(A.Tracks), A.c_double_p, A.c_double_p]
+    L.msfm_epipolar_filter.argtypes = [vp, A.c_float_p, A.c_float_p, i, A.c_double_p, d, A.c_u8_p]
+    _lib = L
+    return L
+
+
+def default_options(**kw):
+    o = A.BaOptions()
+    lib().msfm_ba_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    """One per GPU (one process per GPU)."""
+
+    def __init__(self, device=-1):
+        self._h = C.c_void_p()
+        rc = lib().msfm_ctx_create(device, C.byref(self._h))
+        if rc != 0:
+            raise MsfmError(rc, "msfm_ctx_create failed (no visible GPU? libmsfm has no CPU fallback)")
+        self._cb = None
+
+    def close(self):
+        if self._h:
+            lib().msfm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise MsfmError(rc, lib().msfm_last_error(self._h).decode())
+
+    @property
+    def stream(self):
+        return lib().msfm_ctx_stream(self._h)
+
+    def synchronize(self):
+        self.check(lib().msfm_ctx_synchronize(self._h))
+
+    # -- profiling --
+    def profile(self, enable=True):
+        self.check(lib().msfm_ctx_profile_enable(self._h, int(enable)))
+
+    def profile_reset(self):
+        self.check(lib().msfm_ctx_profile_reset(self._h))
+
+    def profile_get(self):
+        arr = (A.KernelStat * A.MSFM_MAX_KERNEL_STATS)()
+        n = C.c_int()
+        self.check(lib().msfm_ctx_profile_get(self._h, arr, A.MSFM_MAX_KERNEL_STATS, C.byref(n)))
+        return {arr[k].name.decode(): dict(launches=int(arr[k].launches), total_ms=float(arr[k].total_ms))
+                for k in range(n.value)}
+
+    def set_allreduce(self, fn, rank, world_size):
+        """fn(buf_ptr:int, count:int, op:int, stream_ptr:int) -> int (0 ok); op 0 = sum, 1 = max."""
+        if fn is None:
+            self._cb = ALLREDUCE_FN()
+        else:
+            def tramp(user, buf, count, op, stream):
+                try:
+                    return int(fn(buf, count, op, stream) or 0)
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            self._cb = ALLREDUCE_FN(tramp)
+        self.check(lib().msfm_ctx_set_allreduce(self._h, self._cb, None, rank, world_size))
+
+    # -- matching --
+    def knn2(self, train, query):
+        """fine_matching_graph.cc:99 shaped call: returns ids [nq,2] i32, sqdists [nq,2] f32."""
+        train, query = A.as_c(train, np.float32), A.as_c(query, np.float32)
+        if train.ndim != 2 or query.ndim != 2 or train.shape[1] != query.shape[1]:
+            raise ValueError("train/query must be [n, dim] with equal dim")
+        ids = np.zeros((len(query), 2), dtype=np.int32)
+        d = np.zeros((len(query), 2), dtype=np.float32)
+        self.check(lib().msfm_knn2_f32(self._h, A.ptr(train, A.c_float_p), len(train), A.ptr(query, A.c_float_p),
+                                       len(query), train.shape[1], A.ptr(ids, A.c_int_p), A.ptr(d, A.c_float_p)))
+        return ids, d
+
+    def descset(self, descs):
+        return DescSet(self, descs)
+
+    # -- bundle adjustment --
+    def ba_solve(self, arrays: A.BaArrays, options=None, capacity=512):
+        """msfm_ba_solve: optimises `arrays` IN PLACE; returns the summary dict."""
+        options = options or default_options()
+        buf = A.SummaryBuf(capacity)
+        self.check(lib().msfm_ba_solve(self._h, C.byref(arrays.struct), C.byref(options), C.byref(buf.struct)))
+        return buf.result()
+
+    def ba(self, arrays: A.BaArrays):
+        return BaResident(self, arrays)
+
+    # -- triangulation --
+    def _tri(self, fn, tracks, th_error, th_angle, X0):
+        n = tracks.struct.n_tracks
+        X = np.zeros((n, 3)) if X0 is None else np.array(X0, dtype=np.float64, order="C")
+        mse, ok = np.zeros(n), np.zeros(n, dtype=np.uint8)
+        self.check(fn(self._h, C.byref(tracks.struct), th_error, th_angle, A.ptr(X, A.c_double_p),
+                      A.ptr(mse, A.c_double_p), A.ptr(ok, A.c_u8_p)))
+        return X, mse, ok
+
+    def triangulate_midpoint(self, tracks, th_error, th_angle, X0=None):
+        return self._tri(lib().msfm_triangulate_midpoint_batch, tracks, th_error, th_angle, X0)
+
+    def triangulate_dlt(self, tracks, th_error, th_angle, X0=None):
+        return self._tri(lib().msfm_triangulate_dlt_batch, tracks, th_error, th_angle, X0)
+
+    def reproject_mse(self, tracks, X):
+        X = A.as_c(X, np.float64)
+        mse = np.zeros(tracks.struct.n_tracks)
+        self.check(lib().msfm_reproject_mse_batch(self._h, C.byref(tracks.struct), A.ptr(X, A.c_double_p),
+                                                  A.ptr(mse, A.c_double_p)))
+        return mse
+
+    def epipolar_filter(self, pt1, pt2, F, th=3.0):
+        pt1, pt2 = A.as_c(pt1, np.float32), A.as_c(pt2, np.float32)
+        F = A.as_c(np.asarray(F, dtype=np.float64).reshape(9), np.float64)
+        out = np.zeros(len(pt1), dtype=np.uint8)
+        self.check(lib().msfm_epipolar_filter(self._h, A.ptr(pt1, A.c_float_p), A.ptr(pt2, A.c_float_p), len(pt1),
+                                              A.ptr(F, A.c_double_p), th, A.ptr(out, A.c_u8_p)))
+        return out
+
+
+class DescSet:
+    """Device-resident descriptors of a set of images (msfm_descset)."""
+
+    def __init__(self, ctx: Context, descs):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        dim = descs[0].shape[1]
+        ctx.check(lib().msfm_descset_create(ctx._h, len(descs), dim, C.byref(self._h)))
+        for i, d in enumerate(descs):
+            d = A.as_c(d, np.float32)
+            ctx.check(lib().msfm_descset_upload(self._h, i, A.ptr(d, A.c_float_p), len(d)))
+        self.counts = [len(d) for d in descs]
+
+    def match_pairs(self, pairs, ratio_good=0.6, ratio_all=0.85, keep_knn=False):
+        return MatchResult(self, pairs, ratio_good, ratio_all, keep_knn)
+
+    def close(self):
+        if self._h:
+            lib().msfm_descset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MatchResult:
+    def __init__(self, ds: DescSet, pairs, ratio_good, ratio_all, keep_knn):
+        self.ds, self.ctx = ds, ds.ctx
+        self.pairs = A.as_c(np.asarray(pairs).reshape(-1, 2), np.int32)
+        self.keep_knn = keep_knn
+        self._h = C.c_void_p()
+        self.ctx.check(lib().msfm_match_pairs(ds._h, A.ptr(self.pairs, A.c_int_p), len(self.pairs), ratio_good,
+                                              ratio_all, int(keep_knn), C.byref(self._h)))
+
+    def rerun(self):
+        self.ctx.check(lib().msfm_match_pairs_rerun(self.ds._h, self._h))
+
+    def counts(self):
+        na, ng = np.zeros(len(self.pairs), np.int32), np.zeros(len(self.pairs), np.int32)
+        self.ctx.check(lib().msfm_match_result_counts(self._h, A.ptr(na, A.c_int_p), A.ptr(ng, A.c_int_p)))
+        return na, ng
+
+    def fetch(self, pair):
+        nq = self.ds.counts[self.pairs[pair, 1]]
+        code = np.zeros(nq, np.int32)
+        ids = np.zeros((nq, 2), np.int32) if self.keep_knn else None
+        d = np.zeros((nq, 2), np.float32) if self.keep_knn else None
+        self.ctx.check(lib().msfm_match_result_fetch(self._h, pair, A.ptr(code, A.c_int_p), A.ptr(ids, A.c_int_p),
+                                                     A.ptr(d, A.c_float_p)))
+        return code, ids, d
+
+    def close(self):
+        if self._h:
+            lib().msfm_match_result_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BaResident:
+    """msfm_ba_create / run / upload / download: a BA problem kept in HBM across solves."""
+
+    def __init__(self, ctx: Context, arrays: A.BaArrays):
+        self.ctx, self.arrays = ctx, arrays
+        self._h = C.c_void_p()
+        ctx.check(lib().msfm_ba_create(ctx._h, C.byref(arrays.struct), C.byref(self._h)))
+
+    def run(self, options=None, capacity=512):
+        options = options or default_options()
+        buf = A.SummaryBuf(capacity)
+        self.ctx.check(lib().msfm_ba_run(self._h, C.byref(options), C.byref(buf.struct)))
+        return buf.result()
+
+    def upload(self, cam_pose=None, cam_model=None, point=None):
+        cp, cm, pt = A.as_c(cam_pose, np.float64), A.as_c(cam_model, np.float64), A.as_c(point, np.float64)
+        self.ctx.check(lib().msfm_ba_upload_params(self._h, A.ptr(cp, A.c_double_p), A.ptr(cm, A.c_double_p),
+                                                   A.ptr(pt, A.c_double_p)))
+
+    def download(self):
+        a = self.arrays
+        cp, cm, pt = np.zeros_like(a.cam_pose), np.zeros_like(a.cam_model), np.zeros_like(a.point)
+        self.ctx.check(lib().msfm_ba_download_params(self._h, A.ptr(cp, A.c_double_p), A.ptr(cm, A.c_double_p),
+                                                     A.ptr(pt, A.c_double_p)))
+        return cp, cm, pt
+
+    def close(self):
+        if self._h:
+            lib().msfm_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,1357 @@
+// Bundle adjustment on MI355X: Levenberg–Marquardt with a dense Schur complement, replacing
+// `ceres::Solve(options_, &problem_, &summary_)` at SfM/src/optimizer.cc:133 (problem assembly
+// :59-129, options :42-48) and SfM/src/slam_gps.cc:841 (GPS residuals :818-830).
+//
+// Per linearisation (k_linearize, one thread per observation): residual + closed-form Jacobian
+// of the reference's projection model, Huber(1) corrector, Jacobi column scaling; written
+// point-major SoA (for the per-point kernels) and camera-major AoS (for the per-camera sums).
+// Per linear solve:
+//   k_point      one thread per point: V = Jp^T Jp + D^2, 3x3 Cholesky, T = (Jc^T Jp) L^-T per
+//                observation, T.u for the right-hand side
+//   k_ftf        one wave per chunk of a camera's observations: Jc^T Jc, Jm^T Jc, Jm^T Jm, J^T r
+//   k_pairs      one wave per chunk of a (block row, block col) pair list: sum T_a T_b^T — the
+//                Schur complement contributions W V^-1 W^T, reduced in a fixed order (no atomics)
+//   k_asm_*      assemble S and rhs into the padded dense matrix; chol.hip factors and solves
+//   k_backsub    one thread per point: back substitution, candidate point, model cost change
+// The LM control flow (step acceptance, radius update, stopping rules) follows Ceres 1.13's
+// TrustRegionMinimizer and runs on the host; one small scalar read-back per phase.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+
+#include "ba_device.h"
+#include "common.h"
+
+int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* Linv, double* w, double* z, int* fail);
+
+#define PSTRIDE 80   // doubles per FTF partial
+#define CHUNK 1024   // entries per reduction chunk (16 per lane)
+// FTF partial layout
+#define F_JCJC 0     // 36
+#define F_JMJC 36    // 18 (3x6)
+#define F_JMJM 54    // 9
+#define F_JCR 63     // 6
+#define F_JMR 69     // 3
+#define F_TU 72      // 6
+
+// scalar slots (device `scal` array)
+enum { S_COST = 0, S_MCC, S_DX2, S_X2, S_GMAX, S_FAIL, S_N };  // [0,4) are sums, [4,6) are maxima
+
+struct BaPtrs {
+  int A, AE, ncb, nmb, npb, NCR;
+  const double *cam, *model, *pt;  // parameters being evaluated
+  const int *o_cam, *o_model, *o_pt, *o_cb, *o_mb, *o_pb, *o_cpos, *o_pm;
+  const double *o_x, *o_y, *o_w;
+  double *lin_r, *lin_Jc, *lin_Jm, *lin_Jp, *camrow;
+  const double *scale_c, *scale_m, *scale_p;
+  double huber;
+};
+
+// --------------------------------------------------------------------------------------
+// k_linearize: thread per active observation.
+// --------------------------------------------------------------------------------------
+template <bool WRITE_JAC>
+__global__ __launch_bounds__(256) void k_linearize(BaPtrs P, double* __restrict__ cost_partial) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double cost = 0.0;
+  if (i < P.A) {
+    const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
+    double pose[6], cm[3], X[3];
+#pragma unroll
+    for (int j = 0; j < 6; j++) pose[j] = P.cam[6 * (size_t)c + j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; X[j] = P.pt[3 * (size_t)p + j]; }
+    double r[2], J[24];
+    msfm_reproj(pose, cm, X, P.o_x[i], P.o_y[i], P.o_w[i], r, WRITE_JAC ? J : nullptr);
+    double rho0, rho1;
+    msfm_huber(P.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
+    cost = 0.5 * rho0;
+    if (WRITE_JAC) {
+      const double sq = sqrt(rho1);
+      const int cb = P.o_cb[i], mb = P.o_mb[i], pb = P.o_pb[i];
+      const size_t A = P.A;
+      const double r0 = sq * r[0], r1 = sq * r[1];
+      P.lin_r[i] = r0;
+      P.lin_r[A + i] = r1;
+      double jc[12], jm[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const double s = cb >= 0 ? sq * P.scale_c[6 * cb + j] : 0.0;
+        jc[j] = s * J[j];
+        jc[6 + j] = s * J[12 + j];
+        P.lin_Jc[(size_t)j * A + i] = jc[j];
+        P.lin_Jc[(size_t)(6 + j) * A + i] = jc[6 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const double s = mb >= 0 ? sq * P.scale_m[3 * mb + j] : 0.0;
+        jm[j] = s * J[6 + j];
+        jm[3 + j] = s * J[12 + 6 + j];
+        P.lin_Jm[(size_t)j * A + i] = jm[j];
+        P.lin_Jm[(size_t)(3 + j) * A + i] = jm[3 + j];
+        const double sp = pb >= 0 ? sq * P.scale_p[3 * (size_t)pb + j] : 0.0;
+        P.lin_Jp[(size_t)j * A + i] = sp * J[9 + j];
+        P.lin_Jp[(size_t)(3 + j) * A + i] = sp * J[12 + 9 + j];
+      }
+      const int cp = P.o_cpos[i];
+      if (cp >= 0) {
+        double* row = P.camrow + 20 * (size_t)cp;
+#pragma unroll
+        for (int j = 0; j < 12; j++) row[j] = jc[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) row[12 + j] = jm[j];
+        row[18] = r0;
+        row[19] = r1;
+      }
+    }
+  }
+  const double t = block_sum256(cost, sh);
+  if (threadIdx.x == 0) cost_partial[blockIdx.x] = t;
+}
+
+// GPS residual per camera block (gps_error_pose_absolute.h:31-44; d|x|/dx = x<0 ? -1 : 1).
+// Writes corrected, column-scaled r and J (diagonal) and the cost into cost_partial[slot].
+template <bool WRITE_JAC>
+__global__ __launch_bounds__(256) void k_gps(int ncb, const int* __restrict__ cb_cam, const double* __restrict__ cam,
+                                              const double* __restrict__ gps, double w, double huber,
+                                              const double* __restrict__ scale_c, double* __restrict__ g_r,
+                                              double* __restrict__ g_J, double* __restrict__ cost_partial) {
+  __shared__ double sh[4];
+  const int cb = blockIdx.x * 256 + threadIdx.x;
+  double cost = 0.0;
+  if (cb < ncb) {
+    const int c = cb_cam[cb];
+    const double wz[3] = {w, w, w / 5.0};
+    double r[3], J[3], s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double d = cam[6 * (size_t)c + 3 + k] - gps[3 * (size_t)cb + k];
+      r[k] = wz[k] * fabs(d);
+      J[k] = wz[k] * (d < 0.0 ? -1.0 : 1.0);
+      s += r[k] * r[k];
+    }
+    double rho0, rho1;
+    msfm_huber(huber, s, rho0, rho1);
+    cost = 0.5 * rho0;
+    if (WRITE_JAC) {
+      const double sq = sqrt(rho1);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        g_r[3 * (size_t)cb + k] = sq * r[k];
+        g_J[3 * (size_t)cb + k] = sq * J[k] * scale_c[6 * cb + 3 + k];
+      }
+    }
+  }
+  const double t = block_sum256(cost, sh);
+  if (threadIdx.x == 0) cost_partial[blockIdx.x] = t;
+}
+
+// Sum `n` partials in a fixed order into scal[slot] (single workgroup).
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ scal,
+                                                       int slot, int is_max) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) v = is_max ? fmax(v, partial[i]) : v + partial[i];
+  const double t = is_max ? block_max256(v, sh) : block_sum256(v, sh);
+  if (threadIdx.x == 0) scal[slot] = t;
+}
+
+// --------------------------------------------------------------------------------------
+// k_point: thread per eliminated point.  mode 0: full; mode 1: raw squared column norms only.
+// --------------------------------------------------------------------------------------
+struct PointPtrs {
+  int A, npb;
+  const int *pt_first, *o_cpos, *o_mb, *pm_first, *pm_mb;
+  const double *lin_r, *lin_Jc, *lin_Jm, *lin_Jp;
+  double *diag_p;
+  const double* scale_p;
+  double *ptL, *ptg, *T, *Tu, *Tm, *Tmu;
+  double radius, dmin, dmax;
+  int reuse_diag, mode;
+  int* fail;
+};
+
+__global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__ gmax_partial) {
+  __shared__ double sh[4];
+  const int pb = blockIdx.x * 256 + threadIdx.x;
+  double gmax = 0.0;
+  if (pb < P.npb) {
+    const size_t A = P.A;
+    const int f = P.pt_first[pb], l = P.pt_first[pb + 1];
+    double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0;
+    for (int i = f; i < l; i++) {
+      const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
+      const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
+      const double r0 = P.lin_r[i], r1 = P.lin_r[A + i];
+      V00 += a0 * a0 + b0 * b0; V10 += a1 * a0 + b1 * b0; V11 += a1 * a1 + b1 * b1;
+      V20 += a2 * a0 + b2 * b0; V21 += a2 * a1 + b2 * b1; V22 += a2 * a2 + b2 * b2;
+      g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
+    }
+    double* dg = P.diag_p + 3 * (size_t)pb;
+    if (P.mode == 1) {
+      dg[0] = V00; dg[1] = V11; dg[2] = V22;
+    } else {
+      if (!P.reuse_diag) {
+        dg[0] = fmin(fmax(V00, P.dmin), P.dmax);
+        dg[1] = fmin(fmax(V11, P.dmin), P.dmax);
+        dg[2] = fmin(fmax(V22, P.dmin), P.dmax);
+      }
+      // lm_diagonal = sqrt(diagonal / radius); the eliminator adds its square
+      const double q0 = sqrt(dg[0] / P.radius), q1 = sqrt(dg[1] / P.radius), q2 = sqrt(dg[2] / P.radius);
+      V00 += q0 * q0; V11 += q1 * q1; V22 += q2 * q2;
+      // 3x3 Cholesky (Eigen LLT on the e-block in Ceres' InvertPSDMatrix)
+      bool ok = V00 > 0.0;
+      const double l00 = sqrt(V00);
+      const double l10 = V10 / l00, l20 = V20 / l00;
+      const double d1 = V11 - l10 * l10;
+      ok = ok && d1 > 0.0;
+      const double l11 = sqrt(d1);
+      const double l21 = (V21 - l20 * l10) / l11;
+      const double d2 = V22 - l20 * l20 - l21 * l21;
+      ok = ok && d2 > 0.0;
+      const double l22 = sqrt(d2);
+      if (!ok) atomicOr(P.fail, 2);
+      double* L = P.ptL + 6 * (size_t)pb;
+      L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
+      double* gp = P.ptg + 3 * (size_t)pb;
+      gp[0] = g0; gp[1] = g1; gp[2] = g2;
+      const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+      // u = L^-1 g
+      const double u0 = g0 * i00;
+      const double u1 = (g1 - l10 * u0) * i11;
+      const double u2 = (g2 - l20 * u0 - l21 * u1) * i22;
+      const double* sp = P.scale_p + 3 * (size_t)pb;
+      gmax = fmax(fabs(g0 / sp[0]), fmax(fabs(g1 / sp[1]), fabs(g2 / sp[2])));
+      // camera entries: T = (Jc^T Jp) L^-T, T.u
+      for (int i = f; i < l; i++) {
+        const int cp = P.o_cpos[i];
+        if (cp < 0) continue;
+        const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
+        const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
+        double* T = P.T + 18 * (size_t)cp;
+        double* Tu = P.Tu + 6 * (size_t)cp;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          const double ja = P.lin_Jc[(size_t)a * A + i], jb = P.lin_Jc[(size_t)(6 + a) * A + i];
+          const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
+          const double t0 = w0 * i00;
+          const double t1 = (w1 - l10 * t0) * i11;
+          const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
+          T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
+          Tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+        }
+      }
+      // (point, intrinsics-block) entries: Tm = (sum Jm^T Jp) L^-T
+      for (int e = P.pm_first[pb]; e < P.pm_first[pb + 1]; e++) {
+        const int mb = P.pm_mb[e];
+        double W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = f; i < l; i++) {
+          if (P.o_mb[i] != mb) continue;
+          const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
+          const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const double ja = P.lin_Jm[(size_t)a * A + i], jb = P.lin_Jm[(size_t)(3 + a) * A + i];
+            W[a * 3 + 0] += ja * a0 + jb * b0; W[a * 3 + 1] += ja * a1 + jb * b1; W[a * 3 + 2] += ja * a2 + jb * b2;
+          }
+        }
+        double* Tm = P.Tm + 9 * (size_t)e;
+        double* Tmu = P.Tmu + 3 * (size_t)e;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const double t0 = W[a * 3] * i00;
+          const double t1 = (W[a * 3 + 1] - l10 * t0) * i11;
+          const double t2 = (W[a * 3 + 2] - l20 * t0 - l21 * t1) * i22;
+          Tm[a * 3 + 0] = t0; Tm[a * 3 + 1] = t1; Tm[a * 3 + 2] = t2;
+          Tmu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+        }
+      }
+    }
+  }
+  const double t = block_max256(gmax, sh);
+  if (threadIdx.x == 0) gmax_partial[blockIdx.x] = t;
+}
+
+// --------------------------------------------------------------------------------------
+// k_ftf: one wave per chunk of a camera's (camera-major) observation rows.
+// partial[chunk][PSTRIDE]: Jc^T Jc | Jm^T Jc | Jm^T Jm | Jc^T r | Jm^T r | sum T.u
+// --------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wave_reduce_store(double (&acc)[N], double* out, int lane) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) out[k] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
+                                              const double* __restrict__ camrow, const double* __restrict__ Tu,
+                                              const int* __restrict__ cpos_pb, double* __restrict__ partial) {
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (chunk >= nchunk) return;
+  double acc[78];
+#pragma unroll
+  for (int k = 0; k < 78; k++) acc[k] = 0.0;
+  for (int e = ch_start[chunk] + lane; e < ch_end[chunk]; e += 64) {
+    const double* row = camrow + 20 * (size_t)e;
+    double jc[12], jm[6];
+#pragma unroll
+    for (int k = 0; k < 12; k++) jc[k] = row[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) jm[k] = row[12 + k];
+    const double r0 = row[18], r1 = row[19];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[F_JCJC + a * 6 + b] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b];
+      acc[F_JCR + a] += jc[a] * r0 + jc[6 + a] * r1;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int b = 0; b < 6; b++) acc[F_JMJC + a * 6 + b] += jm[a] * jc[b] + jm[3 + a] * jc[6 + b];
+#pragma unroll
+      for (int b = 0; b < 3; b++) acc[F_JMJM + a * 3 + b] += jm[a] * jm[b] + jm[3 + a] * jm[3 + b];
+      acc[F_JMR + a] += jm[a] * r0 + jm[3 + a] * r1;
+    }
+    if (cpos_pb[e] >= 0) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) acc[F_TU + a] += Tu[6 * (size_t)e + a];
+    }
+  }
+  wave_reduce_store<78>(acc, partial + (size_t)chunk * PSTRIDE, lane);
+}
+
+// Sum the FTF partials of each camera block (fixed order) -> camftf[cb][PSTRIDE]; the GPS rows
+// are folded in by the lead rank only (the buffer is summed over ranks afterwards).
+__global__ __launch_bounds__(128) void k_camftf(int ncb, const int* __restrict__ cam_chunk_first,
+                                                 const double* __restrict__ partial, double* __restrict__ camftf,
+                                                 const double* __restrict__ g_r, const double* __restrict__ g_J, int add_gps) {
+  const int cb = blockIdx.x, t = threadIdx.x;
+  if (t < PSTRIDE) {
+    double s = 0.0;
+    for (int ch = cam_chunk_first[cb]; ch < cam_chunk_first[cb + 1]; ch++) s += partial[(size_t)ch * PSTRIDE + t];
+    if (add_gps) {
+      if (t >= F_JCJC && t < F_JCJC + 36) {
+        const int a = (t - F_JCJC) / 6, b = (t - F_JCJC) % 6;
+        if (a == b && a >= 3) { const double j = g_J[3 * (size_t)cb + a - 3]; s += j * j; }
+      } else if (t >= F_JCR + 3 && t < F_JCR + 6) {
+        const int k = t - F_JCR - 3;
+        s += g_J[3 * (size_t)cb + k] * g_r[3 * (size_t)cb + k];
+      }
+    }
+    camftf[(size_t)cb * PSTRIDE + t] = s;
+  }
+}
+
+// From the (globally summed) camftf: LM diagonal / raw column norms of the camera columns and
+// the gradient entries |g / scale|.
+__global__ void k_cam_post(int ncb, const double* __restrict__ camftf, double* __restrict__ diag_c,
+                           const double* __restrict__ scale_c, int reuse_diag, int mode, double dmin, double dmax,
+                           double* __restrict__ gmax_c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 6 * ncb) return;
+  const int cb = i / 6, a = i % 6;
+  const double* f = camftf + (size_t)cb * PSTRIDE;
+  const double s = f[F_JCJC + a * 6 + a];
+  if (mode == 1) diag_c[i] = s;
+  else if (!reuse_diag) diag_c[i] = fmin(fmax(s, dmin), dmax);
+  gmax_c[i] = fabs(f[F_JCR + a] / scale_c[i]);
+}
+
+// Per intrinsics block: sum camftf(Jm^T Jm | Jm^T r) over its cameras (one wave, lanes strided,
+// fixed butterfly) -> modelsum[mb][12]; LM diagonal / raw norms; gradient.
+__global__ __launch_bounds__(64) void k_modelsum(const int* __restrict__ mcam_first, const int* __restrict__ mcam,
+                                                  const double* __restrict__ camftf, double* __restrict__ modelsum,
+                                                  double* __restrict__ diag_m, const double* __restrict__ scale_m, int reuse_diag,
+                                                  int mode, double dmin, double dmax, double* __restrict__ gmax_m) {
+  const int mb = blockIdx.x, lane = threadIdx.x;
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+  for (int q = mcam_first[mb] + lane; q < mcam_first[mb + 1]; q += 64) {
+    const double* f = camftf + (size_t)mcam[q] * PSTRIDE;
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] += f[F_JMJM + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) acc[9 + k] += f[F_JMR + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+    for (int k = 0; k < 12; k++) modelsum[12 * (size_t)mb + k] = acc[k];
+    for (int a = 0; a < 3; a++) {
+      const double s = acc[a * 3 + a];
+      if (mode == 1) diag_m[3 * mb + a] = s;
+      else if (!reuse_diag) diag_m[3 * mb + a] = fmin(fmax(s, dmin), dmax);
+      gmax_m[3 * mb + a] = fabs(acc[9 + a] / scale_m[3 * mb + a]);
+    }
+  }
+}
+
+// jacobian_scaling = 1 / (1 + sqrt(squared column norm))  (Ceres, iteration 0)
+__global__ void k_make_scale(int n, const double* __restrict__ norm2, double* __restrict__ scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scale[i] = 1.0 / (1.0 + sqrt(norm2[i]));
+}
+
+// --------------------------------------------------------------------------------------
+// k_pairs: one wave per chunk of a block-pair list: sum_e A[pa[e]] (DA x 3) * B[pb[e]]^T (3 x DB).
+// --------------------------------------------------------------------------------------
+template <int DA, int DB, bool WITH_U>
+__global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
+                                                const int* __restrict__ pa, const int* __restrict__ pb,
+                                                const double* __restrict__ TA, const double* __restrict__ TB,
+                                                const double* __restrict__ UA, double* __restrict__ partial) {
+  constexpr int NOUT = DA * DB + (WITH_U ? DA : 0);
+  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (chunk >= nchunk) return;
+  double acc[NOUT];
+#pragma unroll
+  for (int k = 0; k < NOUT; k++) acc[k] = 0.0;
+  for (int e = ch_start[chunk] + lane; e < ch_end[chunk]; e += 64) {
+    const int ia = pa[e], ib = pb[e];
+    double ta[DA * 3], tb[DB * 3];
+    const double* pa_ = TA + (size_t)ia * (DA * 3);
+    const double* pb_ = TB + (size_t)ib * (DB * 3);
+#pragma unroll
+    for (int k = 0; k < DA * 3; k++) ta[k] = pa_[k];
+#pragma unroll
+    for (int k = 0; k < DB * 3; k++) tb[k] = pb_[k];
+#pragma unroll
+    for (int a = 0; a < DA; a++)
+#pragma unroll
+      for (int b = 0; b < DB; b++)
+        acc[a * DB + b] += ta[a * 3] * tb[b * 3] + ta[a * 3 + 1] * tb[b * 3 + 1] + ta[a * 3 + 2] * tb[b * 3 + 2];
+    if (WITH_U && ia == ib) {
+#pragma unroll
+      for (int a = 0; a < DA; a++) acc[DA * DB + a] += UA[(size_t)ia * DA + a];
+    }
+  }
+  wave_reduce_store<NOUT>(acc, partial + (size_t)chunk * NOUT, lane);
+}
+
+// --------------------------------------------------------------------------------------
+// Assembly of the padded dense system M (row-major npad x npad, lower triangle; row n = rhs).
+// --------------------------------------------------------------------------------------
+// camera-camera blocks: 64 threads (36 used) per block.
+__global__ __launch_bounds__(64) void k_asm_cc(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                                const double* __restrict__ camftf, const double* __restrict__ diag_c,
+                                                double radius, double* __restrict__ M, int ld, int lead) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= 36) return;
+  const int rb = blk_row[b], cbk = blk_col[b];
+  double s = 0.0;
+  for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 36 + t];
+  double v = -s;
+  const int a = t / 6, c = t % 6;
+  if (rb == cbk && lead) {
+    v += camftf[(size_t)rb * PSTRIDE + F_JCJC + t];
+    if (a == c) { const double q = sqrt(diag_c[6 * rb + a] / radius); v += q * q; }
+  }
+  M[(size_t)(6 * rb + a) * ld + 6 * cbk + c] = v;
+}
+
+// intrinsics-camera blocks (rows 6*ncb + 3*mb.., cols 6*cb..): 18 used threads.
+__global__ __launch_bounds__(64) void k_asm_mc(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                                const double* __restrict__ camftf, const int* __restrict__ cb_mb, int ncb,
+                                                double* __restrict__ M, int ld, int lead) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= 18) return;
+  const int mb = blk_row[b], cb = blk_col[b];
+  double s = 0.0;
+  for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 18 + t];
+  double v = -s;
+  if (lead && cb_mb[cb] == mb) v += camftf[(size_t)cb * PSTRIDE + F_JMJC + t];
+  const int a = t / 6, c = t % 6;
+  M[(size_t)(6 * ncb + 3 * mb + a) * ld + 6 * cb + c] = v;
+}
+
+// intrinsics-intrinsics blocks: one wave per block, lanes strided over chunks.
+// partial layout per chunk: 9 (Tm Tm'^T) + 3 (sum Tm.u, self pairs only).
+__global__ __launch_bounds__(64) void k_asm_mm(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                                const double* __restrict__ modelsum, const double* __restrict__ diag_m, double radius,
+                                                int ncb, int n, double* __restrict__ M, int ld, int lead) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int rb = blk_row[b], cbk = blk_col[b];
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.0;
+  for (int ch = blk_chunk_first[b] + lane; ch < blk_chunk_first[b + 1]; ch += 64)
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] += partial[(size_t)ch * 12 + k];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = wave_sum(acc[k]);
+  if (lane < 9) {
+    const int a = lane / 3, c = lane % 3;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) if (k == lane) v = -acc[k];
+    if (rb == cbk && lead) {
+      v += modelsum[12 * (size_t)rb + lane];
+      if (a == c) { const double q = sqrt(diag_m[3 * rb + a] / radius); v += q * q; }
+    }
+    M[(size_t)(6 * ncb + 3 * rb + a) * ld + 6 * ncb + 3 * cbk + c] = v;
+  } else if (lane < 12 && rb == cbk) {
+    const int a = lane - 9;
+    double u = 0.0;
+#pragma unroll
+    for (int k = 9; k < 12; k++) if (k == lane) u = acc[k];
+    M[(size_t)n * ld + 6 * ncb + 3 * rb + a] = (lead ? modelsum[12 * (size_t)rb + 9 + a] : 0.0) - u;  // rhs row
+  }
+}
+
+// rhs of the camera columns + intrinsics blocks that have no (point, intrinsics) entries.
+// camftf is already global (summed over ranks), so only the lead rank contributes it.
+__global__ void k_asm_rhs_cam(int ncb, const double* __restrict__ camftf, double* __restrict__ M, int ld, int n, int lead) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 6 * ncb) return;
+  const int cb = i / 6, a = i % 6;
+  const double* f = camftf + (size_t)cb * PSTRIDE;
+  M[(size_t)n * ld + i] = lead ? f[F_JCR + a] - f[F_TU + a] : 0.0;
+}
+
+__global__ void k_fail_to_scal(const int* __restrict__ fail, double* __restrict__ scal, int slot) { scal[slot] = (double)*fail; }
+__global__ void k_scale_scal(double* __restrict__ scal, int slot, double f) { scal[slot] *= f; }
+
+// --------------------------------------------------------------------------------------
+// After the reduced solve: camera / intrinsics update, point back substitution, model cost.
+// z = solution of S z = rhs (scaled space); step = -z.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_blocks(int nblocks, int dim, const int* __restrict__ blk_param, const double* __restrict__ z,
+                                                        int zoff, const double* __restrict__ scale, const double* __restrict__ x,
+                                                        double* __restrict__ xc, double* __restrict__ dx2_partial,
+                                                        double* __restrict__ x2_partial, double count_weight) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double dx2 = 0.0, x2 = 0.0;
+  if (i < nblocks * dim) {
+    const int b = i / dim, a = i % dim;
+    const size_t k = (size_t)blk_param[b] * dim + a;
+    const double xv = x[k];
+    const double cand = xv + (-z[zoff + i]) * scale[i];
+    xc[k] = cand;
+    const double d = cand - xv;
+    dx2 = d * d * count_weight;  // replicated blocks are counted by the lead rank only
+    x2 = xv * xv * count_weight;
+  }
+  const double t1 = block_sum256(dx2, sh);
+  const double t2 = block_sum256(x2, sh);
+  if (threadIdx.x == 0) { dx2_partial[blockIdx.x] = t1; x2_partial[blockIdx.x] = t2; }
+}
+
+struct BackPtrs {
+  int A, npb, ncb;
+  const int *pt_first, *o_cb, *o_mb, *pb_pt;
+  const double *lin_r, *lin_Jc, *lin_Jm, *lin_Jp, *ptL, *z, *scale_p, *pt;
+  double* pt_c;
+};
+
+__global__ __launch_bounds__(256) void k_backsub(BackPtrs P, double* __restrict__ mcc_partial, double* __restrict__ dx2_partial,
+                                                  double* __restrict__ x2_partial) {
+  __shared__ double sh[4];
+  const int pb = blockIdx.x * 256 + threadIdx.x;
+  double mcc = 0.0, dx2 = 0.0, x2 = 0.0;
+  if (pb < P.npb) {
+    const size_t A = P.A;
+    const int f = P.pt_first[pb], l = P.pt_first[pb + 1];
+    double y0 = 0, y1 = 0, y2 = 0;
+    for (int i = f; i < l; i++) {
+      double s0 = P.lin_r[i], s1 = P.lin_r[A + i];
+      const int cb = P.o_cb[i], mb = P.o_mb[i];
+      if (cb >= 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const double zj = P.z[6 * cb + j];
+          s0 -= P.lin_Jc[(size_t)j * A + i] * zj;
+          s1 -= P.lin_Jc[(size_t)(6 + j) * A + i] * zj;
+        }
+      }
+      if (mb >= 0) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const double zj = P.z[6 * P.ncb + 3 * mb + j];
+          s0 -= P.lin_Jm[(size_t)j * A + i] * zj;
+          s1 -= P.lin_Jm[(size_t)(3 + j) * A + i] * zj;
+        }
+      }
+      y0 += P.lin_Jp[i] * s0 + P.lin_Jp[3 * A + i] * s1;
+      y1 += P.lin_Jp[A + i] * s0 + P.lin_Jp[4 * A + i] * s1;
+      y2 += P.lin_Jp[2 * A + i] * s0 + P.lin_Jp[5 * A + i] * s1;
+    }
+    const double* L = P.ptL + 6 * (size_t)pb;
+    const double l00 = L[0], l10 = L[1], l11 = L[2], l20 = L[3], l21 = L[4], l22 = L[5];
+    // (L L^T) y' = y
+    double q0 = y0 / l00;
+    double q1 = (y1 - l10 * q0) / l11;
+    double q2 = (y2 - l20 * q0 - l21 * q1) / l22;
+    q2 = q2 / l22;
+    q1 = (q1 - l21 * q2) / l11;
+    q0 = (q0 - l10 * q1 - l20 * q2) / l00;
+    const double sp0 = -q0, sp1 = -q1, sp2 = -q2;  // step (scaled space)
+    const double* sc = P.scale_p + 3 * (size_t)pb;
+    const size_t p = P.pb_pt[pb];
+    const double x0 = P.pt[3 * p], x1 = P.pt[3 * p + 1], x2v = P.pt[3 * p + 2];
+    const double c0 = x0 + sp0 * sc[0], c1 = x1 + sp1 * sc[1], c2 = x2v + sp2 * sc[2];
+    P.pt_c[3 * p] = c0; P.pt_c[3 * p + 1] = c1; P.pt_c[3 * p + 2] = c2;
+    dx2 = (c0 - x0) * (c0 - x0) + (c1 - x1) * (c1 - x1) + (c2 - x2v) * (c2 - x2v);
+    x2 = x0 * x0 + x1 * x1 + x2v * x2v;
+    // model cost change of this point's rows: -(J s)^T (r + J s / 2)
+    for (int i = f; i < l; i++) {
+      double m0 = P.lin_Jp[i] * sp0 + P.lin_Jp[A + i] * sp1 + P.lin_Jp[2 * A + i] * sp2;
+      double m1 = P.lin_Jp[3 * A + i] * sp0 + P.lin_Jp[4 * A + i] * sp1 + P.lin_Jp[5 * A + i] * sp2;
+      const int cb = P.o_cb[i], mb = P.o_mb[i];
+      if (cb >= 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const double sj = -P.z[6 * cb + j];
+          m0 += P.lin_Jc[(size_t)j * A + i] * sj;
+          m1 += P.lin_Jc[(size_t)(6 + j) * A + i] * sj;
+        }
+      }
+      if (mb >= 0) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const double sj = -P.z[6 * P.ncb + 3 * mb + j];
+          m0 += P.lin_Jm[(size_t)j * A + i] * sj;
+          m1 += P.lin_Jm[(size_t)(3 + j) * A + i] * sj;
+        }
+      }
+      mcc -= m0 * (P.lin_r[i] + m0 / 2.0) + m1 * (P.lin_r[A + i] + m1 / 2.0);
+    }
+  }
+  const double t0 = block_sum256(mcc, sh);
+  const double t1 = block_sum256(dx2, sh);
+  const double t2 = block_sum256(x2, sh);
+  if (threadIdx.x == 0) { mcc_partial[blockIdx.x] = t0; dx2_partial[blockIdx.x] = t1; x2_partial[blockIdx.x] = t2; }
+}
+
+// model cost change of rows without an eliminated point (obs [AE, A)) and of the GPS rows.
+__global__ __launch_bounds__(256) void k_mcc_rest(int A, int AE, int ncb, const int* __restrict__ o_cb, const int* __restrict__ o_mb,
+                                                   const double* __restrict__ lin_r, const double* __restrict__ lin_Jc,
+                                                   const double* __restrict__ lin_Jm, const double* __restrict__ z, int has_gps,
+                                                   const double* __restrict__ g_r, const double* __restrict__ g_J,
+                                                   double* __restrict__ mcc_partial) {
+  __shared__ double sh[4];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nrest = A - AE;
+  double mcc = 0.0;
+  if (t < nrest) {
+    const int i = AE + t;
+    const size_t As = A;
+    double m0 = 0, m1 = 0;
+    const int cb = o_cb[i], mb = o_mb[i];
+    if (cb >= 0)
+      for (int j = 0; j < 6; j++) { const double sj = -z[6 * cb + j]; m0 += lin_Jc[(size_t)j * As + i] * sj; m1 += lin_Jc[(size_t)(6 + j) * As + i] * sj; }
+    if (mb >= 0)
+      for (int j = 0; j < 3; j++) { const double sj = -z[6 * ncb + 3 * mb + j]; m0 += lin_Jm[(size_t)j * As + i] * sj; m1 += lin_Jm[(size_t)(3 + j) * As + i] * sj; }
+    mcc -= m0 * (lin_r[i] + m0 / 2.0) + m1 * (lin_r[As + i] + m1 / 2.0);
+  } else if (has_gps && t < nrest + ncb) {
+    const int cb = t - nrest;
+    for (int k = 0; k < 3; k++) {
+      const double m = g_J[3 * (size_t)cb + k] * (-z[6 * cb + 3 + k]);
+      mcc -= m * (g_r[3 * (size_t)cb + k] + m / 2.0);
+    }
+  }
+  const double s = block_sum256(mcc, sh);
+  if (threadIdx.x == 0) mcc_partial[blockIdx.x] = s;
+}
+
+__global__ void k_check_finite(int n, const double* __restrict__ z, int* fail) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !isfinite(z[i])) atomicOr(fail, 4);
+}
+
+__global__ void k_zero_int(int* p) { *p = 0; }
+
+// =======================================================================================
+// Host side
+// =======================================================================================
+struct PairJobs {
+  int n_pairs = 0, n_chunks = 0, n_blocks = 0;
+  DevBuf<int> pa, pb, ch_start, ch_end, blk_row, blk_col, blk_chunk_first;
+  DevBuf<double> partial;
+};
+
+struct msfm_ba {
+  msfm_ctx* ctx = nullptr;
+  int Nc = 0, Nm = 0, Np = 0;
+  int ncb = 0, nmb = 0, npb = 0, nred = 0, npad = 0;
+  int A = 0, AE = 0, NCR = 0, NPM = 0;
+  bool has_gps = false;
+  double gps_weight = 0;
+  int n_residuals = 0;
+  std::vector<int> h_cb_cam, h_mb_model, h_pb_pt;
+  DevBuf<double> cam, model, pt, cam_c, model_c, pt_c;
+  DevBuf<int> cb_cam, mb_model, pb_pt, cb_mb;
+  DevBuf<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
+  DevBuf<double> o_x, o_y, o_w;
+  DevBuf<double> lin_r, lin_Jc, lin_Jm, lin_Jp, camrow, T, Tu, Tm, Tmu;
+  DevBuf<int> cpos_pb;
+  DevBuf<double> scale_c, scale_m, scale_p, diag_c, diag_m, diag_p;
+  DevBuf<int> pt_first, pm_first, pm_mb;
+  DevBuf<double> ptL, ptg;
+  // ftf jobs
+  int n_fchunks = 0;
+  DevBuf<int> f_start, f_end, cam_chunk_first;
+  DevBuf<double> f_partial, camftf, modelsum;
+  DevBuf<int> mcam_first, mcam;
+  PairJobs cc, mc, mm;
+  DevBuf<double> M, Linv, w, z;
+  DevBuf<double> gps, g_r, g_J;
+  DevBuf<double> partial, partial2, partial3, gmax_buf, scal;
+  DevBuf<int> fail;
+  double* h_scal = nullptr;  // pinned
+  int* h_fail = nullptr;
+  int nblk_obs = 0, nblk_pt = 0;
+  double setup_ms = 0;
+  int world_at_create = 1;
+};
+
+static bool is_mut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
+
+// Build chunk / block lists from pair entries already sorted by block key.
+static int finish_jobs(msfm_ba* ba, PairJobs& J, const std::vector<int>& pa, const std::vector<int>& pb,
+                       const std::vector<long>& key_first /*per present block: first entry*/, const std::vector<int>& brow,
+                       const std::vector<int>& bcol, int nout) {
+  hipStream_t s = ba->ctx->stream;
+  J.n_pairs = (int)pa.size();
+  J.n_blocks = (int)brow.size();
+  std::vector<int> cs, ce, bcf(J.n_blocks + 1, 0);
+  for (int b = 0; b < J.n_blocks; b++) {
+    bcf[b] = (int)cs.size();
+    for (long e = key_first[b]; e < key_first[b + 1]; e += CHUNK) {
+      cs.push_back((int)e);
+      ce.push_back((int)std::min<long>(e + CHUNK, key_first[b + 1]));
+    }
+  }
+  bcf[J.n_blocks] = (int)cs.size();
+  J.n_chunks = (int)cs.size();
+  HIP_TRY(ba->ctx, J.pa.from(pa, s));
+  HIP_TRY(ba->ctx, J.pb.from(pb, s));
+  HIP_TRY(ba->ctx, J.ch_start.from(cs, s));
+  HIP_TRY(ba->ctx, J.ch_end.from(ce, s));
+  HIP_TRY(ba->ctx, J.blk_row.from(brow, s));
+  HIP_TRY(ba->ctx, J.blk_col.from(bcol, s));
+  HIP_TRY(ba->ctx, J.blk_chunk_first.from(bcf, s));
+  HIP_TRY(ba->ctx, J.partial.alloc((size_t)std::max(1, J.n_chunks) * nout));
+  HIP_TRY(ba->ctx, hipStreamSynchronize(s));  // host vectors go out of scope
+  return MSFM_OK;
+}
+
+MSFM_API void msfm_ba_options_default(msfm_ba_options* o) {
+  if (!o) return;
+  o->max_num_iterations = 200;
+  o->num_threads = 1;
+  o->progress_to_stdout = 0;
+  o->huber_delta = 1.0;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+}
+
+MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
+  if (!ba) return;
+  (void)hipStreamSynchronize(ba->ctx->stream);
+  if (ba->h_scal) (void)hipHostFree(ba->h_scal);
+  if (ba->h_fail) (void)hipHostFree(ba->h_fail);
+  delete ba;
+}
+
+MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** out) {
+  if (!ctx || !P || !out) return MSFM_E_INVAL;
+  *out = nullptr;
+  if (P->n_cams <= 0 || P->n_models <= 0 || P->n_points < 0 || P->n_obs < 0 || !P->cam_pose || !P->cam_model ||
+      !P->cam_model_of_cam || (P->n_points > 0 && !P->point) ||
+      (P->n_obs > 0 && (!P->obs_cam || !P->obs_pt || !P->obs_xy)))
+    return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_ba_create: null or empty problem arrays");
+  for (int c = 0; c < P->n_cams; c++)
+    if (P->cam_model_of_cam[c] < 0 || P->cam_model_of_cam[c] >= P->n_models)
+      return msfm_set_error(ctx, MSFM_E_INVAL, "cam_model_of_cam[%d] out of range", c);
+  for (int o = 0; o < P->n_obs; o++) {
+    if (P->obs_cam[o] < 0 || P->obs_cam[o] >= P->n_cams || P->obs_pt[o] < 0 || P->obs_pt[o] >= P->n_points)
+      return msfm_set_error(ctx, MSFM_E_INVAL, "observation %d: index out of range", o);
+    if (o > 0 && P->obs_pt[o] < P->obs_pt[o - 1])
+      return msfm_set_error(ctx, MSFM_E_INVAL, "obs_pt must be non-decreasing (gather order, optimizer.cc:62)");
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  msfm_ba* ba = new msfm_ba();
+  struct Guard { msfm_ba* p; ~Guard() { if (p) msfm_ba_destroy(p); } } guard{ba};
+  ba->ctx = ctx;
+  ba->world_at_create = ctx->world;
+  const int Nc = ba->Nc = P->n_cams, Nm = ba->Nm = P->n_models, Np = ba->Np = P->n_points, No = P->n_obs;
+  // ---- which parameter blocks exist (a block exists iff some residual uses it) ----
+  std::vector<int> cam_slot(Nc, -1), model_slot(Nm, -1), pt_slot(Np, -1);
+  {
+    std::vector<char> cu(Nc, 0), mu(Nm, 0), pu(Np, 0);
+    for (int o = 0; o < No; o++) {
+      const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
+      const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
+      if (!cm && !pm) continue;
+      if (pm) pu[p] = 1;
+      if (cm) { cu[c] = 1; if (is_mut(P->model_mutable, m)) mu[m] = 1; }
+    }
+    if (P->gps_xyz) for (int c = 0; c < Nc; c++) if (is_mut(P->cam_mutable, c)) cu[c] = 1;
+    if (ctx->world > 1) {
+      // points are sharded over ranks: the block structure of the reduced system must be the same
+      // everywhere, so every mutable camera / intrinsics block gets a slot whether or not this
+      // rank's shard observes it
+      for (int c = 0; c < Nc; c++) if (is_mut(P->cam_mutable, c)) { cu[c] = 1; if (is_mut(P->model_mutable, P->cam_model_of_cam[c])) mu[P->cam_model_of_cam[c]] = 1; }
+    }
+    for (int c = 0; c < Nc; c++) if (cu[c]) { cam_slot[c] = ba->ncb++; ba->h_cb_cam.push_back(c); }
+    for (int m = 0; m < Nm; m++) if (mu[m]) { model_slot[m] = ba->nmb++; ba->h_mb_model.push_back(m); }
+    for (int p = 0; p < Np; p++) if (pu[p]) { pt_slot[p] = ba->npb++; ba->h_pb_pt.push_back(p); }
+  }
+  const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
+  ba->nred = 6 * ncb + 3 * nmb;
+  ba->npad = 64 * cdiv(ba->nred + 1, 64);
+  ba->has_gps = P->gps_xyz != nullptr;
+  ba->gps_weight = P->gps_weight;
+  // ---- active observations: eliminated-point rows first (point-major), then the rest ----
+  std::vector<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
+  std::vector<double> o_x, o_y, o_w;
+  std::vector<int> pt_first(npb + 1, 0);
+  for (int pass = 0; pass < 2; pass++) {
+    for (int o = 0; o < No; o++) {
+      const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
+      const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
+      if (!cm && !pm) continue;
+      if ((pass == 0) != pm) continue;
+      o_cam.push_back(c); o_model.push_back(m); o_pt.push_back(p);
+      o_cb.push_back(cm ? cam_slot[c] : -1);
+      o_mb.push_back((cm && is_mut(P->model_mutable, m)) ? model_slot[m] : -1);
+      o_pb.push_back(pm ? pt_slot[p] : -1);
+      if (pm) pt_first[pt_slot[p] + 1]++;
+      o_x.push_back(P->obs_xy[2 * (size_t)o]); o_y.push_back(P->obs_xy[2 * (size_t)o + 1]);
+      o_w.push_back(P->pt_weight ? P->pt_weight[p] : 1.0);
+    }
+    if (pass == 0) ba->AE = (int)o_cam.size();
+  }
+  for (int i = 0; i < npb; i++) pt_first[i + 1] += pt_first[i];
+  const int A = ba->A = (int)o_cam.size();
+  ba->n_residuals = 2 * A + (ba->has_gps ? 3 * ncb : 0);
+  // ---- camera-major positions ----
+  std::vector<int> cam_first(ncb + 1, 0);
+  for (int i = 0; i < A; i++) if (o_cb[i] >= 0) cam_first[o_cb[i] + 1]++;
+  for (int c = 0; c < ncb; c++) cam_first[c + 1] += cam_first[c];
+  const int NCR = ba->NCR = cam_first[ncb];
+  o_cpos.assign(A, -1);
+  std::vector<int> cpos_pb(std::max(1, NCR), -1), cpos_cb(std::max(1, NCR), -1);
+  {
+    std::vector<int> fill(cam_first.begin(), cam_first.end() - 1);
+    for (int i = 0; i < A; i++)
+      if (o_cb[i] >= 0) {
+        const int pos = fill[o_cb[i]]++;
+        o_cpos[i] = pos;
+        cpos_pb[pos] = o_pb[i];
+        cpos_cb[pos] = o_cb[i];
+      }
+  }
+  // ---- (point, intrinsics block) entries ----
+  std::vector<int> pm_first(npb + 1, 0), pm_mb;
+  o_pm.assign(A, -1);
+  for (int pb = 0; pb < npb; pb++) {
+    pm_first[pb] = (int)pm_mb.size();
+    int tmp[64];
+    int nt = 0;
+    for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++) {
+      const int mb = o_mb[i];
+      if (mb < 0) continue;
+      bool seen = false;
+      for (int k = 0; k < nt; k++) seen |= tmp[k] == mb;
+      if (!seen) {
+        if (nt == 64) return msfm_set_error(ctx, MSFM_E_INVAL, "point %d touches more than 64 intrinsics blocks", ba->h_pb_pt[pb]);
+        tmp[nt++] = mb;
+      }
+    }
+    std::sort(tmp, tmp + nt);
+    for (int k = 0; k < nt; k++) pm_mb.push_back(tmp[k]);
+    for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++)
+      if (o_mb[i] >= 0)
+        for (int k = 0; k < nt; k++) if (tmp[k] == o_mb[i]) o_pm[i] = pm_first[pb] + k;
+  }
+  pm_first[npb] = (int)pm_mb.size();
+  const int NPM = ba->NPM = (int)pm_mb.size();
+  // ---- FTF chunks (camera-major rows) ----
+  std::vector<int> f_start, f_end, cam_chunk_first(ncb + 1, 0);
+  for (int c = 0; c < ncb; c++) {
+    cam_chunk_first[c] = (int)f_start.size();
+    for (int e = cam_first[c]; e < cam_first[c + 1]; e += CHUNK) { f_start.push_back(e); f_end.push_back(std::min(e + CHUNK, cam_first[c + 1])); }
+  }
+  cam_chunk_first[ncb] = (int)f_start.size();
+  ba->n_fchunks = (int)f_start.size();
+  // cameras of each intrinsics block
+  std::vector<int> cb_mb(std::max(1, ncb), -1), mcam_first(nmb + 1, 0), mcam;
+  for (int cb = 0; cb < ncb; cb++) {
+    const int m = P->cam_model_of_cam[ba->h_cb_cam[cb]];
+    cb_mb[cb] = is_mut(P->model_mutable, m) ? model_slot[m] : -1;
+  }
+  for (int mb = 0; mb < nmb; mb++) {
+    mcam_first[mb] = (int)mcam.size();
+    for (int cb = 0; cb < ncb; cb++) if (cb_mb[cb] == mb) mcam.push_back(cb);
+  }
+  mcam_first[nmb] = (int)mcam.size();
+  // ---- pair lists, counting-sorted by (block row, block col) ----
+  auto build_pairs = [&](int kind, PairJobs& J, int nout) -> int {
+    // kind 0: cam-cam (rows cb_a >= cols cb_b), 1: intr-cam, 2: intr-intr (mb_a >= mb_b)
+    const long nrow = kind == 0 ? ncb : nmb, ncol = kind == 2 ? nmb : ncb;
+    std::vector<long> cnt((size_t)(nrow * ncol) + 1, 0);
+    auto visit = [&](auto&& emit) {
+      for (int pb = 0; pb < npb; pb++) {
+        const int f = pt_first[pb], l = pt_first[pb + 1];
+        if (kind == 0) {
+          for (int i = f; i < l; i++) {
+            if (o_cpos[i] < 0) continue;
+            for (int j = f; j < l; j++) {
+              if (o_cpos[j] < 0) continue;
+              if (o_cb[i] > o_cb[j] || o_cb[i] == o_cb[j]) emit(o_cb[i], o_cb[j], o_cpos[i], o_cpos[j]);
+            }
+          }
+        } else if (kind == 1) {
+          for (int e = pm_first[pb]; e < pm_first[pb + 1]; e++)
+            for (int j = f; j < l; j++) if (o_cpos[j] >= 0) emit(pm_mb[e], o_cb[j], e, o_cpos[j]);
+        } else {
+          for (int e = pm_first[pb]; e < pm_first[pb + 1]; e++)
+            for (int g = pm_first[pb]; g <= e; g++) emit(pm_mb[e], pm_mb[g], e, g);
+        }
+      }
+    };
+    visit([&](int r, int c, int, int) { cnt[(size_t)r * ncol + c + 1]++; });
+    if (kind == 0) for (int c = 0; c < ncb; c++) (void)c;  // diagonal blocks are forced below
+    std::vector<long> first(cnt.size(), 0);
+    for (size_t k = 1; k < cnt.size(); k++) first[k] = first[k - 1] + cnt[k];
+    const long total = first.back();
+    if (total > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_NOMEM, "pair list too long");
+    std::vector<int> pa((size_t)total), pbv((size_t)total);
+    std::vector<long> fill(first.begin(), first.end() - 1);
+    visit([&](int r, int c, int a, int b) { const long q = fill[(size_t)r * ncol + c]++; pa[q] = a; pbv[q] = b; });
+    std::vector<long> key_first;
+    std::vector<int> brow, bcol;
+    for (long r = 0; r < nrow; r++)
+      for (long c = 0; c < ncol; c++) {
+        const size_t k = (size_t)r * ncol + c;
+        const bool force = (kind == 0 || kind == 2) ? (r == c) : (cb_mb[c] == r);  // FTF-only blocks still need assembling
+        if (first[k + 1] > first[k] || force) { key_first.push_back(first[k]); brow.push_back((int)r); bcol.push_back((int)c); }
+      }
+    key_first.push_back(total);
+    // key_first of forced empty blocks must still be monotone: it is (first[k] == first[k+1]).
+    return finish_jobs(ba, J, pa, pbv, key_first, brow, bcol, nout);
+  };
+  // ---- upload ----
+  std::vector<double> gps_cb;
+  if (ba->has_gps) {
+    gps_cb.resize(3 * (size_t)ncb);
+    for (int cb = 0; cb < ncb; cb++) for (int k = 0; k < 3; k++) gps_cb[3 * (size_t)cb + k] = P->gps_xyz[3 * (size_t)ba->h_cb_cam[cb] + k];
+  }
+#define UP(buf, vec) HIP_TRY(ctx, ba->buf.from(vec, s))
+  UP(o_cam, o_cam); UP(o_model, o_model); UP(o_pt, o_pt); UP(o_cb, o_cb); UP(o_mb, o_mb); UP(o_pb, o_pb);
+  UP(o_cpos, o_cpos); UP(o_pm, o_pm); UP(o_x, o_x); UP(o_y, o_y); UP(o_w, o_w);
+  UP(cb_cam, ba->h_cb_cam); UP(mb_model, ba->h_mb_model); UP(pb_pt, ba->h_pb_pt); UP(cb_mb, cb_mb);
+  UP(cpos_pb, cpos_pb); UP(pt_first, pt_first); UP(pm_first, pm_first);
+  if (NPM) UP(pm_mb, pm_mb);
+  UP(f_start, f_start); UP(f_end, f_end); UP(cam_chunk_first, cam_chunk_first);
+  UP(mcam_first, mcam_first);
+  if (!mcam.empty()) UP(mcam, mcam);
+  if (ba->has_gps) UP(gps, gps_cb);
+#undef UP
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  MSFM_TRY(build_pairs(0, ba->cc, 36));
+  MSFM_TRY(build_pairs(1, ba->mc, 18));
+  MSFM_TRY(build_pairs(2, ba->mm, 12));
+  const size_t As = std::max(1, A);
+#define AL(buf, n) HIP_TRY(ctx, ba->buf.alloc((size_t)std::max<size_t>(1, (n))))
+  AL(cam, 6 * (size_t)Nc); AL(model, 3 * (size_t)Nm); AL(pt, 3 * (size_t)std::max(1, Np));
+  AL(cam_c, 6 * (size_t)Nc); AL(model_c, 3 * (size_t)Nm); AL(pt_c, 3 * (size_t)std::max(1, Np));
+  AL(lin_r, 2 * As); AL(lin_Jc, 12 * As); AL(lin_Jm, 6 * As); AL(lin_Jp, 6 * As);
+  AL(camrow, 20 * (size_t)NCR); AL(T, 18 * (size_t)NCR); AL(Tu, 6 * (size_t)NCR);
+  AL(Tm, 9 * (size_t)NPM); AL(Tmu, 3 * (size_t)NPM);
+  AL(scale_c, 6 * (size_t)ncb); AL(scale_m, 3 * (size_t)nmb); AL(scale_p, 3 * (size_t)npb);
+  AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
+  AL(ptL, 6 * (size_t)npb); AL(ptg, 3 * (size_t)npb);
+  AL(f_partial, (size_t)ba->n_fchunks * PSTRIDE); AL(camftf, (size_t)ncb * PSTRIDE); AL(modelsum, 12 * (size_t)nmb);
+  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 64); AL(w, ba->npad); AL(z, ba->npad);
+  AL(g_r, 3 * (size_t)ncb); AL(g_J, 3 * (size_t)ncb);
+  ba->nblk_obs = cdiv(As, 256);
+  ba->nblk_pt = cdiv(std::max(1, npb), 256);
+  const size_t npart = (size_t)ba->nblk_obs + ba->nblk_pt + cdiv(std::max(1, ncb), 256) + 64;
+  AL(partial, npart); AL(partial2, npart); AL(partial3, npart);
+  AL(gmax_buf, (size_t)ba->nblk_pt + 6 * (size_t)ncb + 3 * (size_t)nmb + 8);
+  AL(scal, 16);
+  HIP_TRY(ctx, ba->fail.alloc(4));
+#undef AL
+  HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_scal, 16 * sizeof(double)));
+  HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_fail, 4 * sizeof(int)));
+  HIP_TRY(ctx, hipMemsetAsync(ba->camrow.p, 0, sizeof(double) * std::max<size_t>(1, 20 * (size_t)NCR), s));
+  HIP_TRY(ctx, hipMemsetAsync(ba->T.p, 0, sizeof(double) * std::max<size_t>(1, 18 * (size_t)NCR), s));
+  HIP_TRY(ctx, hipMemsetAsync(ba->Tu.p, 0, sizeof(double) * std::max<size_t>(1, 6 * (size_t)NCR), s));
+  HIP_TRY(ctx, hipMemcpyAsync(ba->cam.p, P->cam_pose, sizeof(double) * 6 * (size_t)Nc, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemcpyAsync(ba->model.p, P->cam_model, sizeof(double) * 3 * (size_t)Nm, hipMemcpyHostToDevice, s));
+  if (Np) HIP_TRY(ctx, hipMemcpyAsync(ba->pt.p, P->point, sizeof(double) * 3 * (size_t)Np, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  ba->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  guard.p = nullptr;
+  *out = ba;
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_ba_upload_params(msfm_ba* ba, const double* cam_pose, const double* cam_model, const double* point) {
+  if (!ba) return MSFM_E_INVAL;
+  msfm_ctx* ctx = ba->ctx;
+  hipStream_t s = ctx->stream;
+  if (cam_pose) HIP_TRY(ctx, hipMemcpyAsync(ba->cam.p, cam_pose, sizeof(double) * 6 * (size_t)ba->Nc, hipMemcpyHostToDevice, s));
+  if (cam_model) HIP_TRY(ctx, hipMemcpyAsync(ba->model.p, cam_model, sizeof(double) * 3 * (size_t)ba->Nm, hipMemcpyHostToDevice, s));
+  if (point && ba->Np) HIP_TRY(ctx, hipMemcpyAsync(ba->pt.p, point, sizeof(double) * 3 * (size_t)ba->Np, hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_ba_download_params(msfm_ba* ba, double* cam_pose, double* cam_model, double* point) {
+  if (!ba) return MSFM_E_INVAL;
+  msfm_ctx* ctx = ba->ctx;
+  hipStream_t s = ctx->stream;
+  if (cam_pose) HIP_TRY(ctx, hipMemcpyAsync(cam_pose, ba->cam.p, sizeof(double) * 6 * (size_t)ba->Nc, hipMemcpyDeviceToHost, s));
+  if (cam_model) HIP_TRY(ctx, hipMemcpyAsync(cam_model, ba->model.p, sizeof(double) * 3 * (size_t)ba->Nm, hipMemcpyDeviceToHost, s));
+  if (point && ba->Np) HIP_TRY(ctx, hipMemcpyAsync(point, ba->pt.p, sizeof(double) * 3 * (size_t)ba->Np, hipMemcpyDeviceToHost, s));
+  HIP_TRY(ctx, hipStreamSynchronize(s));
+  return MSFM_OK;
+}
+
+// ---- phases ----------------------------------------------------------------------------
+static BaPtrs make_ptrs(msfm_ba* ba, bool candidate, double huber) {
+  BaPtrs P;
+  P.A = ba->A; P.AE = ba->AE; P.ncb = ba->ncb; P.nmb = ba->nmb; P.npb = ba->npb; P.NCR = ba->NCR;
+  P.cam = candidate ? ba->cam_c.p : ba->cam.p;
+  P.model = candidate ? ba->model_c.p : ba->model.p;
+  P.pt = candidate ? ba->pt_c.p : ba->pt.p;
+  P.o_cam = ba->o_cam.p; P.o_model = ba->o_model.p; P.o_pt = ba->o_pt.p; P.o_cb = ba->o_cb.p; P.o_mb = ba->o_mb.p;
+  P.o_pb = ba->o_pb.p; P.o_cpos = ba->o_cpos.p; P.o_pm = ba->o_pm.p;
+  P.o_x = ba->o_x.p; P.o_y = ba->o_y.p; P.o_w = ba->o_w.p;
+  P.lin_r = ba->lin_r.p; P.lin_Jc = ba->lin_Jc.p; P.lin_Jm = ba->lin_Jm.p; P.lin_Jp = ba->lin_Jp.p; P.camrow = ba->camrow.p;
+  P.scale_c = ba->scale_c.p; P.scale_m = ba->scale_m.p; P.scale_p = ba->scale_p.p;
+  P.huber = huber;
+  return P;
+}
+
+static int allreduce(msfm_ba* ba, double* buf, size_t count, int op) {
+  msfm_ctx* ctx = ba->ctx;
+  if (ctx->world <= 1) return MSFM_OK;
+  KTimer t(ctx, count > 4096 ? "ba_allreduce_system" : "ba_allreduce_small");
+  const int rc = ctx->allreduce(ctx->allreduce_user, buf, count, op, (void*)ctx->stream);
+  if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce hook failed: %d", rc);
+  return MSFM_OK;
+}
+
+// cost (and, with jac, the stored linearisation) at x or at the candidate -> scal[S_COST]
+// (local partial; summed over ranks by the caller together with the other scalars)
+static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber) {
+  msfm_ctx* ctx = ba->ctx;
+  hipStream_t s = ctx->stream;
+  const bool lead = ctx->rank == 0;
+  // every rank needs the GPS rows' Jacobian (k_cam_post uses g_J via camftf only on the lead), but
+  // only the lead rank counts their cost
+  const int nb = ba->nblk_obs, ng = ba->has_gps ? cdiv(ba->ncb, 256) : 0;
+  BaPtrs P = make_ptrs(ba, candidate, huber);
+  {
+    KTimer t(ctx, jac ? "ba_linearize" : "ba_cost");
+    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb), dim3(256), 0, s, P, ba->partial.p);
+    else hipLaunchKernelGGL(k_linearize<false>, dim3(nb), dim3(256), 0, s, P, ba->partial.p);
+    if (ng) {
+      if (jac) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
+      else hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
+    }
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->scal.p, S_COST, 0);
+  }
+  return MSFM_OK;
+}
+
+// point kernel + camera sums (+, for mode 0, the reduced system in M)
+static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, bool reuse_diag, int mode) {
+  msfm_ctx* ctx = ba->ctx;
+  hipStream_t s = ctx->stream;
+  const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
+  const int lead = ctx->rank == 0 ? 1 : 0;
+  {
+    KTimer t(ctx, "ba_point");
+    PointPtrs Q;
+    Q.A = ba->A; Q.npb = npb; Q.pt_first = ba->pt_first.p; Q.o_cpos = ba->o_cpos.p; Q.o_mb = ba->o_mb.p;
+    Q.pm_first = ba->pm_first.p; Q.pm_mb = ba->pm_mb.p;
+    Q.lin_r = ba->lin_r.p; Q.lin_Jc = ba->lin_Jc.p; Q.lin_Jm = ba->lin_Jm.p; Q.lin_Jp = ba->lin_Jp.p;
+    Q.diag_p = ba->diag_p.p; Q.scale_p = ba->scale_p.p; Q.ptL = ba->ptL.p; Q.ptg = ba->ptg.p;
+    Q.T = ba->T.p; Q.Tu = ba->Tu.p; Q.Tm = ba->Tm.p; Q.Tmu = ba->Tmu.p;
+    Q.radius = radius; Q.dmin = opt->min_lm_diagonal; Q.dmax = opt->max_lm_diagonal;
+    Q.reuse_diag = reuse_diag; Q.mode = mode; Q.fail = ba->fail.p;
+    hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, s, Q, ba->gmax_buf.p);
+  }
+  double* gmax_c = ba->gmax_buf.p + ba->nblk_pt;
+  double* gmax_m = gmax_c + 6 * (size_t)ncb;
+  {
+    KTimer t(ctx, "ba_ftf");
+    if (ba->n_fchunks)
+      hipLaunchKernelGGL(k_ftf, dim3(cdiv(ba->n_fchunks, 4)), dim3(256), 0, s, ba->n_fchunks, ba->f_start.p, ba->f_end.p,
+                         ba->camrow.p, ba->Tu.p, ba->cpos_pb.p, ba->f_partial.p);
+    if (ncb)
+      hipLaunchKernelGGL(k_camftf, dim3(ncb), dim3(128), 0, s, ncb, ba->cam_chunk_first.p, ba->f_partial.p, ba->camftf.p,
+                         ba->g_r.p, ba->g_J.p, (ba->has_gps && lead) ? 1 : 0);
+  }
+  if (ncb) MSFM_TRY(allreduce(ba, ba->camftf.p, (size_t)ncb * PSTRIDE, MSFM_REDUCE_SUM));  // per-camera sums over all shards
+  {
+    KTimer t(ctx, "ba_ftf");
+    if (ncb)
+      hipLaunchKernelGGL(k_cam_post, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, ncb, ba->camftf.p, ba->diag_c.p, ba->scale_c.p,
+                         reuse_diag ? 1 : 0, mode, opt->min_lm_diagonal, opt->max_lm_diagonal, gmax_c);
+    if (nmb)
+      hipLaunchKernelGGL(k_modelsum, dim3(nmb), dim3(64), 0, s, ba->mcam_first.p, ba->mcam.p, ba->camftf.p, ba->modelsum.p,
+                         ba->diag_m.p, ba->scale_m.p, reuse_diag ? 1 : 0, mode, opt->min_lm_diagonal, opt->max_lm_diagonal, gmax_m);
+  }
+  if (mode == 1) return MSFM_OK;
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, ba->scal.p,
+                     S_GMAX, 1);
+  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->scal.p, S_FAIL);
+  {
+    KTimer t(ctx, "ba_schur_pairs");
+    if (ba->cc.n_chunks)
+      hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, s, ba->cc.n_chunks, ba->cc.ch_start.p,
+                         ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, ba->cc.partial.p);
+    if (ba->mc.n_chunks)
+      hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->mc.n_chunks, 4)), dim3(256), 0, s, ba->mc.n_chunks, ba->mc.ch_start.p,
+                         ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, ba->mc.partial.p);
+    if (ba->mm.n_chunks)
+      hipLaunchKernelGGL((k_pairs<3, 3, true>), dim3(cdiv(ba->mm.n_chunks, 4)), dim3(256), 0, s, ba->mm.n_chunks, ba->mm.ch_start.p,
+                         ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, ba->mm.partial.p);
+  }
+  {
+    KTimer t(ctx, "ba_assemble");
+    HIP_TRY(ctx, hipMemsetAsync(ba->M.p, 0, sizeof(double) * (size_t)ba->npad * ba->npad, s));
+    if (ba->cc.n_blocks)
+      hipLaunchKernelGGL(k_asm_cc, dim3(ba->cc.n_blocks), dim3(64), 0, s, ba->cc.blk_row.p, ba->cc.blk_col.p, ba->cc.blk_chunk_first.p,
+                         ba->cc.partial.p, ba->camftf.p, ba->diag_c.p, radius, ba->M.p, ba->npad, lead);
+    if (ba->mc.n_blocks)
+      hipLaunchKernelGGL(k_asm_mc, dim3(ba->mc.n_blocks), dim3(64), 0, s, ba->mc.blk_row.p, ba->mc.blk_col.p, ba->mc.blk_chunk_first.p,
+                         ba->mc.partial.p, ba->camftf.p, ba->cb_mb.p, ncb, ba->M.p, ba->npad, lead);
+    if (ba->mm.n_blocks)
+      hipLaunchKernelGGL(k_asm_mm, dim3(ba->mm.n_blocks), dim3(64), 0, s, ba->mm.blk_row.p, ba->mm.blk_col.p, ba->mm.blk_chunk_first.p,
+                         ba->mm.partial.p, ba->modelsum.p, ba->diag_m.p, radius, ncb, ba->nred, ba->M.p, ba->npad, lead);
+    if (ncb) hipLaunchKernelGGL(k_asm_rhs_cam, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, ncb, ba->camftf.p, ba->M.p, ba->npad, ba->nred, lead);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "assemble launch: %s", hipGetErrorString(e));
+  // rows [0, nred] of M (S and the rhs row) are contiguous: one sum over ranks
+  MSFM_TRY(allreduce(ba, ba->M.p, (size_t)(ba->nred + 1) * ba->npad, MSFM_REDUCE_SUM));
+  MSFM_TRY(allreduce(ba, ba->scal.p + S_GMAX, 2, MSFM_REDUCE_MAX));
+  return MSFM_OK;
+}
+
+static int read_scalars(msfm_ba* ba) {
+  msfm_ctx* ctx = ba->ctx;
+  HIP_TRY(ctx, hipMemcpyAsync(ba->h_scal, ba->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSFM_OK;
+}
+
+// factor + solve + candidate + model cost change + candidate cost
+static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
+  msfm_ctx* ctx = ba->ctx;
+  hipStream_t s = ctx->stream;
+  const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
+  const bool lead = ctx->rank == 0;
+  if (ba->nred > 0) {
+    MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nred, ba->Linv.p, ba->w.p, ba->z.p, ba->fail.p));
+    hipLaunchKernelGGL(k_check_finite, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ba->nred, ba->z.p, ba->fail.p);
+  }
+  {
+    KTimer t(ctx, "ba_backsub");
+    const int nbc = cdiv(std::max(1, 6 * ncb), 256), nbm = cdiv(std::max(1, 3 * nmb), 256), nbp = ba->nblk_pt;
+    // candidate buffers start as copies of x so inactive blocks carry over
+    HIP_TRY(ctx, hipMemcpyAsync(ba->cam_c.p, ba->cam.p, sizeof(double) * 6 * (size_t)ba->Nc, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ba->model_c.p, ba->model.p, sizeof(double) * 3 * (size_t)ba->Nm, hipMemcpyDeviceToDevice, s));
+    if (ba->Np) HIP_TRY(ctx, hipMemcpyAsync(ba->pt_c.p, ba->pt.p, sizeof(double) * 3 * (size_t)ba->Np, hipMemcpyDeviceToDevice, s));
+    int off = 0;
+    const double wrep = lead ? 1.0 : 0.0;
+    // partial2 = |dx|^2 partials, partial3 = |x|^2 partials, partial = model cost partials
+    if (ncb) { hipLaunchKernelGGL(k_update_blocks, dim3(nbc), dim3(256), 0, s, ncb, 6, ba->cb_cam.p, ba->z.p, 0, ba->scale_c.p, ba->cam.p, ba->cam_c.p, ba->partial2.p + off, ba->partial3.p + off, wrep); off += nbc; }
+    if (nmb) { hipLaunchKernelGGL(k_update_blocks, dim3(nbm), dim3(256), 0, s, nmb, 3, ba->mb_model.p, ba->z.p, 6 * ncb, ba->scale_m.p, ba->model.p, ba->model_c.p, ba->partial2.p + off, ba->partial3.p + off, wrep); off += nbm; }
+    int moff = 0;
+    if (npb) {
+      BackPtrs Q;
+      Q.A = ba->A; Q.npb = npb; Q.ncb = ncb; Q.pt_first = ba->pt_first.p; Q.o_cb = ba->o_cb.p; Q.o_mb = ba->o_mb.p; Q.pb_pt = ba->pb_pt.p;
+      Q.lin_r = ba->lin_r.p; Q.lin_Jc = ba->lin_Jc.p; Q.lin_Jm = ba->lin_Jm.p; Q.lin_Jp = ba->lin_Jp.p; Q.ptL = ba->ptL.p; Q.z = ba->z.p;
+      Q.scale_p = ba->scale_p.p; Q.pt = ba->pt.p; Q.pt_c = ba->pt_c.p;
+      hipLaunchKernelGGL(k_backsub, dim3(nbp), dim3(256), 0, s, Q, ba->partial.p, ba->partial2.p + off, ba->partial3.p + off);
+      off += nbp; moff += nbp;
+    }
+    const int ngps = (ba->has_gps && lead) ? ncb : 0;
+    const int nrest = (ba->A - ba->AE) + ngps;
+    if (nrest) {
+      hipLaunchKernelGGL(k_mcc_rest, dim3(cdiv(nrest, 256)), dim3(256), 0, s, ba->A, ba->AE, ncb, ba->o_cb.p, ba->o_mb.p, ba->lin_r.p,
+                         ba->lin_Jc.p, ba->lin_Jm.p, ba->z.p, ngps ? 1 : 0, ba->g_r.p, ba->g_J.p, ba->partial.p + moff);
+      moff += cdiv(nrest, 256);
+    }
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial.p, moff, ba->scal.p, S_MCC, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial2.p, off, ba->scal.p, S_DX2, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial3.p, off, ba->scal.p, S_X2, 0);
+  }
+  MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/false, opt->huber_delta));
+  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->scal.p, S_FAIL);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "solve launch: %s", hipGetErrorString(e));
+  MSFM_TRY(allreduce(ba, ba->scal.p + S_COST, 4, MSFM_REDUCE_SUM));
+  MSFM_TRY(allreduce(ba, ba->scal.p + S_FAIL, 1, MSFM_REDUCE_MAX));
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summary* sum) {
+  if (!ba || !opt || !sum) return MSFM_E_INVAL;
+  msfm_ctx* ctx = ba->ctx;
+  if (ctx->world != ba->world_at_create)
+    return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_ctx_set_allreduce must be called before msfm_ba_create");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  hipEvent_t ev0, ev1;
+  HIP_TRY(ctx, hipEventCreate(&ev0));
+  HIP_TRY(ctx, hipEventCreate(&ev1));
+  HIP_TRY(ctx, hipEventRecord(ev0, s));
+  sum->num_residuals = ba->n_residuals;
+  sum->num_reduced_params = ba->nred;
+  sum->num_successful_steps = sum->num_unsuccessful_steps = 0;
+  sum->setup_ms = ba->setup_ms;
+  int rows = 0;
+  auto push = [&](const msfm_ba_iteration& it) {
+    if (sum->iterations && rows < sum->iterations_capacity) sum->iterations[rows] = it;
+    rows++;
+  };
+  const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
+  auto fill_ones = [&](DevBuf<double>& b, size_t n) -> int {
+    std::vector<double> ones(std::max<size_t>(1, n), 1.0);
+    HIP_TRY(ctx, hipMemcpyAsync(b.p, ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MSFM_OK;
+  };
+  MSFM_TRY(fill_ones(ba->scale_c, 6 * (size_t)ncb));
+  MSFM_TRY(fill_ones(ba->scale_m, 3 * (size_t)nmb));
+  MSFM_TRY(fill_ones(ba->scale_p, 3 * (size_t)npb));
+  hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
+  double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
+  bool reuse_diag = false;
+  // ---- IterationZero ----
+  MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta));
+  if (opt->jacobi_scaling) {
+    // squared column norms of the corrected, unscaled Jacobian -> scaling -> re-linearise scaled
+    MSFM_TRY(run_assemble(ba, opt, radius, false, /*mode=*/1));
+    if (ncb) hipLaunchKernelGGL(k_make_scale, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, 6 * ncb, ba->diag_c.p, ba->scale_c.p);
+    if (nmb) hipLaunchKernelGGL(k_make_scale, dim3(cdiv(3 * nmb, 256)), dim3(256), 0, s, 3 * nmb, ba->diag_m.p, ba->scale_m.p);
+    if (npb) hipLaunchKernelGGL(k_make_scale, dim3(cdiv(3 * npb, 256)), dim3(256), 0, s, 3 * npb, ba->diag_p.p, ba->scale_p.p);
+    MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta));
+  }
+  MSFM_TRY(allreduce(ba, ba->scal.p + S_COST, 1, MSFM_REDUCE_SUM));
+  MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0));
+  MSFM_TRY(read_scalars(ba));
+  double x_cost = ba->h_scal[S_COST];
+  msfm_ba_iteration it;
+  memset(&it, 0, sizeof it);
+  it.cost = x_cost; it.gradient_max_norm = ba->h_scal[S_GMAX]; it.trust_region_radius = radius;
+  it.step_is_valid = 1; it.step_is_successful = 1;
+  sum->initial_cost = x_cost;
+  int iteration = 0, num_invalid = 0, termination = 0;
+  for (;;) {
+    if (it.step_is_successful && iteration > 0) sum->num_successful_steps++;
+    it.trust_region_radius = radius;
+    push(it);
+    if (opt->progress_to_stdout && ctx->rank == 0)
+      printf("%4d  cost %.6e  change %.3e  |grad| %.3e  |step| %.3e  rho %.3e  radius %.3e\n", iteration, it.cost,
+             it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, radius);
+    if (iteration >= opt->max_num_iterations) { termination = MSFM_BA_NO_CONVERGENCE; break; }
+    if (it.gradient_max_norm <= opt->gradient_tolerance) { termination = MSFM_BA_CONVERGENCE_GRADIENT; break; }
+    if (radius <= opt->min_trust_region_radius) { termination = MSFM_BA_MIN_RADIUS; break; }
+    const double prev_gmax = it.gradient_max_norm;
+    memset(&it, 0, sizeof it);
+    iteration++;
+    // ---- ComputeTrustRegionStep ----
+    const bool assembled_ok = ((int)ba->h_scal[S_FAIL] & 2) == 0;  // every 3x3 point block was positive definite
+    bool solved = false;
+    double mcc = 0, cand_cost = 0, dx2 = 0, x2 = 0;
+    if (assembled_ok) {
+      MSFM_TRY(run_solve(ba, opt));
+      MSFM_TRY(read_scalars(ba));
+      solved = (int)ba->h_scal[S_FAIL] == 0;
+      mcc = ba->h_scal[S_MCC]; cand_cost = ba->h_scal[S_COST]; dx2 = ba->h_scal[S_DX2]; x2 = ba->h_scal[S_X2];
+    }
+    it.step_is_valid = solved && (mcc > 0.0);
+    bool relinearise = false;
+    if (!it.step_is_valid) {
+      if (++num_invalid >= opt->max_num_consecutive_invalid_steps) { termination = MSFM_BA_FAILURE; break; }
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
+      it.cost = x_cost; it.gradient_max_norm = prev_gmax;
+      sum->num_unsuccessful_steps++;
+    } else {
+      num_invalid = 0;
+      it.step_norm = std::sqrt(dx2);
+      const double x_norm = std::sqrt(x2);
+      if (it.step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { termination = MSFM_BA_CONVERGENCE_PARAMETER; break; }
+      it.cost_change = x_cost - cand_cost;
+      if (std::fabs(it.cost_change) <= opt->function_tolerance * x_cost) { termination = MSFM_BA_CONVERGENCE_FUNCTION; break; }
+      it.relative_decrease = (x_cost - cand_cost) / mcc;
+      if (it.relative_decrease > opt->min_relative_decrease) {
+        std::swap(ba->cam.p, ba->cam_c.p); std::swap(ba->model.p, ba->model_c.p); std::swap(ba->pt.p, ba->pt_c.p);
+        relinearise = true;
+        it.step_is_successful = 1;
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
+        radius = std::min(opt->max_trust_region_radius, radius);
+        decrease_factor = 2.0; reuse_diag = false;
+      } else {
+        it.step_is_successful = 0; it.cost = cand_cost; it.gradient_max_norm = prev_gmax;
+        radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diag = true;
+        sum->num_unsuccessful_steps++;
+      }
+    }
+    // ---- next reduced system (new Jacobian after a successful step, else new radius only) ----
+    hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
+    if (relinearise) {
+      MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta));
+      MSFM_TRY(allreduce(ba, ba->scal.p + S_COST, 1, MSFM_REDUCE_SUM));
+    }
+    MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0));
+    MSFM_TRY(read_scalars(ba));
+    if (relinearise) {
+      x_cost = ba->h_scal[S_COST];
+      it.cost = x_cost;
+      it.gradient_max_norm = ba->h_scal[S_GMAX];
+    }
+  }
+  sum->termination = termination;
+  sum->num_iterations = rows - 1;
+  sum->final_cost = x_cost;
+  HIP_TRY(ctx, hipEventRecord(ev1, s));
+  HIP_TRY(ctx, hipEventSynchronize(ev1));
+  float ms = 0;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, ev0, ev1));
+  sum->solve_ms = ms;
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_ba_solve(msfm_ctx* ctx, msfm_ba_problem* problem, const msfm_ba_options* options, msfm_ba_summary* summary) {
+  if (!ctx || !problem || !options || !summary) return MSFM_E_INVAL;
+  msfm_ba* ba = nullptr;
+  MSFM_TRY(msfm_ba_create(ctx, problem, &ba));
+  int rc = msfm_ba_run(ba, options, summary);
+  if (rc == MSFM_OK) rc = msfm_ba_download_params(ba, problem->cam_pose, problem->cam_model, problem->point);
+  msfm_ba_destroy(ba);
+  return rc;
+}

@@ -1,0 +1,90 @@
+// Internal header of libmsfm (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msfm.h"
+
+#define MSFM_API extern "C" __attribute__((visibility("default")))
+
+struct msfm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // multi-GPU hook
+  msfm_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  int rank = 0, world = 1;
+  // per-kernel-class timing (HIP events on `stream`)
+  bool profile = false;
+  struct Stat { std::string name; uint64_t launches = 0; double ms = 0; };
+  std::vector<Stat> stats;
+  struct Pending { int stat; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+
+int msfm_set_error(msfm_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return msfm_set_error((ctx), MSFM_E_DEVICE, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,  \
+                            hipGetErrorString(e_));                                             \
+  } while (0)
+
+#define MSFM_TRY(expr)            \
+  do {                            \
+    int rc_ = (expr);             \
+    if (rc_ != MSFM_OK) return rc_; \
+  } while (0)
+
+// Scoped kernel-class timer: records two events around a group of launches when
+// profiling is on; resolved lazily in msfm_ctx_profile_get.
+struct KTimer {
+  msfm_ctx* ctx;
+  int idx = -1;
+  hipEvent_t a = nullptr, b = nullptr;
+  KTimer(msfm_ctx* c, const char* name);
+  ~KTimer();
+};
+
+// Simple owning device buffer.
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  hipError_t upload(const T* h, size_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    return hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+  hipError_t from(const std::vector<T>& v, hipStream_t s) {
+    hipError_t e = alloc(v.size());
+    if (e != hipSuccess) return e;
+    return upload(v.data(), v.size(), s);
+  }
+};
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

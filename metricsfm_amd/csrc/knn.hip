@@ -1,0 +1,457 @@
+// Exhaustive 2-nearest-neighbour descriptor matching on MI355X.
+// Replaces flann_build_index + flann_find_nearest_neighbors_index
+// (SfM/src/graph/fine_matching_graph.cc:72-81,99; SfM/src/slam_gps.cc:438-447,463) and fuses
+// the ratio tests of fine_matching_graph.cc:116-133.
+//
+// Fast path (descriptors integer-valued in [0,255], e.g. SIFT bytes stored as float):
+//   d(a,b) = |a|^2 + |b|^2 - 2 a.b is evaluated as a bf16 MFMA GEMM with fp32 accumulators;
+//   every operand (<= 255, and -2*b <= 510) is exact in bf16 and every partial sum is an
+//   integer below 2^24, so the distances are exact and the indices identical to a binary64
+//   brute force.  One workgroup = 4 waves = 128 query descriptors of one image pair; each
+//   wave keeps its 32 queries as MFMA B fragments in registers for the whole sweep, train
+//   descriptors stream through an XOR-swizzled LDS tile shared by the 4 waves; the running
+//   top-2 per query lives in packed (distance << 8 | row) keys, 4 VALU ops per candidate.
+// General path (any float32 descriptors): exact binary64 brute force, sequential in k —
+//   bit-identical to the oracle's definition; slow, used only when the data is not integral.
+#include <algorithm>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32;
+
+#define DIM 128
+#define TT 64          // train rows per LDS tile
+#define WIN 256        // rows per packed-key window
+#define QPB 128        // queries per workgroup
+#define NORM_BIAS 8388608.0f  // 2^23: keeps a2 - 2ab positive for the integer key
+
+struct msfm_descset {
+  msfm_ctx* ctx;
+  int n_images, dim;
+  std::vector<int> count;
+  std::vector<DevBuf<float>*> f32;       // [count][dim]
+  std::vector<DevBuf<unsigned short>*> bf16;  // [count][dim], train copy (plain) — query copy is scaled by -2 on load
+  std::vector<DevBuf<float>*> norm;      // [count]  |a|^2
+  DevBuf<int> nonint;                    // OR of "not integer in [0,255]" over all uploads
+  int h_nonint = 0;
+};
+
+// ---- prep: f32 -> bf16, squared norms, integrality flag -------------------------------
+__global__ __launch_bounds__(256) void k_desc_prep(const float* __restrict__ d, int count, unsigned short* __restrict__ out,
+                                                    float* __restrict__ norm, int* __restrict__ nonint) {
+  // one wave per row, lane handles 2 of the 128 values
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= count) return;
+  const float2 v = reinterpret_cast<const float2*>(d + (size_t)row * DIM)[lane];
+  const bool bad = !(v.x >= 0.f && v.x <= 255.f && v.x == truncf(v.x) && v.y >= 0.f && v.y <= 255.f && v.y == truncf(v.y));
+  if (bad) atomicOr(nonint, 1);
+  ushort2 o;
+  o.x = (unsigned short)(__float_as_uint(v.x) >> 16);  // exact for integers <= 255 (low mantissa bits are zero)
+  o.y = (unsigned short)(__float_as_uint(v.y) >> 16);
+  reinterpret_cast<ushort2*>(out + (size_t)row * DIM)[lane] = o;
+  float s = v.x * v.x + v.y * v.y;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) norm[row] = s;
+}
+
+// ---- fast path --------------------------------------------------------------------------
+struct PairTask {
+  const unsigned short* train;  // bf16 [n_train][128]
+  const unsigned short* query;
+  const float* tnorm;
+  const float* qnorm;
+  int n_train, n_query;
+  int out_off;                  // offset of this pair's queries in the flat outputs
+};
+
+__device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) {
+  u32 r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// merge candidate (d, i) into the sorted pair (d0,i0) <= (d1,i1); ties keep the earlier (lower index first)
+__device__ __forceinline__ void top2_insert(u32& d0, int& i0, u32& d1, int& i1, u32 d, int i) {
+  const bool lt0 = d < d0 || (d == d0 && i < i0);
+  const bool lt1 = d < d1 || (d == d1 && i < i1);
+  if (lt0) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+  else if (lt1) { d1 = d; i1 = i; }
+}
+
+__global__ __launch_bounds__(256, 2) void k_knn2_bf16(const PairTask* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+                                                       float ratio_good, float ratio_all, int32_t* __restrict__ code,
+                                                       int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ n_all,
+                                                       int* __restrict__ n_good) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[TT * 256];
+  __shared__ __attribute__((aligned(16))) float lds_n[TT];
+  // which pair does this workgroup belong to (binary search on the tile prefix)
+  int lo = 0, hi = n_pairs - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_first[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int pair = lo;
+  const PairTask T = tasks[pair];
+  const int q0 = (bid - tile_first[pair]) * QPB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  // ---- this lane's query as B fragments, scaled by -2 (exact: exponent + 1, sign flip) ----
+  const int q = q0 + wave * 32 + r;
+  const bool qvalid = q < T.n_query;
+  bf16x8 bq[8];
+  {
+    const unsigned short* qp = T.query + (size_t)(qvalid ? q : 0) * DIM;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(qp + ks * 16 + h * 8);
+      u32 w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        // each 16-bit half: bf16 v -> -2v  (v == 0 stays +0: adding to the exponent of zero would make garbage)
+        u32 lo16 = w[j] & 0xffffu, hi16 = w[j] >> 16;
+        lo16 = lo16 ? ((lo16 + 0x0080u) | 0x8000u) : 0u;
+        hi16 = hi16 ? ((hi16 + 0x0080u) | 0x8000u) : 0u;
+        w[j] = lo16 | (hi16 << 16);
+      }
+      bq[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+    }
+  }
+  u32 D0 = 0xffffffffu, D1 = 0xffffffffu;  // global top-2 of this lane: biased distance, row
+  int I0 = 0x7fffffff, I1 = 0x7fffffff;
+  u32 k0 = 0xffffffffu, k1 = 0xffffffffu;  // packed keys of the current window
+  const int n_tiles = (T.n_train + TT - 1) / TT;
+  for (int tile = 0; tile < n_tiles; tile++) {
+    const int t0 = tile * TT;
+    __syncthreads();  // previous tile fully consumed
+    // stage 64 train rows (16 KB): 1024 16-byte chunks, XOR-swizzled per row
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i;
+      const int row = c >> 4, ch = c & 15;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (t0 + row < T.n_train) v = *reinterpret_cast<const uint4*>(T.train + (size_t)(t0 + row) * DIM + ch * 8);
+      *reinterpret_cast<uint4*>(lds_a + row * 256 + ((ch ^ (row & 15)) << 4)) = v;
+    }
+    if (tid < TT) lds_n[tid] = (t0 + tid < T.n_train) ? T.tnorm[t0 + tid] + NORM_BIAS : 16777215.0f;  // padding: above every real biased distance, still an exact integer
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+      // C-in = |a|^2 + 2^23 of the 16 rows this lane's accumulators cover
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 nv = *reinterpret_cast<const f32x4*>(&lds_n[st * 32 + 8 * g + 4 * h]);
+        acc[4 * g + 0] = nv.x; acc[4 * g + 1] = nv.y; acc[4 * g + 2] = nv.z; acc[4 * g + 3] = nv.w;
+      }
+      const int row = st * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        const int ch = 2 * ks + h;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds_a + row * 256 + ((ch ^ (row & 15)) << 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+      }
+      // running top-2 on packed keys: (biased distance << 8) | row-in-window (without the 4h term)
+      const int wbase = ((tile & 3) * 2 + st) * 32;
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const u32 u = (u32)acc[reg];  // v_cvt_u32_f32 of an exact integer < 2^24
+        const u32 key = (u << 8) | (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
+        const u32 nk0 = min(k0, key);
+        k1 = umed3(k0, k1, key);
+        k0 = nk0;
+      }
+    }
+    if ((tile & 3) == 3 || tile == n_tiles - 1) {
+      const int base = (tile & ~3) * TT + 4 * h;
+      if (k0 != 0xffffffffu) top2_insert(D0, I0, D1, I1, k0 >> 8, base + (int)(k0 & 255u));
+      if (k1 != 0xffffffffu) top2_insert(D0, I0, D1, I1, k1 >> 8, base + (int)(k1 & 255u));
+      k0 = k1 = 0xffffffffu;
+    }
+  }
+  // merge the two lane halves (rows 4h+..) of each query
+  {
+    const u32 pd0 = __shfl_xor(D0, 32, 64), pd1 = __shfl_xor(D1, 32, 64);
+    const int pi0 = __shfl_xor(I0, 32, 64), pi1 = __shfl_xor(I1, 32, 64);
+    top2_insert(D0, I0, D1, I1, pd0, pi0);
+    top2_insert(D0, I0, D1, I1, pd1, pi1);
+  }
+  if (h == 0 && qvalid) {
+    const int b2 = (int)T.qnorm[q];
+    const float d0 = (float)((int)D0 - 8388608 + b2), d1 = (float)((int)D1 - 8388608 + b2);
+    const size_t o = (size_t)T.out_off + q;
+    if (ids) { ids[2 * o] = I0; ids[2 * o + 1] = I1; sqd[2 * o] = d0; sqd[2 * o + 1] = d1; }
+    if (code) {
+      const float ratio = d0 / d1;  // fine_matching_graph.cc:118
+      int32_t c = -1;
+      if (ratio < ratio_all) {
+        c = I0;
+        atomicAdd(&n_all[pair], 1);
+        if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
+      }
+      code[o] = c;
+    }
+  }
+}
+
+// ---- general path: exact binary64 brute force, k sequential ------------------------------
+struct PairTaskF {
+  const float* train;
+  const float* query;
+  int n_train, n_query, out_off;
+};
+
+__global__ __launch_bounds__(64) void k_knn2_exact(const PairTaskF* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+                                                    float ratio_good, float ratio_all, int32_t* __restrict__ code,
+                                                    int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ n_all,
+                                                    int* __restrict__ n_good) {
+  __shared__ float ta[64 * (DIM + 1)];
+  int lo = 0, hi = n_pairs - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_first[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int pair = lo;
+  const PairTaskF T = tasks[pair];
+  const int q = (bid - tile_first[pair]) * 64 + threadIdx.x;
+  const bool qvalid = q < T.n_query;
+  float qv[DIM];
+  const float* qp = T.query + (size_t)(qvalid ? q : 0) * DIM;
+#pragma unroll
+  for (int k = 0; k < DIM; k++) qv[k] = qp[k];
+  double d0 = __builtin_inf(), d1 = __builtin_inf();
+  int i0 = -1, i1 = -1;
+  for (int t0 = 0; t0 < T.n_train; t0 += 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * DIM; e += 64) {
+      const int row = e / DIM, k = e % DIM;
+      ta[row * (DIM + 1) + k] = (t0 + row < T.n_train) ? T.train[(size_t)(t0 + row) * DIM + k] : 0.f;
+    }
+    __syncthreads();
+    const int nrow = min(64, T.n_train - t0);
+    for (int row = 0; row < nrow; row++) {
+      const float* a = &ta[row * (DIM + 1)];
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < DIM; k++) {
+        const double d = (double)a[k] - (double)qv[k];
+        s = fma(d, d, s);
+      }
+      const int t = t0 + row;
+      if (s < d0) { d1 = d0; i1 = i0; d0 = s; i0 = t; }
+      else if (s < d1) { d1 = s; i1 = t; }
+    }
+  }
+  if (qvalid) {
+    const float f0 = (float)d0, f1 = (float)d1;
+    const size_t o = (size_t)T.out_off + q;
+    if (ids) { ids[2 * o] = i0; ids[2 * o + 1] = i1; sqd[2 * o] = f0; sqd[2 * o + 1] = f1; }
+    if (code) {
+      const float ratio = f0 / f1;
+      int32_t c = -1;
+      if (ratio < ratio_all) {
+        c = i0;
+        atomicAdd(&n_all[pair], 1);
+        if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
+      }
+      code[o] = c;
+    }
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------
+MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_descset** out) {
+  if (!ctx || !out || n_images <= 0) return MSFM_E_INVAL;
+  if (dim != DIM) return msfm_set_error(ctx, MSFM_E_INVAL, "descriptor dim %d not supported (128 = SIFT)", dim);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  msfm_descset* s = new msfm_descset();
+  s->ctx = ctx; s->n_images = n_images; s->dim = dim;
+  s->count.assign(n_images, 0);
+  s->f32.assign(n_images, nullptr); s->bf16.assign(n_images, nullptr); s->norm.assign(n_images, nullptr);
+  if (s->nonint.alloc(1) != hipSuccess || hipMemsetAsync(s->nonint.p, 0, sizeof(int), ctx->stream) != hipSuccess) {
+    delete s;
+    return msfm_set_error(ctx, MSFM_E_NOMEM, "descset alloc");
+  }
+  *out = s;
+  return MSFM_OK;
+}
+
+MSFM_API void msfm_descset_destroy(msfm_descset* s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s->ctx->stream);
+  for (auto p : s->f32) delete p;
+  for (auto p : s->bf16) delete p;
+  for (auto p : s->norm) delete p;
+  delete s;
+}
+
+MSFM_API int msfm_descset_count(const msfm_descset* s, int image) {
+  if (!s || image < 0 || image >= s->n_images) return MSFM_E_INVAL;
+  return s->count[image];
+}
+
+MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, int count) {
+  if (!s || image < 0 || image >= s->n_images || count < 0 || (count > 0 && !desc)) return MSFM_E_INVAL;
+  msfm_ctx* ctx = s->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  delete s->f32[image]; delete s->bf16[image]; delete s->norm[image];
+  s->f32[image] = new DevBuf<float>(); s->bf16[image] = new DevBuf<unsigned short>(); s->norm[image] = new DevBuf<float>();
+  s->count[image] = count;
+  if (count == 0) return MSFM_OK;
+  HIP_TRY(ctx, s->f32[image]->alloc((size_t)count * DIM));
+  HIP_TRY(ctx, s->bf16[image]->alloc((size_t)count * DIM));
+  HIP_TRY(ctx, s->norm[image]->alloc(count));
+  HIP_TRY(ctx, s->f32[image]->upload(desc, (size_t)count * DIM, st));
+  hipLaunchKernelGGL(k_desc_prep, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->bf16[image]->p,
+                     s->norm[image]->p, s->nonint.p);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(&s->h_nonint, s->nonint.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSFM_OK;
+}
+
+struct msfm_match_result {
+  msfm_descset* set;
+  int n_pairs = 0;
+  long total_q = 0;
+  bool keep_knn = false;
+  float ratio_good = 0.6f, ratio_all = 0.85f;
+  std::vector<int> pairs, out_off, nq;
+  DevBuf<int32_t> code;
+  DevBuf<int> ids, n_all, n_good, tile_first;
+  DevBuf<float> sqd;
+  DevBuf<PairTask> tasks;
+  DevBuf<PairTaskF> tasksf;
+  int n_tiles = 0;
+  bool exact_path = false;
+};
+
+static int launch_match(msfm_match_result* R) {
+  msfm_ctx* ctx = R->set->ctx;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipMemsetAsync(R->n_all.p, 0, sizeof(int) * R->n_pairs, st));
+  HIP_TRY(ctx, hipMemsetAsync(R->n_good.p, 0, sizeof(int) * R->n_pairs, st));
+  if (R->n_tiles == 0) return MSFM_OK;
+  if (!R->exact_path) {
+    KTimer t(ctx, "knn2_bf16_mfma");
+    hipLaunchKernelGGL(k_knn2_bf16, dim3(R->n_tiles), dim3(256), 0, st, R->tasks.p, R->tile_first.p, R->n_pairs, R->ratio_good,
+                       R->ratio_all, R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr,
+                       R->n_all.p, R->n_good.p);
+  } else {
+    KTimer t(ctx, "knn2_exact_f64");
+    hipLaunchKernelGGL(k_knn2_exact, dim3(R->n_tiles), dim3(64), 0, st, R->tasksf.p, R->tile_first.p, R->n_pairs, R->ratio_good,
+                       R->ratio_all, R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr,
+                       R->n_all.p, R->n_good.p);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, float ratio_good, float ratio_all, int keep_knn,
+                              msfm_match_result** out) {
+  if (!s || !out || n_pairs < 0 || (n_pairs > 0 && !pairs)) return MSFM_E_INVAL;
+  msfm_ctx* ctx = s->ctx;
+  *out = nullptr;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (int p = 0; p < n_pairs; p++) {
+    const int a = pairs[2 * p], b = pairs[2 * p + 1];
+    if (a < 0 || a >= s->n_images || b < 0 || b >= s->n_images) return msfm_set_error(ctx, MSFM_E_INVAL, "pair %d: image index out of range", p);
+    if (s->count[a] < 2) return msfm_set_error(ctx, MSFM_E_INVAL, "pair %d: train image %d has %d < 2 descriptors", p, a, s->count[a]);
+  }
+  msfm_match_result* R = new msfm_match_result();
+  struct Guard { msfm_match_result* p; ~Guard() { delete p; } } guard{R};
+  R->set = s; R->n_pairs = n_pairs; R->keep_knn = keep_knn != 0; R->ratio_good = ratio_good; R->ratio_all = ratio_all;
+  R->pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
+  R->exact_path = s->h_nonint != 0;
+  const int qpb = R->exact_path ? 64 : QPB;
+  std::vector<int> tile_first(n_pairs + 1, 0);
+  std::vector<PairTask> tasks(n_pairs);
+  std::vector<PairTaskF> tasksf(n_pairs);
+  long off = 0;
+  long tiles = 0;
+  for (int p = 0; p < n_pairs; p++) {
+    const int a = pairs[2 * p], b = pairs[2 * p + 1];
+    const int nq = s->count[b];
+    R->out_off.push_back((int)off);
+    R->nq.push_back(nq);
+    tile_first[p] = (int)tiles;
+    tasks[p] = PairTask{s->bf16[a]->p, nq ? s->bf16[b]->p : nullptr, s->norm[a]->p, nq ? s->norm[b]->p : nullptr, s->count[a], nq, (int)off};
+    tasksf[p] = PairTaskF{s->f32[a]->p, nq ? s->f32[b]->p : nullptr, s->count[a], nq, (int)off};
+    off += nq;
+    tiles += cdiv(nq, qpb);
+    if (off > 0x7fffffffL || tiles > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_INVAL, "too many queries in one call; split the pair list");
+  }
+  tile_first[n_pairs] = (int)tiles;
+  R->total_q = off;
+  R->n_tiles = (int)tiles;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, R->code.alloc(std::max<long>(1, off)));
+  if (R->keep_knn) { HIP_TRY(ctx, R->ids.alloc(std::max<long>(1, 2 * off))); HIP_TRY(ctx, R->sqd.alloc(std::max<long>(1, 2 * off))); }
+  HIP_TRY(ctx, R->n_all.alloc(std::max(1, n_pairs))); HIP_TRY(ctx, R->n_good.alloc(std::max(1, n_pairs)));
+  HIP_TRY(ctx, R->tile_first.from(tile_first, st));
+  if (n_pairs) { HIP_TRY(ctx, R->tasks.from(tasks, st)); HIP_TRY(ctx, R->tasksf.from(tasksf, st)); }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  MSFM_TRY(launch_match(R));
+  guard.p = nullptr;
+  *out = R;
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_match_pairs_rerun(msfm_descset* s, msfm_match_result* R) {
+  if (!s || !R || R->set != s) return MSFM_E_INVAL;
+  return launch_match(R);
+}
+
+MSFM_API int msfm_match_result_counts(msfm_match_result* R, int* n_all, int* n_good) {
+  if (!R) return MSFM_E_INVAL;
+  msfm_ctx* ctx = R->set->ctx;
+  if (R->n_pairs == 0) return MSFM_OK;
+  if (n_all) HIP_TRY(ctx, hipMemcpyAsync(n_all, R->n_all.p, sizeof(int) * R->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_good) HIP_TRY(ctx, hipMemcpyAsync(n_good, R->n_good.p, sizeof(int) * R->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_match_result_fetch(msfm_match_result* R, int pair, int32_t* code, int* ids, float* sqdists) {
+  if (!R || pair < 0 || pair >= R->n_pairs) return MSFM_E_INVAL;
+  msfm_ctx* ctx = R->set->ctx;
+  if ((ids || sqdists) && !R->keep_knn) return msfm_set_error(ctx, MSFM_E_INVAL, "result was created without keep_knn");
+  const size_t o = R->out_off[pair], n = R->nq[pair];
+  hipStream_t st = ctx->stream;
+  if (n == 0) return MSFM_OK;
+  if (code) HIP_TRY(ctx, hipMemcpyAsync(code, R->code.p + o, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+  if (ids) HIP_TRY(ctx, hipMemcpyAsync(ids, R->ids.p + 2 * o, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, st));
+  if (sqdists) HIP_TRY(ctx, hipMemcpyAsync(sqdists, R->sqd.p + 2 * o, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSFM_OK;
+}
+
+MSFM_API void msfm_match_result_destroy(msfm_match_result* R) {
+  if (!R) return;
+  (void)hipStreamSynchronize(R->set->ctx->stream);
+  delete R;
+}
+
+// The FLANN-shaped entry point: one train set, one query set, host buffers in and out.
+MSFM_API int msfm_knn2_f32(msfm_ctx* ctx, const float* train, int n_train, const float* query, int n_query, int dim, int* ids,
+                           float* sqdists) {
+  if (!ctx || !train || n_query < 0 || (n_query > 0 && (!query || !ids || !sqdists))) return MSFM_E_INVAL;
+  if (n_train < 2) return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_knn2_f32 needs n_train >= 2 (got %d)", n_train);
+  msfm_descset* s = nullptr;
+  MSFM_TRY(msfm_descset_create(ctx, 2, dim, &s));
+  int rc = msfm_descset_upload(s, 0, train, n_train);
+  if (rc == MSFM_OK) rc = msfm_descset_upload(s, 1, query, n_query);
+  msfm_match_result* R = nullptr;
+  const int pr[2] = {0, 1};
+  if (rc == MSFM_OK) rc = msfm_match_pairs(s, pr, 1, 0.6f, 0.85f, 1, &R);
+  if (rc == MSFM_OK) rc = msfm_match_result_fetch(R, 0, nullptr, ids, sqdists);
+  msfm_match_result_destroy(R);
+  msfm_descset_destroy(s);
+  return rc;
+}

@@ -1,0 +1,95 @@
+"""Multi-GPU sharding of the hot path: one process per GPU.
+
+* Bundle adjustment: points (with all their observations) are split over ranks, cameras and
+  intrinsics are replicated.  A point's V, W, g and its Schur contribution depend only on its own
+  observations, so each rank builds a partial reduced system; the all-reduce hook of the C ABI
+  (msfm_ctx_set_allreduce) sums the per-camera J^T J terms and the partial S / rhs over ranks —
+  torch.distributed all_reduce, i.e. RCCL over xGMI with backend "nccl".  The reference has no
+  counterpart (no collective anywhere in SfM/src).
+* Matching: ordered image pairs are independent (fine_matching_graph.cc:58,87): contiguous,
+  cost-balanced slices of the idx1-major pair list, no collective.
+"""
+import numpy as np
+
+from . import _abi as A
+
+
+def point_ranges(obs_pt: np.ndarray, n_points: int, world: int):
+    """Contiguous point ranges [lo, hi) per rank, balanced by sum k_p^2 (the Schur pair count)."""
+    k = np.bincount(obs_pt, minlength=n_points).astype(np.int64)
+    cost = np.cumsum(k * k + 4 * k)
+    total = cost[-1] if n_points else 0
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(cost, total * r / world, side="left")))
+    cuts.append(n_points)
+    for r in range(1, world + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def shard_ba_arrays(full: A.BaArrays, rank: int, world: int) -> A.BaArrays:
+    """The sub-problem of `rank`: its point range and their observations; every camera."""
+    if world == 1:
+        return full
+    lo, hi = point_ranges(full.obs_pt, len(full.point), world)[rank]
+    sel = (full.obs_pt >= lo) & (full.obs_pt < hi)
+    sub = lambda a: None if a is None else a[lo:hi]
+    out = A.BaArrays(full.cam_pose, full.cam_model, full.cam_model_of_cam, full.point[lo:hi], full.obs_cam[sel],
+                     full.obs_pt[sel] - lo, full.obs_xy[sel], full.pt_weight[lo:hi], cam_mutable=full.cam_mutable,
+                     model_mutable=full.model_mutable, pt_mutable=sub(full.pt_mutable), gps_xyz=full.gps_xyz,
+                     gps_weight=full.struct.gps_weight)
+    out.point_range = (lo, hi)
+    return out
+
+
+def shard_pairs(pairs: np.ndarray, rank: int, world: int, counts=None) -> np.ndarray:
+    """Contiguous slice of the (idx1-major) pair list; balanced by M1*M2 when `counts` is given."""
+    pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    if world == 1 or len(pairs) == 0:
+        return pairs
+    if counts is None:
+        w = np.ones(len(pairs))
+    else:
+        counts = np.asarray(counts, dtype=np.float64)
+        w = counts[pairs[:, 0]] * counts[pairs[:, 1]] + 1.0
+    c = np.cumsum(w)
+    lo = int(np.searchsorted(c, c[-1] * rank / world, side="left")) if rank else 0
+    hi = int(np.searchsorted(c, c[-1] * (rank + 1) / world, side="left")) if rank + 1 < world else len(pairs)
+    return pairs[lo:hi]
+
+
+class _DevPtr:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class TorchAllReduce:
+    """The msfm_allreduce_fn hook on torch.distributed: backend "nccl" (= RCCL over xGMI) reduces
+    the device buffer in place, stream-ordered on the library's stream; with "gloo" (CPU tests,
+    or several ranks sharing one GPU) the buffer is staged through the host."""
+
+    def __init__(self, dist, device_index=0, group=None):
+        import torch
+        self.torch, self.dist, self.group = torch, dist, group
+        self.device = torch.device("cuda", device_index)
+        self.backend = dist.get_backend(group)
+        self.calls = 0
+        self.bytes = 0
+
+    def __call__(self, buf_ptr, count, op, stream_ptr):
+        torch, dist = self.torch, self.dist
+        rop = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
+        self.calls += 1
+        self.bytes += 8 * count
+        ext = torch.cuda.ExternalStream(stream_ptr, device=self.device)
+        with torch.cuda.stream(ext):
+            t = torch.as_tensor(_DevPtr(buf_ptr, count), device=self.device)
+            if self.backend == "nccl":
+                dist.all_reduce(t, op=rop, group=self.group)  # ordered after / before work on `ext`
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, op=rop, group=self.group)
+                t.copy_(h)
+                ext.synchronize()
+        return 0

@@ -1,0 +1,118 @@
+"""Parity of the HIP 2-NN matcher (through the C ABI) with the CPU oracle: bit-exact."""
+import numpy as np
+import pytest
+
+from metricsfm_amd import _abi as A
+from metricsfm_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _sift_ints(rng, n):
+    return scene._sift_like(rng, n).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_train,n_query", [(2, 1), (64, 64), (65, 130), (300, 77), (1000, 513), (4096, 4096)])
+def test_knn2_integer_exact(ctx, oracle, n_train, n_query):
+    rng = np.random.default_rng(n_train * 7 + n_query)
+    tr, qu = _sift_ints(rng, n_train), _sift_ints(rng, n_query)
+    if n_query <= 600:
+        ids_r, d_r = oracle.knn2(tr, qu)
+    else:
+        ids_r, d_r = oracle.knn2(tr, qu, fast=True)  # identical on integer data (tested on CPU)
+    ids_g, d_g = ctx.knn2(tr, qu)
+    np.testing.assert_array_equal(ids_g, ids_r)
+    np.testing.assert_array_equal(d_g, d_r)
+
+
+def test_knn2_ties_and_duplicates(ctx, oracle):
+    """Planted exact duplicates and equidistant rows: lower train index must win, at both ranks."""
+    rng = np.random.default_rng(5)
+    tr = _sift_ints(rng, 200)
+    tr[150] = tr[3]          # duplicate far apart (different LDS tiles)
+    tr[17] = tr[16]          # adjacent duplicate
+    tr[199] = tr[0]
+    qu = np.concatenate([tr[[3, 16, 0, 150]], _sift_ints(rng, 60)])
+    qu[10] = tr[40]; qu[10, 0] += 1  # equidistant to two planted rows
+    tr[41] = tr[40]; tr[41, 0] += 2
+    ids_r, d_r = oracle.knn2(tr, qu)
+    ids_g, d_g = ctx.knn2(tr, qu)
+    np.testing.assert_array_equal(ids_g, ids_r)
+    np.testing.assert_array_equal(d_g, d_r)
+    assert (ids_g[0] == [3, 150]).all() and (d_g[0] == 0).all()
+    # extreme values: all-zero and all-255 rows (largest possible distance 128*255^2)
+    tr2 = np.zeros((5, 128), np.float32); tr2[1] = 255; tr2[4] = 255
+    qu2 = np.zeros((3, 128), np.float32); qu2[1] = 255
+    ids_r, d_r = oracle.knn2(tr2, qu2)
+    ids_g, d_g = ctx.knn2(tr2, qu2)
+    np.testing.assert_array_equal(ids_g, ids_r)
+    np.testing.assert_array_equal(d_g, d_r)
+    assert d_g.max() == 128 * 255 * 255
+
+
+def test_knn2_general_floats(ctx, oracle):
+    """Non-integer descriptors (VLFeat 512*x floats, feature_extractor_vl_sift.cpp:202; unit-norm
+    cudaSift floats): exact binary64 path, bit-identical to the oracle's definition."""
+    rng = np.random.default_rng(8)
+    tr = (rng.gamma(0.6, 1.0, (333, 128)) * 40).astype(np.float32)
+    qu = (rng.gamma(0.6, 1.0, (150, 128)) * 40).astype(np.float32)
+    tr[100] = tr[7]
+    ids_r, d_r = oracle.knn2(tr, qu)
+    ids_g, d_g = ctx.knn2(tr, qu)
+    np.testing.assert_array_equal(ids_g, ids_r)
+    np.testing.assert_array_equal(d_g, d_r)
+    unit = tr / np.linalg.norm(tr, axis=1, keepdims=True)
+    ids_r, d_r = oracle.knn2(unit, unit[:50])
+    ids_g, d_g = ctx.knn2(unit, unit[:50])
+    np.testing.assert_array_equal(ids_g, ids_r)
+    np.testing.assert_array_equal(d_g, d_r)
+
+
+def test_match_pairs_ratio_codes(ctx, oracle):
+    """Batched pairs + fused ratio tests vs fine_matching_graph.cc:116-133 restated; ragged image sizes,
+    an empty image, and the counts of matches_all / matches_good."""
+    sc = scene.add_features(scene.make_aerial_scene(6, 800, seed=31), 700)
+    descs = [d.copy() for d in sc.desc]
+    descs[2] = descs[2][:333]
+    descs[4] = descs[4][:0]  # image without features as query
+    pairs = np.array([(i, j) for i in range(6) for j in range(6) if i != j and i != 4], dtype=np.int32)
+    ds = ctx.descset(descs)
+    res = ds.match_pairs(pairs, 0.6, 0.85, keep_knn=True)
+    na, ng = res.counts()
+    total_good = 0
+    for p, (i, j) in enumerate(pairs):
+        code, ids, d = res.fetch(p)
+        if len(descs[j]) == 0:
+            assert len(code) == 0 and na[p] == 0
+            continue
+        ids_r, d_r = oracle.knn2(descs[i], descs[j])
+        code_r, na_r, ng_r = oracle.ratio_codes(ids_r, d_r, 0.6, 0.85)
+        np.testing.assert_array_equal(ids, ids_r)
+        np.testing.assert_array_equal(d, d_r)
+        np.testing.assert_array_equal(code, code_r)
+        assert (na[p], ng[p]) == (na_r, ng_r)
+        total_good += ng_r
+    assert total_good > 100  # the scene has real correspondences
+    # rerun into the same result object is idempotent
+    res.rerun()
+    na2, ng2 = res.counts()
+    np.testing.assert_array_equal(na, na2)
+    np.testing.assert_array_equal(ng, ng2)
+    # the matches point at the right 3-D points (ground truth of the synthetic scene)
+    code, ids, _ = res.fetch(0)
+    i, j = pairs[0]
+    good = (code >= 0) & ((code & A.MSFM_MATCH_GOOD) != 0)
+    assert good.sum() > 10
+    assert (sc.feat_point[i][code[good] & 0x3FFFFFFF] == sc.feat_point[j][np.nonzero(good)[0]]).mean() > 0.95
+
+
+def test_knn2_bad_arguments(ctx):
+    from metricsfm_amd import capi
+    one = np.zeros((1, 128), np.float32)
+    with pytest.raises(capi.MsfmError) as e:
+        ctx.knn2(one, one)  # n_train < 2: the reference would divide by an unset distance
+    assert e.value.code == A.MSFM_E_INVAL
+    with pytest.raises(capi.MsfmError):
+        ctx.knn2(np.zeros((4, 64), np.float32), np.zeros((4, 64), np.float32))  # dim != 128
+    ids, d = ctx.knn2(np.zeros((4, 128), np.float32), np.zeros((0, 128), np.float32))  # empty query
+    assert ids.shape == (0, 2)
