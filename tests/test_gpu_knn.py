@@ -41,8 +41,8 @@ def test_knn2_ties_and_duplicates(ctx, oracle):
     np.testing.assert_array_equal(d_g, d_r)
     assert (ids_g[0] == [3, 150]).all() and (d_g[0] == 0).all()
     # extreme values: all-zero and all-255 rows (largest possible distance 128*255^2)
-    tr2 = np.zeros((5, 128), np.float32); tr2[1] = 255; tr2[4] = 255
-    qu2 = np.zeros((3, 128), np.float32); qu2[1] = 255
+    tr2 = np.zeros((3, 128), np.float32); tr2[1] = 255; tr2[2] = 255
+    qu2 = np.zeros((3, 128), np.float32); qu2[1] = 255; qu2[2, :64] = 255
     ids_r, d_r = oracle.knn2(tr2, qu2)
     ids_g, d_g = ctx.knn2(tr2, qu2)
     np.testing.assert_array_equal(ids_g, ids_r)
@@ -71,8 +71,8 @@ def test_knn2_general_floats(ctx, oracle):
 def test_match_pairs_ratio_codes(ctx, oracle):
     """Batched pairs + fused ratio tests vs fine_matching_graph.cc:116-133 restated; ragged image sizes,
     an empty image, and the counts of matches_all / matches_good."""
-    sc = scene.add_features(scene.make_aerial_scene(6, 800, seed=31), 700)
-    descs = [d.copy() for d in sc.desc]
+    sc = scene.add_features(scene.make_aerial_scene(16, 1500, seed=31), 700, images=range(6))
+    descs = [d.copy() for d in sc.desc[:6]]
     descs[2] = descs[2][:333]
     descs[4] = descs[4][:0]  # image without features as query
     pairs = np.array([(i, j) for i in range(6) for j in range(6) if i != j and i != 4], dtype=np.int32)
