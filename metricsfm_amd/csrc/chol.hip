@@ -19,93 +19,174 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------
-// potrf of the 64x64 diagonal block at (j0,j0).  Columns with global index >= n are left
-// alone (padding / rhs row).  fail[0] is set when a pivot is not positive (Eigen LLT:
-// info() != Success -> Ceres LINEAR_SOLVER_FAILURE).
+// potrf of the 64x64 diagonal block at (j0,j0), plus the inverses of its four 16x16 diagonal
+// sub-blocks (Dinv[blk][4][16][16], row-major) that trsm and the back substitution use.
+// Columns with global index >= n are left alone (padding / rhs row).  fail[0] |= 1 when a pivot
+// is not positive (Eigen LLT: info() != Success -> Ceres LINEAR_SOLVER_FAILURE).
+//
+// Blocked by 16 columns.  The 64x16 panel is factored by wave 0 alone, one row per lane, the 16
+// panel entries in registers: pivots and multipliers travel by v_readlane (no LDS round trip, no
+// barrier inside the panel).  The trailing update (K = 16) is 16x16 f64 MFMA tiles on waves 0-2
+// while wave 3 inverts the 16x16 diagonal block by substitution.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ M, int ld, int j0, int n, int* fail) {
-  __shared__ double a[NB][NB + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    a[r][c] = (c <= r) ? M[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
-  }
-  __syncthreads();
-  const int ncol = min(NB, n - j0);
-  for (int c = 0; c < ncol; c++) {
-    const double d = a[c][c];
-    if (!(d > 0.0)) {
-      if (tid == 0) atomicOr(fail, 1);
-      return;  // uniform: every thread sees the same d
-    }
-    const double rs = 1.0 / sqrt(d);
-    __syncthreads();  // everyone has read a[c][c]
-    if (tid < NB) {
-      if (tid > c) a[tid][c] *= rs;
-      else if (tid == c) a[c][c] = d * rs;
-    }
-    __syncthreads();
-    // trailing update, lower triangle: a[r][q] -= a[r][c] * a[q][c], c < q <= r
-    const int m = NB - 1 - c;  // rows/cols c+1 .. 63
-    for (int e = tid; e < m * m; e += 256) {
-      const int rr = e / m, qq = e - rr * m;
-      if (qq <= rr) {
-        const int r = c + 1 + rr, q = c + 1 + qq;
-        a[r][q] -= a[r][c] * a[q][c];
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void potrf64_lds(double* __restrict__ a /*[64][LDT]*/, double* __restrict__ dinv /*[4][16][17]*/,
+                                            double* __restrict__ rdiag /*[64]*/, int ncol, int tid, int* fail) {
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int jb = 0; jb < 4; jb++) {
+    const int c0 = 16 * jb;
+    if (!FULL && c0 >= ncol) break;
+    if (wave == 0) {
+      double p[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) p[k] = a[lane * LDT + c0 + k];
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (FULL || c0 + c < ncol) {  // uniform
+          const int piv = c0 + c;
+          const double d = readlane_f64(p[c], piv);
+          bad |= !(d > 0.0);
+          const double rs = rsqrt(d);
+          p[c] = lane > piv ? p[c] * rs : (lane == piv ? d * rs : 0.0);
+          if (lane == piv) rdiag[piv] = rs;  // 1 / l_cc
+#pragma unroll
+          for (int q = c + 1; q < 16; q++) {
+            const double s = readlane_f64(p[c], c0 + q);
+            p[q] -= p[c] * s;
+          }
+        }
       }
+      if (bad && lane == 0) atomicOr(fail, 1);
+#pragma unroll
+      for (int k = 0; k < 16; k++) a[lane * LDT + c0 + k] = p[k];
     }
-    // next iteration's first barrier orders these writes before the reads
     __syncthreads();
-  }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    if (c <= r) M[(size_t)(j0 + r) * ld + j0 + c] = a[r][c];
+    const int tr = 3 - jb;  // 16-row tiles below the panel's diagonal block
+    if (wave < 3) {
+      // tiles (I >= J) of the trailing block, dealt round-robin to waves 0..2
+      const int li = lane & 15, lq = lane >> 4;
+      int t = 0;
+      for (int I = 0; I < tr; I++)
+        for (int J = 0; J <= I; J++, t++) {
+          if (t % 3 != wave) continue;
+          const int R0 = c0 + 16 + 16 * I, C0 = c0 + 16 + 16 * J;
+          d4 acc = {0, 0, 0, 0};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++) {
+            const int k = c0 + 4 * s4 + lq;
+            double av = a[(R0 + li) * LDT + k], bv = a[(C0 + li) * LDT + k];
+            if (!FULL && k >= ncol) { av = 0.0; bv = 0.0; }
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) a[(R0 + lq + 4 * i) * LDT + C0 + li] -= acc[i];
+        }
+    } else if (lane < 16) {
+      // inverse of the 16x16 diagonal block: lane = column of the inverse, forward substitution
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) x[r] = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const bool real = FULL || c0 + c < ncol;
+        const double xc = real ? x[c] * rdiag[c0 + c] : x[c];
+        x[c] = xc;
+#pragma unroll
+        for (int q = c + 1; q < 16; q++) x[q] -= (real && (FULL || c0 + q < ncol)) ? xc * a[(c0 + q) * LDT + c0 + c] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) dinv[(jb * 16 + r) * 17 + lane] = x[r];
+    }
+    __syncthreads();
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// trsm: rows r in [j0+64, nrows): X L11^T = A21  ->  forward substitution per row.
-// One thread per row; L11 (64x64) in LDS, read as broadcasts.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ M, int ld, int j0, int n, int nrows) {
-  __shared__ double L[NB][NB + 1];
+__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ M, int ld, int j0, int n, double* __restrict__ Dinv, int* fail) {
+  __shared__ double a[NB * LDT];
+  __shared__ double dinv[4 * 16 * 17];
   __shared__ double rdiag[NB];
-  __shared__ double tile[64][NB + 1];  // staging of 64 rows x 64 cols, coalesced <-> per-thread rows
   const int tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    L[r][c] = (c <= r) ? M[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
+  // 64 x 64 block, 16-byte loads; the strict upper triangle is cleared
+  for (int e = tid; e < NB * 32; e += 256) {
+    const int r = e >> 5, c2 = (e & 31) * 2;
+    d2 v = *reinterpret_cast<const d2*>(&M[(size_t)(j0 + r) * ld + j0 + c2]);
+    a[r * LDT + c2] = (c2 <= r) ? v.x : 0.0;
+    a[r * LDT + c2 + 1] = (c2 + 1 <= r) ? v.y : 0.0;
   }
+  for (int e = tid; e < 4 * 16 * 17; e += 256) dinv[e] = ((e % 17) == ((e / 17) & 15)) ? 1.0 : 0.0;  // identity for padding
   __syncthreads();
   const int ncol = min(NB, n - j0);
-  if (tid < NB) rdiag[tid] = (tid < ncol) ? 1.0 / L[tid][tid] : 1.0;
-  // this workgroup owns 64 rows; only wave 0 substitutes, all four waves move data
-  const int r0 = j0 + NB + blockIdx.x * 64;
-  for (int e = tid; e < 64 * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    tile[r][c] = (r0 + r < nrows) ? M[(size_t)(r0 + r) * ld + j0 + c] : 0.0;
+  if (ncol == NB) potrf64_lds<true>(a, dinv, rdiag, ncol, tid, fail);
+  else potrf64_lds<false>(a, dinv, rdiag, ncol, tid, fail);
+  for (int e = tid; e < NB * 32; e += 256) {
+    const int r = e >> 5, c2 = (e & 31) * 2;
+    if (c2 + 1 <= r) {
+      d2 v = {a[r * LDT + c2], a[r * LDT + c2 + 1]};
+      *reinterpret_cast<d2*>(&M[(size_t)(j0 + r) * ld + j0 + c2]) = v;
+    } else if (c2 <= r) {
+      M[(size_t)(j0 + r) * ld + j0 + c2] = a[r * LDT + c2];
+    }
   }
+  double* out = Dinv + (size_t)(j0 / NB) * 1024;
+  for (int e = tid; e < 1024; e += 256) out[e] = dinv[(e >> 4) * 17 + (e & 15)];
+}
+
+// ---------------------------------------------------------------------------------------
+// trsm: rows r in [j0+64, ..): X L11^T = A21.  One workgroup = 64 rows, each wave owns 16 rows and
+// runs the 16-column-blocked forward substitution on its own with f64 MFMA 16x16 tiles held
+// TRANSPOSED in the accumulator layout (columns of L on the accumulator rows), so that every
+// product has the LDS matrix on the left and the register tile on the right:
+//   T_jb^T = A_jb^T - sum_{i<jb} L_{jb,i} X_i^T ;  X_jb^T = Dinv_jb T_jb^T
+// (an accumulator tile is directly the B operand of the next MFMA when the k index of slice s is
+// taken as (lane >> 4) + 4 s).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ M, int ld, int j0, const double* __restrict__ Dinv) {
+  __shared__ double L[NB * LDT];
+  __shared__ double dv[4 * 16 * 18];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * 32; e += 256) {
+    const int r = e >> 5, c2 = (e & 31) * 2;
+    const d2 v = *reinterpret_cast<const d2*>(&M[(size_t)(j0 + r) * ld + j0 + c2]);
+    L[r * LDT + c2] = v.x;
+    L[r * LDT + c2 + 1] = v.y;
+  }
+  const double* Di = Dinv + (size_t)(j0 / NB) * 1024;
+  for (int e = tid; e < 1024; e += 256) dv[(e >> 4) * 18 + (e & 15)] = Di[e];
   __syncthreads();
-  if (tid < 64) {
-    double x[NB];
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lj = lane & 15, lq = lane >> 4;
+  const size_t row = (size_t)(j0 + NB + blockIdx.x * 64 + 16 * wave + lj);
+  double* mrow = M + row * ld + j0;
+  d4 X[4];
 #pragma unroll
-    for (int c = 0; c < NB; c++) x[c] = tile[tid][c];
+  for (int jb = 0; jb < 4; jb++) {
+    d4 T;
 #pragma unroll
-    for (int c = 0; c < NB; c++) {
-      if (c < ncol) {
-        const double xc = x[c] * rdiag[c];
-        x[c] = xc;
+    for (int i = 0; i < 4; i++) T[i] = mrow[16 * jb + lq + 4 * i];
 #pragma unroll
-        for (int q = c + 1; q < NB; q++) x[q] -= xc * L[q][c];
+    for (int i2 = 0; i2 < jb; i2++) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        const double av = -L[(16 * jb + lj) * LDT + 16 * i2 + lq + 4 * s4];
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[i2][s4], T, 0, 0, 0);
       }
     }
+    d4 Y = {0, 0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < NB; c++) tile[tid][c] = x[c];
-  }
-  __syncthreads();
-  for (int e = tid; e < 64 * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    if (r0 + r < nrows) M[(size_t)(r0 + r) * ld + j0 + c] = tile[r][c];
+    for (int s4 = 0; s4 < 4; s4++) {
+      const double av = dv[(16 * jb + lj) * 18 + lq + 4 * s4];
+      Y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s4], Y, 0, 0, 0);
+    }
+    X[jb] = Y;
+#pragma unroll
+    for (int i = 0; i < 4; i++) mrow[16 * jb + lq + 4 * i] = Y[i];
   }
 }
 
@@ -168,70 +249,59 @@ __global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, 
 }
 
 // ---------------------------------------------------------------------------------------
-// Inverse of every 64x64 diagonal block of the factor (one workgroup per block), used by the
-// back substitution.  Padding columns (>= n) are treated as identity.  Linv[b] row-major.
-// Thread t < 64 solves L x = e_t.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_trinv64(const double* __restrict__ M, int ld, int n, double* __restrict__ Linv) {
-  __shared__ double L[NB][NB + 1];
-  const int b = blockIdx.x, j0 = b * NB, tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 64) {
-    const int r = e >> 6, c = e & 63;
-    double v = 0.0;
-    if (j0 + r < n && j0 + c < n) v = (c <= r) ? M[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
-    else if (r == c) v = 1.0;
-    L[r][c] = v;
-  }
-  __syncthreads();
-  double x[NB];
-#pragma unroll
-  for (int r = 0; r < NB; r++) x[r] = (r == tid) ? 1.0 : 0.0;
-#pragma unroll
-  for (int c = 0; c < NB; c++) {
-    const double xc = x[c] / L[c][c];
-    x[c] = xc;
-#pragma unroll
-    for (int q = c + 1; q < NB; q++) x[q] -= xc * L[q][c];
-  }
-  double* out = Linv + (size_t)b * NB * NB;
-#pragma unroll
-  for (int r = 0; r < NB; r++) out[r * NB + tid] = x[r];  // column tid of the inverse
-}
-
-// ---------------------------------------------------------------------------------------
 // Back substitution step for block jb (from the last block down):
-//   z_j = Linv_j^T w_j ;  w_i -= L_ji^T z_j for every block i < j.
-// Grid = jb workgroups: workgroup i < jb updates w_i.  Every workgroup recomputes z_j itself
-// (64x64 mat-vec) so there is no in-launch dependency; k_backsolve_final stores z_j.
+//   z_j = L_jj^-T w_j  (four 16-wide sub-steps with the inverted 16x16 diagonal blocks);
+//   w_i -= L_ji^T z_j for every block i < j.
+// Grid = max(jb, 1) workgroups of 256 threads; every workgroup recomputes z_j itself so there is
+// no in-launch dependency; workgroup 0 stores z_j; workgroup i < jb updates w_i.  Nobody writes
+// w_j in this launch.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_backsolve_step(const double* __restrict__ M, int ld, int n, int jb,
-                                                       const double* __restrict__ Linv, double* __restrict__ w) {
-  __shared__ double zj[NB];
+__global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict__ M, int ld, int n, int jb,
+                                                         const double* __restrict__ Dinv, double* __restrict__ w,
+                                                         double* __restrict__ z) {
+  __shared__ double Lb[NB * (NB + 1)];
+  __shared__ double dv[4 * 16 * 17];
+  __shared__ double v[NB], zj[NB];
+  __shared__ double part[4][NB];
   const int tid = threadIdx.x, j0 = jb * NB;
-  const double* Li = Linv + (size_t)jb * NB * NB;
-  double s = 0.0;
-  for (int k = 0; k < NB; k++) s += Li[k * NB + tid] * w[j0 + k];  // (Linv^T w)_tid, coalesced over tid
-  zj[tid] = s;
-  __syncthreads();
-  const int i = blockIdx.x;  // grid = jb workgroups, i < jb: nobody writes w_j in this launch
-  // w_i[tid] -= sum_k L[j0+k][i*64+tid] * z_j[k]
-  const int i0 = i * NB;
-  double acc = 0.0;
-  for (int k = 0; k < NB; k++) {
-    const int r = j0 + k;
-    if (r < n) acc += M[(size_t)r * ld + i0 + tid] * zj[k];
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Lb[r * (NB + 1) + c] = (c <= r && j0 + r < n) ? M[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
   }
-  w[i0 + tid] -= acc;
-}
-
-// Separate tiny kernel that finalises z_j (avoids the read/write race on w_j inside one launch).
-__global__ __launch_bounds__(64) void k_backsolve_final(int jb, const double* __restrict__ Linv,
-                                                        const double* __restrict__ w, double* __restrict__ z) {
-  const int tid = threadIdx.x, j0 = jb * NB;
-  const double* Li = Linv + (size_t)jb * NB * NB;
-  double s = 0.0;
-  for (int k = 0; k < NB; k++) s += Li[k * NB + tid] * w[j0 + k];
-  z[j0 + tid] = s;
+  const double* Di = Dinv + (size_t)jb * 1024;
+  for (int e = tid; e < 1024; e += 256) dv[(e >> 4) * 17 + (e & 15)] = Di[e];
+  if (tid < NB) v[tid] = w[j0 + tid];
+  __syncthreads();
+  for (int sb = 3; sb >= 0; sb--) {
+    if (tid < 16) {  // z_sb = Dinv_sb^T v_sb
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) s += dv[(16 * sb + k) * 17 + tid] * v[16 * sb + k];
+      zj[16 * sb + tid] = s;
+    }
+    __syncthreads();
+    if (tid < 16 * sb) {  // v_c -= sum_k L[16 sb + k][c] z[16 sb + k]
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) s += Lb[(16 * sb + k) * (NB + 1) + tid] * zj[16 * sb + k];
+      v[tid] -= s;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid < NB) z[j0 + tid] = zj[tid];
+  if (jb == 0) return;
+  const int col = tid & 63, kq = tid >> 6;
+  const int i0 = blockIdx.x * NB;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int r = j0 + 16 * kq + k;
+    const double l = (r < n) ? M[(size_t)r * ld + i0 + col] : 0.0;
+    acc += l * zj[16 * kq + k];
+  }
+  part[kq][col] = acc;
+  __syncthreads();
+  if (tid < NB) w[i0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
 __global__ void k_copy_row(const double* __restrict__ M, int ld, int row, int n, double* __restrict__ w, int npad) {
@@ -251,31 +321,25 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* Li
     if (j0 >= n) break;
     {
       KTimer t(ctx, "chol_potrf64");
-      hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, j0, n, fail);
+      hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, j0, n, Linv, fail);
     }
     const int rows_below = nrows - (j0 + NB);
     if (rows_below <= 0) continue;
-    {
-      KTimer t(ctx, "chol_trsm64");
-      hipLaunchKernelGGL(k_trsm64, dim3(cdiv(rows_below, 64)), dim3(256), 0, s, M, npad, j0, n, nrows);
-    }
     const int nt = cdiv(rows_below, 64);
+    {
+      KTimer t(ctx, "chol_trsm_mfma");
+      hipLaunchKernelGGL(k_trsm64, dim3(nt), dim3(256), 0, s, M, npad, j0, Linv);
+    }
     {
       KTimer t(ctx, "chol_syrk64_mfma");
       hipLaunchKernelGGL(k_syrk64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, M, npad, j0, nt);
     }
   }
   {
-    KTimer t(ctx, "chol_trinv64");
-    hipLaunchKernelGGL(k_trinv64, dim3(cdiv(n, NB)), dim3(64), 0, s, M, npad, n, Linv);
-  }
-  {
     KTimer t(ctx, "chol_backsolve");
     hipLaunchKernelGGL(k_copy_row, dim3(cdiv(npad, 256)), dim3(256), 0, s, M, npad, n, n, w, npad);
-    for (int jb = cdiv(n, NB) - 1; jb >= 0; jb--) {
-      hipLaunchKernelGGL(k_backsolve_final, dim3(1), dim3(64), 0, s, jb, Linv, w, z);
-      if (jb > 0) hipLaunchKernelGGL(k_backsolve_step, dim3(jb), dim3(64), 0, s, M, npad, n, jb, Linv, w);
-    }
+    for (int jb = cdiv(n, NB) - 1; jb >= 0; jb--)
+      hipLaunchKernelGGL(k_backsolve_step, dim3(jb > 0 ? jb : 1), dim3(256), 0, s, M, npad, n, jb, Linv, w, z);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "cholesky launch: %s", hipGetErrorString(e));

@@ -1074,8 +1074,13 @@ static void knn2_impl(const float* train, int n_train, const float* query, int n
     for (int t = 0; t < n_train; t++) {
       const float* a = train + (size_t)t * dim;
       Acc s = 0;
+      if (sizeof(Acc) == sizeof(double)) {
+        // the definition: binary64, k sequential, one fused multiply-add per term
+        for (int k = 0; k < dim; k++) { const double d = (double)a[k] - (double)b[k]; s = (Acc)std::fma(d, d, (double)s); }
+      } else {
 #pragma omp simd reduction(+ : s)
-      for (int k = 0; k < dim; k++) { const Acc d = (Acc)a[k] - (Acc)b[k]; s += d * d; }
+        for (int k = 0; k < dim; k++) { const Acc d = (Acc)a[k] - (Acc)b[k]; s += d * d; }
+      }
       if (s < d0) { d1 = d0; i1 = i0; d0 = s; i0 = t; }
       else if (s < d1) { d1 = s; i1 = t; }
     }

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Generates the fixtures in this directory.  The reference has no golden vectors and cannot be
+built or imported here (C++/MSVC, Ceres/Eigen/OpenCV/FLANN absent — SURVEY.md §8c), so these are
+outputs of the repo's own CPU oracle on seeded inputs: they pin the oracle against regressions and
+give the GPU tests byte-stable inputs; they are NOT outputs of the reference ("parity unpinned")."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from metricsfm_amd import _abi as A, scene  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    # BA: 8 ring cameras, 120 points, a frozen camera and some frozen points (window semantics)
+    sc = scene.make_ring_scene(8, 120, seed=1234)
+    cam_mut = np.ones(8, np.uint8); cam_mut[0] = 0
+    pt_mut = (np.arange(120) % 7 != 0).astype(np.uint8)
+    w = np.full(120, 2.0)
+    arr = A.BaArrays(sc.cam_pose, sc.cam_model, sc.cam_model_of_cam, sc.point, sc.obs_cam, sc.obs_pt, sc.obs_xy, w,
+                     cam_mutable=cam_mut, pt_mutable=pt_mut)
+    max_it = 25
+    res = O.ba_solve(arr, O.default_options(max_num_iterations=max_it))
+    np.savez_compressed(os.path.join(HERE, "ba_c1_small.npz"), cam_pose0=sc.cam_pose, cam_model0=sc.cam_model,
+                        point0=sc.point, cam_model_of_cam=sc.cam_model_of_cam, obs_cam=sc.obs_cam, obs_pt=sc.obs_pt,
+                        obs_xy=sc.obs_xy, pt_weight=w, cam_mutable=cam_mut, pt_mutable=pt_mut, max_it=max_it,
+                        traj_cost=res["iterations"]["cost"], traj_ok=res["iterations"]["step_is_successful"],
+                        cam_pose=arr.cam_pose, cam_model=arr.cam_model, point=arr.point)
+    # matching: 96 x 80 integer descriptors with duplicates
+    rng = np.random.default_rng(99)
+    tr = scene._sift_like(rng, 96).astype(np.float32); qu = scene._sift_like(rng, 80).astype(np.float32)
+    tr[70] = tr[2]; qu[5] = tr[2]; qu[6] = tr[33]; qu[6, 3] += 1
+    ids, sqd = O.knn2(tr, qu)
+    np.savez_compressed(os.path.join(HERE, "knn_small.npz"), train=tr.astype(np.uint8), query=qu.astype(np.uint8), ids=ids, sqd=sqd)
+    # triangulation
+    sc = scene.make_ring_scene(6, 60, seed=77)
+    R, t, c, fk = scene.cameras_for_tracks(sc)
+    tra = A.TrackArrays(sc.track_offsets(), sc.obs_cam, sc.obs_xy, R, t, c, fk)
+    th = np.deg2rad(3.0)
+    Xm, _, okm = O.triangulate_midpoint(tra, 3.0, th)
+    Xd, _, okd = O.triangulate_dlt(tra, 3.0, th)
+    np.savez_compressed(os.path.join(HERE, "tri_small.npz"), off=tra.track_off, cam=tra.track_cam, xy=tra.track_xy, R=R, t=t,
+                        c=c, fk=fk, th_angle=th, X_mid=Xm, ok_mid=okm, X_dlt=Xd, ok_dlt=okd)
+
+
+if __name__ == "__main__":
+    main()
