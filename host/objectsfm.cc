@@ -1,0 +1,334 @@
+// See objectsfm.h.  Host-side glue only: gather -> C ABI -> scatter.
+#include "objectsfm.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <stdexcept>
+
+namespace objectsfm {
+
+// ---- rotation (SfM/src/utils/basic_funcs.cc:25-158) --------------------------------------
+void rotation::AngleAxisToRotationMatrix(const Vec3& aa, Mat3& R) {
+  const double theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (theta2 > std::numeric_limits<double>::epsilon()) {
+    const double theta = std::sqrt(theta2);
+    const double wx = aa[0] / theta, wy = aa[1] / theta, wz = aa[2] / theta;
+    const double c = std::cos(theta), s = std::sin(theta);
+    R(0, 0) = c + wx * wx * (1 - c);       R(1, 0) = wz * s + wx * wy * (1 - c);  R(2, 0) = -wy * s + wx * wz * (1 - c);
+    R(0, 1) = wx * wy * (1 - c) - wz * s;  R(1, 1) = c + wy * wy * (1 - c);       R(2, 1) = wx * s + wy * wz * (1 - c);
+    R(0, 2) = wy * s + wx * wz * (1 - c);  R(1, 2) = -wx * s + wy * wz * (1 - c); R(2, 2) = c + wz * wz * (1 - c);
+  } else {
+    R(0, 0) = 1; R(1, 0) = aa[2]; R(2, 0) = -aa[1];
+    R(0, 1) = -aa[2]; R(1, 1) = 1; R(2, 1) = aa[0];
+    R(0, 2) = aa[1]; R(1, 2) = -aa[0]; R(2, 2) = 1;
+  }
+}
+
+void rotation::RotationMatrixToAngleAxis(const Mat3& R, Vec3& axis) {
+  double q[4];
+  const double trace = R(0, 0) + R(1, 1) + R(2, 2);
+  if (trace >= 0.0) {
+    double t = std::sqrt(trace + 1.0);
+    q[0] = 0.5 * t; t = 0.5 / t;
+    q[1] = (R(2, 1) - R(1, 2)) * t; q[2] = (R(0, 2) - R(2, 0)) * t; q[3] = (R(1, 0) - R(0, 1)) * t;
+  } else {
+    int i = 0;
+    if (R(1, 1) > R(0, 0)) i = 1;
+    if (R(2, 2) > R(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(R(i, i) - R(j, j) - R(k, k) + 1.0);
+    q[i + 1] = 0.5 * t; t = 0.5 / t;
+    q[0] = (R(k, j) - R(j, k)) * t; q[j + 1] = (R(j, i) + R(i, j)) * t; q[k + 1] = (R(k, i) + R(i, k)) * t;
+  }
+  const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  double k = 2.0;
+  if (s2 > 0.0) {
+    const double s = std::sqrt(s2);
+    k = 2.0 * ((q[0] < 0.0) ? std::atan2(-s, -q[0]) : std::atan2(s, q[0])) / s;
+  }
+  axis[0] = q[1] * k; axis[1] = q[2] * k; axis[2] = q[3] * k;
+}
+
+// ---- CameraModel / Camera ------------------------------------------------------------------
+CameraModel::CameraModel(int id, int h, int w, double f_mm, double f, std::string cam_maker, std::string cam_model) {
+  f_mm_ = f_mm; f_ = f; f_hyp_ = (w > h ? w : h) * 1.2; w_ = w; h_ = h; px_ = w / 2.0; py_ = h / 2.0;
+  id_ = id; cam_maker_ = cam_maker; cam_model_ = cam_model;
+  UpdateDataFromModel();
+}
+
+void Camera::SetRTPose(const Mat3& R, const Vec3& t) {
+  pos_rt_.R = R; pos_rt_.t = t;
+  rotation::RotationMatrixToAngleAxis(pos_rt_.R, pos_ac_.a);
+  const Vec3 c = transpose(R) * t;  // c = -R^-1 t
+  for (int i = 0; i < 3; i++) pos_ac_.c[i] = -c[i];
+  UpdateDataFromPose();
+}
+
+void Camera::SetACPose(const Vec3& a, const Vec3& c) {
+  pos_ac_.a = a; pos_ac_.c = c;
+  rotation::AngleAxisToRotationMatrix(pos_ac_.a, pos_rt_.R);
+  const Vec3 t = pos_rt_.R * c;
+  for (int i = 0; i < 3; i++) pos_rt_.t[i] = -t[i];
+  UpdateDataFromPose();
+}
+
+void Camera::UpdateDataFromPose() {
+  for (int i = 0; i < 3; i++) { data[i] = pos_ac_.a[i]; data[3 + i] = pos_rt_.t[i]; }
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[4 * r + c] = pos_rt_.R(r, c); M[4 * r + 3] = pos_rt_.t[r]; }
+}
+
+void Camera::UpdatePoseFromData() {
+  for (int i = 0; i < 3; i++) { pos_ac_.a[i] = data[i]; pos_rt_.t[i] = data[3 + i]; }
+  rotation::AngleAxisToRotationMatrix(pos_ac_.a, pos_rt_.R);
+  const Vec3 c = transpose(pos_rt_.R) * pos_rt_.t;
+  for (int i = 0; i < 3; i++) pos_ac_.c[i] = -c[i];
+  for (int r = 0; r < 3; r++) { for (int cc = 0; cc < 3; cc++) M[4 * r + cc] = pos_rt_.R(r, cc); M[4 * r + 3] = pos_rt_.t[r]; }
+}
+
+// ---- context ---------------------------------------------------------------------------------
+static msfm_ctx* g_ctx = nullptr;
+static void destroy_ctx() { if (g_ctx) msfm_ctx_destroy(g_ctx); g_ctx = nullptr; }
+msfm_ctx* Context() {
+  if (!g_ctx) {
+    if (msfm_ctx_create(-1, &g_ctx) != MSFM_OK) throw std::runtime_error("libmsfm: no usable MI355X (there is no CPU fallback)");
+    std::atexit(destroy_ctx);
+  }
+  return g_ctx;
+}
+static void check(int rc, const char* what) {
+  if (rc != MSFM_OK) throw std::runtime_error(std::string(what) + ": " + msfm_last_error(g_ctx));
+}
+
+// ---- Point3D ------------------------------------------------------------------------------------
+void Point3D::AddObservation(Camera* cam, double x, double y, int idx) {
+  cams_.insert(std::make_pair(idx, cam));
+  Vec2 p; p.x = x; p.y = y;
+  pts2d_.insert(std::make_pair(idx, p));
+}
+
+namespace {
+// Flatten a set of points into msfm_tracks (std::map key order, as every reference loop iterates).
+struct Flat {
+  std::vector<int32_t> off, cam;
+  std::vector<double> xy, R, t, c, fk;
+  std::map<Camera*, int> index;
+  msfm_tracks tr;
+  explicit Flat(const std::vector<Point3D*>& pts) {
+    off.push_back(0);
+    for (Point3D* p : pts) {
+      auto ic = p->cams_.begin();
+      auto ip = p->pts2d_.begin();
+      for (; ic != p->cams_.end(); ++ic, ++ip) {
+        auto f = index.find(ic->second);
+        int id;
+        if (f == index.end()) {
+          id = (int)index.size();
+          index[ic->second] = id;
+          Camera* cm = ic->second;
+          for (int k = 0; k < 9; k++) R.push_back(cm->pos_rt_.R.m[k]);
+          for (int k = 0; k < 3; k++) { t.push_back(cm->pos_rt_.t[k]); c.push_back(cm->pos_ac_.c[k]); }
+          fk.push_back(cm->cam_model_->f_); fk.push_back(cm->cam_model_->k1_); fk.push_back(cm->cam_model_->k2_);
+        } else {
+          id = f->second;
+        }
+        cam.push_back(id);
+        xy.push_back(ip->second.x); xy.push_back(ip->second.y);
+      }
+      off.push_back((int32_t)cam.size());
+    }
+    if (index.empty()) { R.assign(9, 0); t.assign(3, 0); c.assign(3, 0); fk.assign(3, 1); }
+    tr.n_tracks = (int)pts.size(); tr.n_cams = (int)std::max<size_t>(1, index.size());
+    tr.track_off = off.data(); tr.track_cam = cam.data(); tr.track_xy = xy.data();
+    tr.cam_R = R.data(); tr.cam_t = t.data(); tr.cam_c = c.data(); tr.cam_fk = fk.data();
+  }
+};
+}  // namespace
+
+void TrianglateBatch(const std::vector<Point3D*>& pts, double th_error, double th_angle, bool dlt, std::vector<char>* ok) {
+  Flat F(pts);
+  std::vector<double> X(3 * pts.size()), mse(pts.size());
+  std::vector<uint8_t> okv(pts.size());
+  for (size_t i = 0; i < pts.size(); i++) for (int k = 0; k < 3; k++) X[3 * i + k] = pts[i]->data[k];
+  check(dlt ? msfm_triangulate_dlt_batch(Context(), &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data())
+            : msfm_triangulate_midpoint_batch(Context(), &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data()),
+        "triangulate");
+  if (ok) ok->assign(pts.size(), 0);
+  for (size_t i = 0; i < pts.size(); i++) {
+    for (int k = 0; k < 3; k++) pts[i]->data[k] = X[3 * i + k];
+    pts[i]->mse_ = mse[i];
+    if (ok) (*ok)[i] = (char)okv[i];
+  }
+}
+
+void ReprojectionBatch(const std::vector<Point3D*>& pts) {
+  Flat F(pts);
+  std::vector<double> X(3 * pts.size()), mse(pts.size());
+  for (size_t i = 0; i < pts.size(); i++) for (int k = 0; k < 3; k++) X[3 * i + k] = pts[i]->data[k];
+  check(msfm_reproject_mse_batch(Context(), &F.tr, X.data(), mse.data()), "reproject");
+  for (size_t i = 0; i < pts.size(); i++) pts[i]->mse_ = mse[i];
+}
+
+bool Point3D::Trianglate(double th_error, double th_angle) {
+  std::vector<char> ok;
+  TrianglateBatch(std::vector<Point3D*>(1, this), th_error, th_angle, true, &ok);
+  return ok[0] != 0;
+}
+bool Point3D::Trianglate2(double th_error, double th_angle) {
+  std::vector<char> ok;
+  TrianglateBatch(std::vector<Point3D*>(1, this), th_error, th_angle, false, &ok);
+  return ok[0] != 0;
+}
+void Point3D::Reprojection() { ReprojectionBatch(std::vector<Point3D*>(1, this)); }
+bool Point3D::SufficientTriangulationAngle(double th) {
+  // the acceptance test of the batch kernel with an unbounded error threshold isolates the angle gate
+  Flat F(std::vector<Point3D*>(1, this));
+  double X[3] = {data[0], data[1], data[2]}, mse = 0;
+  uint8_t ok = 0;
+  (void)X; (void)mse;
+  std::vector<double> c(F.c);
+  const int k = F.off[1];
+  const double cos_min = std::cos(th);
+  for (int i = 0; i + 1 < k; i++)
+    for (int j = i + 1; j < k; j++) {
+      double a[3], b[3], na = 0, nb = 0, d = 0;
+      for (int q = 0; q < 3; q++) { a[q] = data[q] - c[3 * F.cam[i] + q]; b[q] = data[q] - c[3 * F.cam[j] + q]; na += a[q] * a[q]; nb += b[q] * b[q]; }
+      for (int q = 0; q < 3; q++) d += a[q] / std::sqrt(na) * (b[q] / std::sqrt(nb));
+      if (d < cos_min) ok = 1;
+    }
+  return ok != 0;
+}
+
+// ---- BundleAdjuster -----------------------------------------------------------------------------
+BundleAdjuster::BundleAdjuster(std::vector<Camera*> cams, std::vector<CameraModel*> cam_models, std::vector<Point3D*> pts)
+    : cams_(std::move(cams)), cam_models_(std::move(cam_models)), pts_(std::move(pts)) {
+  msfm_ba_options_default(&options_);
+  summary_ = msfm_ba_summary();
+}
+
+void BundleAdjuster::SetOptions(BundleAdjustOptions options) {
+  options_.max_num_iterations = options.max_num_iterations;
+  options_.progress_to_stdout = options.minimizer_progress_to_stdout ? 1 : 0;
+  options_.num_threads = options.num_threads;  // linear solver: dense Schur, always (optimizer.cc:47)
+}
+
+void BundleAdjuster::RunOptimizetion(bool is_initial_run, double weight) {
+  if (is_initial_run) { Normalize(); Perturb(); }
+  // gather (optimizer.cc:59-129): points ascending, observations in std::map key order, bad points skipped
+  std::map<Camera*, int> cam_id;
+  std::map<CameraModel*, int> model_id;
+  for (size_t i = 0; i < cams_.size(); i++) cam_id[cams_[i]] = (int)i;
+  for (size_t i = 0; i < cam_models_.size(); i++) model_id[cam_models_[i]] = (int)i;
+  std::vector<double> cam_pose(6 * cams_.size()), cam_model(3 * cam_models_.size()), point, obs_xy, pt_weight;
+  std::vector<int32_t> model_of_cam(cams_.size()), obs_cam, obs_pt;
+  std::vector<uint8_t> cam_mut(cams_.size()), model_mut(cam_models_.size()), pt_mut;
+  std::vector<Point3D*> used;
+  for (size_t i = 0; i < cams_.size(); i++) {
+    for (int k = 0; k < 6; k++) cam_pose[6 * i + k] = cams_[i]->data[k];
+    model_of_cam[i] = model_id.at(cams_[i]->cam_model_);
+    cam_mut[i] = cams_[i]->is_mutable_;
+  }
+  for (size_t i = 0; i < cam_models_.size(); i++) {
+    for (int k = 0; k < 3; k++) cam_model[3 * i + k] = cam_models_[i]->data[k];
+    model_mut[i] = cam_models_[i]->is_mutable_;
+  }
+  for (Point3D* p : pts_) {
+    if (p->is_bad_estimated_) continue;                 // optimizer.cc:64
+    if (p->cams_.size() == 2) p->weight = 1.0;          // optimizer.cc:69-78
+    if (p->cams_.size() >= 3) p->weight = weight;
+    const int pid = (int)used.size();
+    used.push_back(p);
+    for (int k = 0; k < 3; k++) point.push_back(p->data[k]);
+    pt_weight.push_back(p->weight);
+    pt_mut.push_back(p->is_mutable_);
+    auto ic = p->cams_.begin();
+    auto ip = p->pts2d_.begin();
+    for (; ic != p->cams_.end(); ++ic, ++ip) {
+      obs_cam.push_back(cam_id.at(ic->second));
+      obs_pt.push_back(pid);
+      obs_xy.push_back(ip->second.x); obs_xy.push_back(ip->second.y);
+    }
+  }
+  msfm_ba_problem P;
+  P.n_cams = (int)cams_.size(); P.n_models = (int)cam_models_.size(); P.n_points = (int)used.size(); P.n_obs = (int)obs_cam.size();
+  P.cam_pose = cam_pose.data(); P.cam_model = cam_model.data(); P.cam_model_of_cam = model_of_cam.data(); P.point = point.data();
+  P.obs_cam = obs_cam.data(); P.obs_pt = obs_pt.data(); P.obs_xy = obs_xy.data(); P.pt_weight = pt_weight.data();
+  P.cam_mutable = cam_mut.data(); P.model_mutable = model_mut.data(); P.pt_mutable = pt_mut.data();
+  P.gps_xyz = nullptr; P.gps_weight = 0;
+  iterations_.assign((size_t)options_.max_num_iterations + 2, msfm_ba_iteration());
+  summary_.iterations = iterations_.data();
+  summary_.iterations_capacity = (int)iterations_.size();
+  check(msfm_ba_solve(Context(), &P, &options_, &summary_), "msfm_ba_solve");  // == ceres::Solve, optimizer.cc:133
+  // Ceres writes through the data blocks; so do we
+  for (size_t i = 0; i < cams_.size(); i++) for (int k = 0; k < 6; k++) cams_[i]->data[k] = cam_pose[6 * i + k];
+  for (size_t i = 0; i < cam_models_.size(); i++) for (int k = 0; k < 3; k++) cam_models_[i]->data[k] = cam_model[3 * i + k];
+  for (size_t i = 0; i < used.size(); i++) for (int k = 0; k < 3; k++) used[i]->data[k] = point[3 * i + k];
+}
+
+void BundleAdjuster::UpdateParameters() {
+  for (Camera* c : cams_) c->UpdatePoseFromData();
+  for (CameraModel* m : cam_models_) m->UpdataModelFromData();
+}
+
+void BundleAdjuster::Normalize() {
+  const int n = (int)pts_.size();
+  double mid[3] = {0, 0, 0};
+  for (Point3D* p : pts_) for (int k = 0; k < 3; k++) mid[k] += p->data[k];
+  for (int k = 0; k < 3; k++) mid[k] /= n;
+  double mad = 0;
+  for (Point3D* p : pts_) mad += std::fabs(p->data[0] - mid[0]) + std::fabs(p->data[1] - mid[1]) + std::fabs(p->data[2] - mid[2]);
+  mad /= n;
+  const double scale = 100.0 / mad;
+  for (Point3D* p : pts_) for (int k = 0; k < 3; k++) p->data[k] = scale * (p->data[k] - mid[k]);
+  for (Camera* c : cams_) {
+    Vec3 cc;
+    for (int k = 0; k < 3; k++) cc[k] = scale * (c->pos_ac_.c[k] - mid[k]);
+    c->SetACPose(c->pos_ac_.a, cc);
+  }
+}
+
+void BundleAdjuster::Perturb() {
+  std::mt19937_64 gen(perturb_seed_);
+  std::normal_distribution<double> nrm(0.0, 1.0);
+  const double rotation_sigma = 0.1, translation_sigma = 0.5, point_sigma = 0.5;
+  for (Point3D* p : pts_) for (int k = 0; k < 3; k++) p->data[k] += nrm(gen) * point_sigma;
+  for (Camera* c : cams_) {
+    Vec3 a = c->pos_ac_.a;
+    for (int k = 0; k < 3; k++) a[k] += nrm(gen) * rotation_sigma;
+    c->SetACPose(a, c->pos_ac_.c);
+    Vec3 t = c->pos_rt_.t;
+    for (int k = 0; k < 3; k++) t[k] += nrm(gen) * translation_sigma;
+    c->SetRTPose(c->pos_rt_.R, t);
+  }
+}
+
+// ---- matching -----------------------------------------------------------------------------------
+std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& descriptors,
+                                         const std::vector<std::pair<int, int>>& pairs, float thRatio_good, float thRatio_all) {
+  msfm_descset* set = nullptr;
+  check(msfm_descset_create(Context(), (int)descriptors.size(), 128, &set), "descset_create");
+  for (size_t i = 0; i < descriptors.size(); i++)
+    check(msfm_descset_upload(set, (int)i, descriptors[i].data(), (int)(descriptors[i].size() / 128)), "descset_upload");
+  std::vector<int> flat;
+  for (auto& p : pairs) { flat.push_back(p.first); flat.push_back(p.second); }
+  msfm_match_result* res = nullptr;
+  check(msfm_match_pairs(set, flat.data(), (int)pairs.size(), thRatio_good, thRatio_all, 0, &res), "match_pairs");
+  std::vector<PairMatches> out(pairs.size());
+  for (size_t p = 0; p < pairs.size(); p++) {
+    out[p].idx1 = pairs[p].first; out[p].idx2 = pairs[p].second;
+    const int n2 = (int)(descriptors[pairs[p].second].size() / 128);
+    std::vector<int32_t> code((size_t)std::max(1, n2));
+    check(msfm_match_result_fetch(res, (int)p, code.data(), nullptr, nullptr), "match_fetch");
+    for (int m = 0; m < n2; m++) {  // the loop of fine_matching_graph.cc:116-133, decisions already made on the GPU
+      if (code[m] < 0) continue;
+      const int id1 = code[m] & ~MSFM_MATCH_GOOD;
+      if (code[m] & MSFM_MATCH_GOOD) out[p].matches_good.push_back(std::make_pair(id1, m));
+      out[p].matches_all.push_back(std::make_pair(id1, m));
+    }
+  }
+  msfm_match_result_destroy(res);
+  msfm_descset_destroy(set);
+  return out;
+}
+
+}  // namespace objectsfm

@@ -1,0 +1,144 @@
+// C++ host side above the C ABI: the reference's camera / point / bundle-adjuster classes
+// (same names, members and method spellings, typos included) re-implemented without Eigen, Ceres,
+// OpenCV or FLANN, so that a maintainer can see exactly where libmsfm plugs in:
+//   CameraModel         SfM/src/basic_structs.h:48-124
+//   Camera              SfM/src/camera.h:34-85, camera.cc:43-137
+//   Point3D             SfM/src/structure.h:29-72, structure.cc:163-355
+//   BundleAdjuster      SfM/src/optimizer.h, optimizer.cc:31-232
+//   FineMatchingGraph   SfM/src/graph/fine_matching_graph.cc:40-194 (kNN + ratio tests part)
+// Everything numeric on the hot path goes through include/msfm.h; there is no CPU fallback.
+#pragma once
+#include <array>
+#include <cmath>
+#include <map>
+#include <random>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../include/msfm.h"
+
+namespace objectsfm {
+
+struct Vec2 { double x = 0, y = 0; double operator()(int i) const { return i ? y : x; } };
+struct Vec3 {
+  double v[3] = {0, 0, 0};
+  double& operator()(int i) { return v[i]; }
+  double operator()(int i) const { return v[i]; }
+  double& operator[](int i) { return v[i]; }
+  double operator[](int i) const { return v[i]; }
+};
+struct Mat3 {
+  double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major
+  double& operator()(int r, int c) { return m[3 * r + c]; }
+  double operator()(int r, int c) const { return m[3 * r + c]; }
+};
+inline Vec3 operator*(const Mat3& A, const Vec3& x) {
+  Vec3 y;
+  for (int r = 0; r < 3; r++) y[r] = A(r, 0) * x[0] + A(r, 1) * x[1] + A(r, 2) * x[2];
+  return y;
+}
+inline Mat3 transpose(const Mat3& A) { Mat3 T; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) T(r, c) = A(c, r); return T; }
+
+namespace rotation {  // SfM/src/utils/basic_funcs.cc:25-158
+void AngleAxisToRotationMatrix(const Vec3& angle_axis, Mat3& R);
+void RotationMatrixToAngleAxis(const Mat3& R, Vec3& axis);
+}  // namespace rotation
+
+struct RTPose { Mat3 R; Vec3 t; };  // basic_structs.h:126-145
+struct ACPose { Vec3 a, c; };
+
+struct BundleAdjustOptions {  // basic_structs.h:229-235
+  int max_num_iterations = 200;
+  bool minimizer_progress_to_stdout = true;
+  int num_threads = 1;
+};
+
+struct CameraModel {  // basic_structs.h:48-124
+  CameraModel() {}
+  CameraModel(int id, int h, int w, double f_mm, double f, std::string cam_maker, std::string cam_model);
+  void SetFocalLength(double f) { f_ = f; UpdateDataFromModel(); }
+  void UpdateDataFromModel() { data[0] = f_; data[1] = k1_; data[2] = k2_; data[3] = dcx_; data[4] = dcy_; }
+  void UpdataModelFromData() { f_ = data[0]; k1_ = data[1]; k2_ = data[2]; dcx_ = data[3]; dcy_ = data[4]; px_ += dcx_; py_ += dcy_; }
+  void AddCamera(int idx) { idx_cams_.push_back(idx); num_cams_++; }
+  void SetImmutable() { is_mutable_ = false; }
+  int id_ = 0;
+  std::string cam_maker_, cam_model_;
+  int w_ = 0, h_ = 0;
+  double f_mm_ = 0, f_ = 0, f_hyp_ = 0, px_ = 0, py_ = 0;
+  double k1_ = 0, k2_ = 0, dcx_ = 0, dcy_ = 0;
+  double data[5] = {0, 0, 0, 0, 0};  // {f, k1, k2, dcx, dcy}; BA optimises the first three (optimizer.cc:90-92)
+  int num_cams_ = 0;
+  std::vector<int> idx_cams_;
+  bool is_mutable_ = true;
+};
+
+class Camera {  // camera.h:34-85
+ public:
+  void AssociateImage(int id_img) { id_img_ = id_img; }
+  void AssociateCamereModel(CameraModel* cam_model) { cam_model_ = cam_model; }
+  void SetRTPose(const Mat3& R, const Vec3& t);   // camera.cc:43-54
+  void SetACPose(const Vec3& a, const Vec3& c);   // camera.cc:69-80
+  void UpdateDataFromPose();                      // camera.cc:89-111
+  void UpdatePoseFromData();                      // camera.cc:113-137
+  void SetMutable(bool is_mutable) { is_mutable_ = is_mutable; }
+  int id_img_ = 0;
+  CameraModel* cam_model_ = nullptr;
+  RTPose pos_rt_;
+  ACPose pos_ac_;
+  double data[6] = {0, 0, 0, 0, 0, 0};  // angle-axis, t
+  double M[12] = {0};                   // [R|t] row-major 3x4
+  bool is_mutable_ = true;
+};
+
+class Point3D {  // structure.h:29-72
+ public:
+  void AddObservation(Camera* cam, double x, double y, int idx);  // structure.cc:128-137
+  bool Trianglate(double th_error, double th_angle);   // DLT, structure.cc:163-209
+  bool Trianglate2(double th_error, double th_angle);  // ray midpoint, structure.cc:211-265
+  void Reprojection();                                 // structure.cc:267-300
+  bool SufficientTriangulationAngle(double th_angle_triangulation);  // structure.cc:325-355 (through the batch kernel)
+  void SetMutable(bool is_mutable) { is_mutable_ = is_mutable; }
+  int id_ = 0;
+  double data[3] = {0, 0, 0};
+  std::map<int, Camera*> cams_;
+  std::map<int, Vec2> pts2d_;
+  double weight = 1.0, mse_ = 0.0;
+  bool is_mutable_ = true, is_bad_estimated_ = false, is_new_added_ = true;
+};
+
+// One GPU context per process; created on first use, destroyed at exit.
+msfm_ctx* Context();
+
+// Batched forms the pipeline should prefer (IncrementalSfM::GenerateNew3DPoints /
+// RemovePointOutliers, sfm_incremental.cc:755-915,1831-1863): one kernel launch for all points.
+void TrianglateBatch(const std::vector<Point3D*>& pts, double th_error, double th_angle, bool dlt, std::vector<char>* ok);
+void ReprojectionBatch(const std::vector<Point3D*>& pts);
+
+class BundleAdjuster {  // optimizer.h / optimizer.cc:31-232
+ public:
+  BundleAdjuster(std::vector<Camera*> cams, std::vector<CameraModel*> cam_models, std::vector<Point3D*> pts);
+  void SetOptions(BundleAdjustOptions options);                 // optimizer.cc:42-48
+  void RunOptimizetion(bool is_initial_run, double weight);     // optimizer.cc:50-135 -> msfm_ba_solve
+  void UpdateParameters();                                      // optimizer.cc:142-153
+  void Normalize();                                             // optimizer.cc:155-195
+  void Perturb();                                               // optimizer.cc:197-232 (seeded std::mt19937_64, not std::rand)
+  msfm_ba_summary summary_;
+  std::vector<msfm_ba_iteration> iterations_;
+  unsigned long long perturb_seed_ = 0x4D53464DULL;
+
+ private:
+  std::vector<Camera*> cams_;
+  std::vector<CameraModel*> cam_models_;
+  std::vector<Point3D*> pts_;
+  msfm_ba_options options_;
+};
+
+// The kNN + ratio-test part of FineMatchingGraph::BuildMatchGraph (fine_matching_graph.cc:87-133),
+// one batched call for a whole pair list.  matches_good/all[p] = (ptid1 in idx1, ptid2 in idx2).
+struct PairMatches { int idx1, idx2; std::vector<std::pair<int, int>> matches_good, matches_all; };
+std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& descriptors /*[image][n*128]*/,
+                                         const std::vector<std::pair<int, int>>& pairs, float thRatio_good = 0.6f,
+                                         float thRatio_all = 0.85f);
+
+}  // namespace objectsfm

@@ -1,0 +1,125 @@
+// test_sfm — the reference's entry point (SfM/test/test_sfm/test_sfm.cc:22-70: set options,
+// InitializeSystem(), Run()) reduced to the stages that sit on the GPU hot path, on BASELINE
+// config 1 (10 synthetic pinhole cameras, 2k points, 128-D descriptors):
+//   matching (all ordered pairs, ratio tests)  -> tracks -> Trianglate2 -> seed-style full bundle
+//   adjustment with Normalize + Perturb (sfm_incremental.cc:393,1016-1026) -> outlier check.
+// `int main`, no hard-coded Windows paths; exits non-zero if a stage misbehaves.
+#include <algorithm>
+#include <cstdio>
+#include <numeric>
+#include <random>
+
+#include "objectsfm.h"
+
+using namespace objectsfm;
+
+int main() {
+  const int n_cams = 10, n_pts = 2000, W = 4000, H = 3000;
+  const double f = 1.2 * W;  // f_hyp_ convention, basic_structs.h:56
+  std::mt19937_64 gen(0x4D53464DULL + 1);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::normal_distribution<double> N(0.0, 1.0);
+  // --- scene ---
+  CameraModel model(0, H, W, 0.0, f, "synthetic", "pinhole");
+  std::vector<Camera> cams(n_cams);
+  for (int i = 0; i < n_cams; i++) {
+    const double ang = 2 * M_PI * i / n_cams;
+    Vec3 c; c[0] = 150 * std::cos(ang); c[1] = 150 * std::sin(ang); c[2] = 60;
+    const double nc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    double z[3] = {-c[0] / nc, -c[1] / nc, -c[2] / nc};
+    double x[3] = {z[1], -z[0], 0};  // z x (0,0,1)
+    const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1]);
+    for (double& v : x) v /= nx;
+    double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    Mat3 R;
+    for (int k = 0; k < 3; k++) { R(0, k) = x[k]; R(1, k) = y[k]; R(2, k) = z[k]; }
+    Vec3 t = R * c;
+    for (int k = 0; k < 3; k++) t[k] = -t[k];
+    cams[i].AssociateImage(i);
+    cams[i].AssociateCamereModel(&model);
+    model.AddCamera(i);
+    cams[i].SetRTPose(R, t);
+  }
+  std::vector<std::array<double, 3>> X(n_pts);
+  std::vector<std::array<float, 128>> base(n_pts);
+  std::gamma_distribution<double> G(0.6, 1.0);
+  for (int p = 0; p < n_pts; p++) {
+    X[p] = {30 * U(gen), 30 * U(gen), 10 * U(gen)};
+    double nrm = 0, v[128];
+    for (double& e : v) { e = G(gen); nrm += e * e; }
+    for (int k = 0; k < 128; k++) base[p][k] = (float)std::min(255.0, std::floor(v[k] * 512.0 / std::sqrt(nrm) + 0.5));
+  }
+  // features per image: every point is seen by every camera (config 1), random feature order
+  std::vector<std::vector<float>> desc(n_cams);
+  std::vector<std::vector<Vec2>> kp(n_cams);
+  std::vector<std::vector<int>> feat_pt(n_cams);
+  std::uniform_int_distribution<int> noise(-4, 4);
+  for (int i = 0; i < n_cams; i++) {
+    std::vector<int> order(n_pts);
+    std::iota(order.begin(), order.end(), 0);
+    std::shuffle(order.begin(), order.end(), gen);
+    desc[i].resize((size_t)n_pts * 128);
+    kp[i].resize(n_pts);
+    feat_pt[i] = order;
+    for (int m = 0; m < n_pts; m++) {
+      const int p = order[m];
+      Vec3 xw; for (int k = 0; k < 3; k++) xw[k] = X[p][k];
+      Vec3 pc = cams[i].pos_rt_.R * xw;
+      for (int k = 0; k < 3; k++) pc[k] += cams[i].pos_rt_.t[k];
+      kp[i][m].x = f * pc[0] / pc[2] + 0.5 * N(gen);
+      kp[i][m].y = f * pc[1] / pc[2] + 0.5 * N(gen);
+      for (int k = 0; k < 128; k++) desc[i][(size_t)m * 128 + k] = std::min(255.f, std::max(0.f, base[p][k] + noise(gen)));
+    }
+  }
+  // --- stage 1: matching, matching_type = "all" (test_sfm.cc:50; initial_matching_graph.cc:55-63) ---
+  std::vector<std::pair<int, int>> pairs;
+  for (int i = 0; i < n_cams; i++) for (int j = 0; j < n_cams; j++) if (i != j) pairs.push_back({i, j});
+  std::vector<PairMatches> matches = MatchImagePairs(desc, pairs);
+  long good = 0, good_right = 0;
+  for (auto& pm : matches)
+    for (auto& m : pm.matches_good) { good++; good_right += feat_pt[pm.idx1][m.first] == feat_pt[pm.idx2][m.second]; }
+  std::printf("matching: %zu pairs, %ld good matches, %.2f%% correct\n", pairs.size(), good, 100.0 * good_right / std::max(1L, good));
+  if (good < 0.8 * pairs.size() * n_pts || good_right < 0.99 * good) { std::printf("FAIL: matching\n"); return 1; }
+  // --- stage 2: tracks from the matches against image 0 (union over pairs (0, j)), Trianglate2 ---
+  std::vector<Point3D> pts(n_pts);
+  std::vector<char> has0(n_pts, 0);
+  for (auto& pm : matches) {
+    if (pm.idx1 != 0) continue;
+    for (auto& m : pm.matches_good) {
+      const int id = m.first;  // feature id in image 0 names the track
+      if (!has0[id]) { pts[id].AddObservation(&cams[0], kp[0][id].x, kp[0][id].y, id); has0[id] = 1; }
+      pts[id].AddObservation(&cams[pm.idx2], kp[pm.idx2][m.second].x, kp[pm.idx2][m.second].y, m.second + pm.idx2 * 1000000);
+    }
+  }
+  std::vector<Point3D*> pp;
+  for (auto& p : pts) if (p.cams_.size() >= 2) pp.push_back(&p);
+  std::vector<char> ok;
+  TrianglateBatch(pp, 7.0, 3.0 / 180.0 * M_PI, /*dlt=*/false, &ok);  // thresholds of sfm_incremental.cc:780-784
+  size_t n_ok = 0;
+  for (size_t i = 0; i < pp.size(); i++) { n_ok += ok[i] != 0; pp[i]->is_bad_estimated_ = !ok[i]; }
+  std::printf("triangulation: %zu tracks, %zu accepted\n", pp.size(), n_ok);
+  if (n_ok < 0.9 * pp.size()) { std::printf("FAIL: triangulation\n"); return 1; }
+  // --- stage 3: full bundle adjustment as the seed reconstruction runs it (is_initial_run = true) ---
+  std::vector<Camera*> cp;
+  for (auto& c : cams) cp.push_back(&c);
+  BundleAdjuster ba(cp, {&model}, pp);
+  BundleAdjustOptions opt;
+  opt.max_num_iterations = 100;  // th_max_iteration_full_bundle, test_sfm.cc:35
+  opt.minimizer_progress_to_stdout = true;
+  ba.SetOptions(opt);
+  ba.RunOptimizetion(true, 1.0);
+  ba.UpdateParameters();
+  std::printf("BA: %d iterations, cost %.6e -> %.6e, termination %d, f = %.3f k1 = %.3e k2 = %.3e\n", ba.summary_.num_iterations,
+              ba.summary_.initial_cost, ba.summary_.final_cost, ba.summary_.termination, model.f_, model.k1_, model.k2_);
+  // --- stage 4: RemovePointOutliers (sfm_incremental.cc:1831-1863), th_mse_outliers = 3.0 ---
+  std::vector<Point3D*> live;
+  for (Point3D* p : pp) if (!p->is_bad_estimated_) live.push_back(p);
+  ReprojectionBatch(live);
+  double rms = 0; size_t outl = 0;
+  for (Point3D* p : live) { rms += p->mse_; if (std::sqrt(p->mse_) > 3.0) { p->is_bad_estimated_ = true; outl++; } }
+  rms = std::sqrt(rms / live.size());
+  std::printf("after BA: rms reprojection error %.3f px over %zu points, %zu outliers\n", rms, live.size(), outl);
+  if (!(rms < 1.5) || ba.summary_.termination > MSFM_BA_CONVERGENCE_PARAMETER) { std::printf("FAIL: bundle adjustment\n"); return 1; }
+  std::printf("test_sfm ok\n");
+  return 0;
+}
