@@ -173,90 +173,134 @@ struct PointPtrs {
   int* fail;
 };
 
+#define GROUP_SUM(x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); }
+
+// 8 lanes per point, lane = observation (rounds of 8 for longer tracks): the SoA linearisation is
+// read coalesced, the per-point sums are 3-step xor reductions inside the 8-lane group, and every
+// lane then finishes its own observation's T = (Jc^T Jp) L^-T.  256 threads = 32 points.
 __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__ gmax_partial) {
   __shared__ double sh[4];
-  const int pb = blockIdx.x * 256 + threadIdx.x;
-  double gmax = 0.0;
-  if (pb < P.npb) {
-    const size_t A = P.A;
-    const int f = P.pt_first[pb], l = P.pt_first[pb + 1];
-    double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0;
-    for (int i = f; i < l; i++) {
+  const int tid = threadIdx.x, sub = tid & 7;
+  const int pb = blockIdx.x * 32 + (tid >> 3);
+  const bool act = pb < P.npb;
+  const size_t A = P.A;
+  int f = 0, l = 0;
+  if (act) { f = P.pt_first[pb]; l = P.pt_first[pb + 1]; }
+  const bool single = (l - f) <= 8;
+  double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0;
+  double ca0 = 0, ca1 = 0, ca2 = 0, cb0 = 0, cb1 = 0, cb2 = 0;  // this lane's Jp of the (only) round
+  for (int base = f; base < l; base += 8) {
+    const int i = base + sub;
+    if (i < l) {
       const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
       const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
       const double r0 = P.lin_r[i], r1 = P.lin_r[A + i];
       V00 += a0 * a0 + b0 * b0; V10 += a1 * a0 + b1 * b0; V11 += a1 * a1 + b1 * b1;
       V20 += a2 * a0 + b2 * b0; V21 += a2 * a1 + b2 * b1; V22 += a2 * a2 + b2 * b2;
       g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
+      ca0 = a0; ca1 = a1; ca2 = a2; cb0 = b0; cb1 = b1; cb2 = b2;
     }
+  }
+  GROUP_SUM(V00) GROUP_SUM(V10) GROUP_SUM(V11) GROUP_SUM(V20) GROUP_SUM(V21) GROUP_SUM(V22)
+  GROUP_SUM(g0) GROUP_SUM(g1) GROUP_SUM(g2)
+  double gmax = 0.0;
+  double l00 = 1, l10 = 0, l11 = 1, l20 = 0, l21 = 0, l22 = 1, i00 = 1, i11 = 1, i22 = 1, u0 = 0, u1 = 0, u2 = 0;
+  if (act) {
     double* dg = P.diag_p + 3 * (size_t)pb;
     if (P.mode == 1) {
-      dg[0] = V00; dg[1] = V11; dg[2] = V22;
+      if (sub == 0) { dg[0] = V00; dg[1] = V11; dg[2] = V22; }
     } else {
+      double d0, d1, d2;
       if (!P.reuse_diag) {
-        dg[0] = fmin(fmax(V00, P.dmin), P.dmax);
-        dg[1] = fmin(fmax(V11, P.dmin), P.dmax);
-        dg[2] = fmin(fmax(V22, P.dmin), P.dmax);
+        d0 = fmin(fmax(V00, P.dmin), P.dmax); d1 = fmin(fmax(V11, P.dmin), P.dmax); d2 = fmin(fmax(V22, P.dmin), P.dmax);
+        if (sub == 0) { dg[0] = d0; dg[1] = d1; dg[2] = d2; }
+      } else {
+        d0 = dg[0]; d1 = dg[1]; d2 = dg[2];
       }
       // lm_diagonal = sqrt(diagonal / radius); the eliminator adds its square
-      const double q0 = sqrt(dg[0] / P.radius), q1 = sqrt(dg[1] / P.radius), q2 = sqrt(dg[2] / P.radius);
+      const double q0 = sqrt(d0 / P.radius), q1 = sqrt(d1 / P.radius), q2 = sqrt(d2 / P.radius);
       V00 += q0 * q0; V11 += q1 * q1; V22 += q2 * q2;
       // 3x3 Cholesky (Eigen LLT on the e-block in Ceres' InvertPSDMatrix)
       bool ok = V00 > 0.0;
-      const double l00 = sqrt(V00);
-      const double l10 = V10 / l00, l20 = V20 / l00;
-      const double d1 = V11 - l10 * l10;
-      ok = ok && d1 > 0.0;
-      const double l11 = sqrt(d1);
-      const double l21 = (V21 - l20 * l10) / l11;
-      const double d2 = V22 - l20 * l20 - l21 * l21;
-      ok = ok && d2 > 0.0;
-      const double l22 = sqrt(d2);
-      if (!ok) atomicOr(P.fail, 2);
-      double* L = P.ptL + 6 * (size_t)pb;
-      L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
-      double* gp = P.ptg + 3 * (size_t)pb;
-      gp[0] = g0; gp[1] = g1; gp[2] = g2;
-      const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
-      // u = L^-1 g
-      const double u0 = g0 * i00;
-      const double u1 = (g1 - l10 * u0) * i11;
-      const double u2 = (g2 - l20 * u0 - l21 * u1) * i22;
-      const double* sp = P.scale_p + 3 * (size_t)pb;
-      gmax = fmax(fabs(g0 / sp[0]), fmax(fabs(g1 / sp[1]), fabs(g2 / sp[2])));
-      // camera entries: T = (Jc^T Jp) L^-T, T.u
-      for (int i = f; i < l; i++) {
+      l00 = sqrt(V00);
+      l10 = V10 / l00; l20 = V20 / l00;
+      const double e1 = V11 - l10 * l10;
+      ok = ok && e1 > 0.0;
+      l11 = sqrt(e1);
+      l21 = (V21 - l20 * l10) / l11;
+      const double e2 = V22 - l20 * l20 - l21 * l21;
+      ok = ok && e2 > 0.0;
+      l22 = sqrt(e2);
+      i00 = 1.0 / l00; i11 = 1.0 / l11; i22 = 1.0 / l22;
+      u0 = g0 * i00;
+      u1 = (g1 - l10 * u0) * i11;
+      u2 = (g2 - l20 * u0 - l21 * u1) * i22;
+      if (sub == 0) {
+        if (!ok) atomicOr(P.fail, 2);
+        double* L = P.ptL + 6 * (size_t)pb;
+        L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
+        double* gp = P.ptg + 3 * (size_t)pb;
+        gp[0] = g0; gp[1] = g1; gp[2] = g2;
+        const double* sp = P.scale_p + 3 * (size_t)pb;
+        gmax = fmax(fabs(g0 / sp[0]), fmax(fabs(g1 / sp[1]), fabs(g2 / sp[2])));
+      }
+    }
+  }
+  if (P.mode != 1) {
+    // camera entries: T = (Jc^T Jp) L^-T (one 144-byte record per observation, camera-major), T.u
+    for (int base = f; base < l; base += 8) {
+      const int i = base + sub;
+      if (i < l) {
         const int cp = P.o_cpos[i];
-        if (cp < 0) continue;
-        const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
-        const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
-        double* T = P.T + 18 * (size_t)cp;
-        double* Tu = P.Tu + 6 * (size_t)cp;
+        if (cp >= 0) {
+          double a0 = ca0, a1 = ca1, a2 = ca2, b0 = cb0, b1 = cb1, b2 = cb2;
+          if (!single) {
+            a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
+            b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
+          }
+          double T[18];
+          double* Tu = P.Tu + 6 * (size_t)cp;
 #pragma unroll
-        for (int a = 0; a < 6; a++) {
-          const double ja = P.lin_Jc[(size_t)a * A + i], jb = P.lin_Jc[(size_t)(6 + a) * A + i];
-          const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
-          const double t0 = w0 * i00;
-          const double t1 = (w1 - l10 * t0) * i11;
-          const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
-          T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
-          Tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+          for (int a = 0; a < 6; a++) {
+            const double ja = P.lin_Jc[(size_t)a * A + i], jb = P.lin_Jc[(size_t)(6 + a) * A + i];
+            const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
+            const double t0 = w0 * i00;
+            const double t1 = (w1 - l10 * t0) * i11;
+            const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
+            T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
+            Tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+          }
+          double2* To = reinterpret_cast<double2*>(P.T + 18 * (size_t)cp);  // camera-major: the pair kernel's gathers stay inside one camera's segment
+#pragma unroll
+          for (int k = 0; k < 9; k++) To[k] = make_double2(T[2 * k], T[2 * k + 1]);
         }
       }
-      // (point, intrinsics-block) entries: Tm = (sum Jm^T Jp) L^-T
-      for (int e = P.pm_first[pb]; e < P.pm_first[pb + 1]; e++) {
-        const int mb = P.pm_mb[e];
-        double W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = f; i < l; i++) {
-          if (P.o_mb[i] != mb) continue;
-          const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
-          const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
+    }
+    // (point, intrinsics-block) entries: Tm = (sum Jm^T Jp) L^-T
+    const int e0 = act ? P.pm_first[pb] : 0, e1 = act ? P.pm_first[pb + 1] : 0;
+    for (int e = e0; e < e1; e++) {
+      const int mb = P.pm_mb[e];
+      double W[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) W[k] = 0.0;
+      for (int base = f; base < l; base += 8) {
+        const int i = base + sub;
+        if (i < l && P.o_mb[i] == mb) {
+          double a0 = ca0, a1 = ca1, a2 = ca2, b0 = cb0, b1 = cb1, b2 = cb2;
+          if (!single) {
+            a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
+            b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
+          }
 #pragma unroll
           for (int a = 0; a < 3; a++) {
             const double ja = P.lin_Jm[(size_t)a * A + i], jb = P.lin_Jm[(size_t)(3 + a) * A + i];
             W[a * 3 + 0] += ja * a0 + jb * b0; W[a * 3 + 1] += ja * a1 + jb * b1; W[a * 3 + 2] += ja * a2 + jb * b2;
           }
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 9; k++) GROUP_SUM(W[k])
+      if (sub == 0) {
         double* Tm = P.Tm + 9 * (size_t)e;
         double* Tmu = P.Tmu + 3 * (size_t)e;
 #pragma unroll
@@ -553,78 +597,75 @@ struct BackPtrs {
   double* pt_c;
 };
 
+// 8 lanes per point, lane = observation, single pass: besides y = sum Jp^T (r + q) with
+// q = -(Jc z_c + Jm z_m), the group accumulates the moments that give this point's model cost change
+//   -(J s)^T (r + J s / 2) = -[ sp.g + sum q.r + 1/2 sp^T V sp + sp.(sum Jp^T q) + 1/2 sum q.q ]
+// so the step sp (known only after the group reduction) never needs a second sweep.
 __global__ __launch_bounds__(256) void k_backsub(BackPtrs P, double* __restrict__ mcc_partial, double* __restrict__ dx2_partial,
                                                   double* __restrict__ x2_partial) {
   __shared__ double sh[4];
-  const int pb = blockIdx.x * 256 + threadIdx.x;
-  double mcc = 0.0, dx2 = 0.0, x2 = 0.0;
-  if (pb < P.npb) {
-    const size_t A = P.A;
-    const int f = P.pt_first[pb], l = P.pt_first[pb + 1];
-    double y0 = 0, y1 = 0, y2 = 0;
-    for (int i = f; i < l; i++) {
-      double s0 = P.lin_r[i], s1 = P.lin_r[A + i];
+  const int tid = threadIdx.x, sub = tid & 7;
+  const int pb = blockIdx.x * 32 + (tid >> 3);
+  const bool act = pb < P.npb;
+  const size_t A = P.A;
+  int f = 0, l = 0;
+  if (act) { f = P.pt_first[pb]; l = P.pt_first[pb + 1]; }
+  double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0, h0 = 0, h1 = 0, h2 = 0, qr = 0, qq = 0;
+  for (int base = f; base < l; base += 8) {
+    const int i = base + sub;
+    if (i < l) {
+      const double r0 = P.lin_r[i], r1 = P.lin_r[A + i];
+      double q0 = 0.0, q1 = 0.0;
       const int cb = P.o_cb[i], mb = P.o_mb[i];
       if (cb >= 0) {
 #pragma unroll
         for (int j = 0; j < 6; j++) {
           const double zj = P.z[6 * cb + j];
-          s0 -= P.lin_Jc[(size_t)j * A + i] * zj;
-          s1 -= P.lin_Jc[(size_t)(6 + j) * A + i] * zj;
+          q0 -= P.lin_Jc[(size_t)j * A + i] * zj;
+          q1 -= P.lin_Jc[(size_t)(6 + j) * A + i] * zj;
         }
       }
       if (mb >= 0) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           const double zj = P.z[6 * P.ncb + 3 * mb + j];
-          s0 -= P.lin_Jm[(size_t)j * A + i] * zj;
-          s1 -= P.lin_Jm[(size_t)(3 + j) * A + i] * zj;
+          q0 -= P.lin_Jm[(size_t)j * A + i] * zj;
+          q1 -= P.lin_Jm[(size_t)(3 + j) * A + i] * zj;
         }
       }
-      y0 += P.lin_Jp[i] * s0 + P.lin_Jp[3 * A + i] * s1;
-      y1 += P.lin_Jp[A + i] * s0 + P.lin_Jp[4 * A + i] * s1;
-      y2 += P.lin_Jp[2 * A + i] * s0 + P.lin_Jp[5 * A + i] * s1;
+      const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
+      const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
+      V00 += a0 * a0 + b0 * b0; V10 += a1 * a0 + b1 * b0; V11 += a1 * a1 + b1 * b1;
+      V20 += a2 * a0 + b2 * b0; V21 += a2 * a1 + b2 * b1; V22 += a2 * a2 + b2 * b2;
+      g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
+      h0 += a0 * q0 + b0 * q1; h1 += a1 * q0 + b1 * q1; h2 += a2 * q0 + b2 * q1;
+      qr += q0 * r0 + q1 * r1;
+      qq += q0 * q0 + q1 * q1;
     }
+  }
+  GROUP_SUM(V00) GROUP_SUM(V10) GROUP_SUM(V11) GROUP_SUM(V20) GROUP_SUM(V21) GROUP_SUM(V22)
+  GROUP_SUM(g0) GROUP_SUM(g1) GROUP_SUM(g2) GROUP_SUM(h0) GROUP_SUM(h1) GROUP_SUM(h2) GROUP_SUM(qr) GROUP_SUM(qq)
+  double mcc = 0.0, dx2 = 0.0, x2 = 0.0;
+  if (act && sub == 0) {
     const double* L = P.ptL + 6 * (size_t)pb;
     const double l00 = L[0], l10 = L[1], l11 = L[2], l20 = L[3], l21 = L[4], l22 = L[5];
-    // (L L^T) y' = y
-    double q0 = y0 / l00;
-    double q1 = (y1 - l10 * q0) / l11;
-    double q2 = (y2 - l20 * q0 - l21 * q1) / l22;
+    // (L L^T) y' = y,  y = g + h
+    double q0 = (g0 + h0) / l00;
+    double q1 = ((g1 + h1) - l10 * q0) / l11;
+    double q2 = ((g2 + h2) - l20 * q0 - l21 * q1) / l22;
     q2 = q2 / l22;
     q1 = (q1 - l21 * q2) / l11;
     q0 = (q0 - l10 * q1 - l20 * q2) / l00;
-    const double sp0 = -q0, sp1 = -q1, sp2 = -q2;  // step (scaled space)
+    const double s0 = -q0, s1 = -q1, s2 = -q2;  // step (scaled space)
     const double* sc = P.scale_p + 3 * (size_t)pb;
     const size_t p = P.pb_pt[pb];
     const double x0 = P.pt[3 * p], x1 = P.pt[3 * p + 1], x2v = P.pt[3 * p + 2];
-    const double c0 = x0 + sp0 * sc[0], c1 = x1 + sp1 * sc[1], c2 = x2v + sp2 * sc[2];
+    const double c0 = x0 + s0 * sc[0], c1 = x1 + s1 * sc[1], c2 = x2v + s2 * sc[2];
     P.pt_c[3 * p] = c0; P.pt_c[3 * p + 1] = c1; P.pt_c[3 * p + 2] = c2;
     dx2 = (c0 - x0) * (c0 - x0) + (c1 - x1) * (c1 - x1) + (c2 - x2v) * (c2 - x2v);
     x2 = x0 * x0 + x1 * x1 + x2v * x2v;
-    // model cost change of this point's rows: -(J s)^T (r + J s / 2)
-    for (int i = f; i < l; i++) {
-      double m0 = P.lin_Jp[i] * sp0 + P.lin_Jp[A + i] * sp1 + P.lin_Jp[2 * A + i] * sp2;
-      double m1 = P.lin_Jp[3 * A + i] * sp0 + P.lin_Jp[4 * A + i] * sp1 + P.lin_Jp[5 * A + i] * sp2;
-      const int cb = P.o_cb[i], mb = P.o_mb[i];
-      if (cb >= 0) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          const double sj = -P.z[6 * cb + j];
-          m0 += P.lin_Jc[(size_t)j * A + i] * sj;
-          m1 += P.lin_Jc[(size_t)(6 + j) * A + i] * sj;
-        }
-      }
-      if (mb >= 0) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const double sj = -P.z[6 * P.ncb + 3 * mb + j];
-          m0 += P.lin_Jm[(size_t)j * A + i] * sj;
-          m1 += P.lin_Jm[(size_t)(3 + j) * A + i] * sj;
-        }
-      }
-      mcc -= m0 * (P.lin_r[i] + m0 / 2.0) + m1 * (P.lin_r[A + i] + m1 / 2.0);
-    }
+    const double sVs = s0 * (V00 * s0 + 2.0 * (V10 * s1 + V20 * s2)) + s1 * (V11 * s1 + 2.0 * V21 * s2) + s2 * V22 * s2;
+    mcc = -((s0 * g0 + s1 * g1 + s2 * g2) + qr + 0.5 * sVs + (s0 * h0 + s1 * h1 + s2 * h2) + 0.5 * qq);
   }
   const double t0 = block_sum256(mcc, sh);
   const double t1 = block_sum256(dx2, sh);
@@ -985,16 +1026,26 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
   AL(ptL, 6 * (size_t)npb); AL(ptg, 3 * (size_t)npb);
   AL(f_partial, (size_t)ba->n_fchunks * PSTRIDE); AL(camftf, (size_t)ncb * PSTRIDE); AL(modelsum, 12 * (size_t)nmb);
-  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 64); AL(w, ba->npad); AL(z, ba->npad);
+  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 80); /* 16x16 inverses + full 64x64 block inverses */ AL(w, ba->npad); AL(z, ba->npad);
   AL(g_r, 3 * (size_t)ncb); AL(g_J, 3 * (size_t)ncb);
   ba->nblk_obs = cdiv(As, 256);
-  ba->nblk_pt = cdiv(std::max(1, npb), 256);
+  ba->nblk_pt = cdiv(std::max(1, npb), 32);  // 8 lanes per point
   const size_t npart = (size_t)ba->nblk_obs + ba->nblk_pt + cdiv(std::max(1, ncb), 256) + 64;
   AL(partial, npart); AL(partial2, npart); AL(partial3, npart);
   AL(gmax_buf, (size_t)ba->nblk_pt + 6 * (size_t)ncb + 3 * (size_t)nmb + 8);
   AL(scal, 16);
   HIP_TRY(ctx, ba->fail.alloc(4));
 #undef AL
+  {
+    // every device buffer a kernel may dereference must exist before the first launch
+    const void* must[] = {ba->cam.p, ba->model.p, ba->pt.p, ba->cam_c.p, ba->model_c.p, ba->pt_c.p, ba->lin_r.p, ba->lin_Jc.p,
+                          ba->lin_Jm.p, ba->lin_Jp.p, ba->camrow.p, ba->T.p, ba->Tu.p, ba->Tm.p, ba->Tmu.p, ba->scale_c.p,
+                          ba->scale_m.p, ba->scale_p.p, ba->diag_c.p, ba->diag_m.p, ba->diag_p.p, ba->ptL.p, ba->ptg.p,
+                          ba->f_partial.p, ba->camftf.p, ba->modelsum.p, ba->M.p, ba->Linv.p, ba->w.p, ba->z.p, ba->g_r.p,
+                          ba->g_J.p, ba->partial.p, ba->partial2.p, ba->partial3.p, ba->gmax_buf.p, ba->scal.p, ba->fail.p};
+    for (const void* q : must)
+      if (!q) return msfm_set_error(ctx, MSFM_E_NOMEM, "msfm_ba_create: a device buffer was not allocated");
+  }
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_scal, 16 * sizeof(double)));
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_fail, 4 * sizeof(int)));
   HIP_TRY(ctx, hipMemsetAsync(ba->camrow.p, 0, sizeof(double) * std::max<size_t>(1, 20 * (size_t)NCR), s));

@@ -195,7 +195,10 @@ __global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ M, int ld, 
 // P = the 64-column panel just solved.  4 waves, each a 32x32 quadrant = 2x2 MFMA tiles.
 // blockIdx.x enumerates the lower-triangular tile pairs.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, int j0, int ntile) {
+// The workgroup that owns tile (0,0) — the next diagonal block — goes on to factor it (potrf64_lds)
+// while the other workgroups are still updating: the next panel's potrf costs no launch of its own.
+__global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, int j0, int ntile, int n,
+                                                 double* __restrict__ Dinv, int* fail) {
   __shared__ double As[64 * LDT];
   __shared__ double Bs[64 * LDT];
   // tile pair from linear index: I = floor((sqrt(8b+1)-1)/2), J = b - I(I+1)/2
@@ -237,6 +240,32 @@ __global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, 
   }
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
   const int crow = ri + 32 * wr + lk, ccol = rj + 32 * wc + lr;
+  const int ncol_next = min(NB, n - t0);
+  if (b == 0 && ncol_next > 0) {
+    // updated diagonal tile -> LDS (As), then factor it in place
+    __syncthreads();  // every wave is done reading As / Bs
+    double* dinv = Bs;            // 4*16*17 doubles
+    double* rdiag = Bs + 4 * 16 * 17;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int lrow = 32 * wr + lk + 4 * i, lcol = 32 * wc + lr;
+      As[lrow * LDT + lcol] = M[(size_t)(crow + 4 * i) * ld + ccol] - acc00[i];
+      As[lrow * LDT + lcol + 16] = M[(size_t)(crow + 4 * i) * ld + ccol + 16] - acc01[i];
+      As[(lrow + 16) * LDT + lcol] = M[(size_t)(crow + 16 + 4 * i) * ld + ccol] - acc10[i];
+      As[(lrow + 16) * LDT + lcol + 16] = M[(size_t)(crow + 16 + 4 * i) * ld + ccol + 16] - acc11[i];
+    }
+    for (int e = tid; e < 4 * 16 * 17; e += 256) dinv[e] = ((e % 17) == ((e / 17) & 15)) ? 1.0 : 0.0;
+    __syncthreads();
+    if (ncol_next == NB) potrf64_lds<true>(As, dinv, rdiag, ncol_next, tid, fail);
+    else potrf64_lds<false>(As, dinv, rdiag, ncol_next, tid, fail);
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      if (c <= r) M[(size_t)(t0 + r) * ld + t0 + c] = As[r * LDT + c];
+    }
+    double* out = Dinv + (size_t)(t0 / NB) * 1024;
+    for (int e = tid; e < 1024; e += 256) out[e] = dinv[(e >> 4) * 17 + (e & 15)];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     double* c0 = &M[(size_t)(crow + 4 * i) * ld + ccol];
@@ -249,56 +278,88 @@ __global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, 
 }
 
 // ---------------------------------------------------------------------------------------
-// Back substitution step for block jb (from the last block down):
-//   z_j = L_jj^-T w_j  (four 16-wide sub-steps with the inverted 16x16 diagonal blocks);
-//   w_i -= L_ji^T z_j for every block i < j.
-// Grid = max(jb, 1) workgroups of 256 threads; every workgroup recomputes z_j itself so there is
-// no in-launch dependency; workgroup 0 stores z_j; workgroup i < jb updates w_i.  Nobody writes
-// w_j in this launch.
+// Full inverses of all 64x64 diagonal blocks of the factor (one workgroup per block, after the
+// factorisation, off the critical path): from the 16x16 inverses by two doubling steps
+//   inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1  C^-1].   Linv[blk] row-major 64x64.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict__ M, int ld, int n, int jb,
-                                                         const double* __restrict__ Dinv, double* __restrict__ w,
-                                                         double* __restrict__ z) {
-  __shared__ double Lb[NB * (NB + 1)];
-  __shared__ double dv[4 * 16 * 17];
-  __shared__ double v[NB], zj[NB];
-  __shared__ double part[4][NB];
-  const int tid = threadIdx.x, j0 = jb * NB;
+__global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ M, int ld, int n, const double* __restrict__ Dinv,
+                                                       double* __restrict__ Linv) {
+  __shared__ double L[NB][NB + 1];
+  __shared__ double v[NB][NB + 1];
+  __shared__ double t[NB][NB + 1];
+  const int blk = blockIdx.x, j0 = blk * NB, tid = threadIdx.x;
+  const int ncol = min(NB, n - j0);
   for (int e = tid; e < NB * NB; e += 256) {
     const int r = e >> 6, c = e & 63;
-    Lb[r * (NB + 1) + c] = (c <= r && j0 + r < n) ? M[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
+    L[r][c] = (c <= r && r < ncol) ? M[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
+    const bool diag16 = (r >> 4) == (c >> 4);
+    v[r][c] = diag16 ? Dinv[(size_t)blk * 1024 + ((r >> 4) * 16 + (r & 15)) * 16 + (c & 15)] : 0.0;
   }
-  const double* Di = Dinv + (size_t)jb * 1024;
-  for (int e = tid; e < 1024; e += 256) dv[(e >> 4) * 17 + (e & 15)] = Di[e];
-  if (tid < NB) v[tid] = w[j0 + tid];
   __syncthreads();
-  for (int sb = 3; sb >= 0; sb--) {
-    if (tid < 16) {  // z_sb = Dinv_sb^T v_sb
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; k++) s += dv[(16 * sb + k) * 17 + tid] * v[16 * sb + k];
-      zj[16 * sb + tid] = s;
+  for (int s = 16; s < 64; s *= 2) {
+    const int npair = 64 / (2 * s), ss = s * s;
+    for (int e = tid; e < npair * ss; e += 256) {
+      const int pr = e / ss, rem = e - pr * ss, r = rem / s, c = rem - r * s;
+      const int o = pr * 2 * s;
+      double acc = 0.0;
+      for (int k = c; k < s; k++) acc += L[o + s + r][o + k] * v[o + k][o + c];
+      t[o + s + r][o + c] = acc;
     }
     __syncthreads();
-    if (tid < 16 * sb) {  // v_c -= sum_k L[16 sb + k][c] z[16 sb + k]
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; k++) s += Lb[(16 * sb + k) * (NB + 1) + tid] * zj[16 * sb + k];
-      v[tid] -= s;
+    for (int e = tid; e < npair * ss; e += 256) {
+      const int pr = e / ss, rem = e - pr * ss, r = rem / s, c = rem - r * s;
+      const int o = pr * 2 * s;
+      double acc = 0.0;
+      for (int k = 0; k <= r; k++) acc += v[o + s + r][o + s + k] * t[o + s + k][o + c];
+      v[o + s + r][o + c] = -acc;
     }
     __syncthreads();
   }
-  if (blockIdx.x == 0 && tid < NB) z[j0 + tid] = zj[tid];
-  if (jb == 0) return;
+  double* out = Linv + (size_t)blk * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) out[e] = v[e >> 6][e & 63];
+}
+
+// ---------------------------------------------------------------------------------------
+// Back substitution step for block jb (from the last block down):
+//   z_j = Linv_j^T w_j ;  w_i -= L_ji^T z_j for every block i < j.
+// Grid = max(jb, 1) workgroups of 256 threads; every workgroup recomputes z_j itself (64x64
+// mat-vec against the explicit inverse) so there is no in-launch dependency; workgroup 0 stores
+// z_j; workgroup i < jb updates w_i.  Nobody writes w_j in this launch.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict__ M, int ld, int n, int jb,
+                                                         const double* __restrict__ Linv, double* __restrict__ w,
+                                                         double* __restrict__ z) {
+  __shared__ double part[4][NB];
+  __shared__ double zj[NB];
+  const int tid = threadIdx.x, j0 = jb * NB;
   const int col = tid & 63, kq = tid >> 6;
+  const double* Li = Linv + (size_t)jb * NB * NB;
+  // issue the loads of both phases up front: they do not depend on each other
+  double lv[16], mv[16];
   const int i0 = blockIdx.x * NB;
-  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) lv[k] = Li[(16 * kq + k) * NB + col];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int r = j0 + 16 * kq + k;
-    const double l = (r < n) ? M[(size_t)r * ld + i0 + col] : 0.0;
-    acc += l * zj[16 * kq + k];
+    mv[k] = (jb > 0 && r < n) ? M[(size_t)r * ld + i0 + col] : 0.0;
   }
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) s += lv[k] * w[j0 + 16 * kq + k];
+  part[kq][col] = s;
+  __syncthreads();
+  if (tid < NB) {
+    const double zz = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    zj[tid] = zz;
+    if (blockIdx.x == 0) z[j0 + tid] = zz;
+  }
+  __syncthreads();
+  if (jb == 0) return;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc += mv[k] * zj[16 * kq + k];
+  __syncthreads();
   part[kq][col] = acc;
   __syncthreads();
   if (tid < NB) w[i0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
@@ -311,32 +372,38 @@ __global__ void k_copy_row(const double* __restrict__ M, int ld, int row, int n,
 
 // Host driver.  M: npad x npad, row n = rhs.  On return z[0..n) solves S z = rhs.
 // `fail` (device int) is OR-ed with 1 when S is not positive definite.
-int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* Linv, double* w, double* z,
+// work: npad*16 doubles for the 16x16 inverses followed by npad*64 for the full block inverses.
+int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z,
                            int* fail) {
+  if (!M || !work || !w || !z || !fail || npad % NB != 0 || n < 1 || n + 1 > npad)
+    return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad workspace (null buffer or size)");
   hipStream_t s = ctx->stream;
   const int nblk = npad / NB;
   const int nrows = n + 1;  // rows that carry data (S plus the rhs row)
+  double* Dinv = work;
+  double* Linv = work + (size_t)npad * 16;
+  {
+    KTimer t(ctx, "chol_potrf64");
+    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, 0, n, Dinv, fail);
+  }
   for (int jb = 0; jb < nblk; jb++) {
     const int j0 = jb * NB;
     if (j0 >= n) break;
-    {
-      KTimer t(ctx, "chol_potrf64");
-      hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, j0, n, Linv, fail);
-    }
     const int rows_below = nrows - (j0 + NB);
     if (rows_below <= 0) continue;
     const int nt = cdiv(rows_below, 64);
     {
       KTimer t(ctx, "chol_trsm_mfma");
-      hipLaunchKernelGGL(k_trsm64, dim3(nt), dim3(256), 0, s, M, npad, j0, Linv);
+      hipLaunchKernelGGL(k_trsm64, dim3(nt), dim3(256), 0, s, M, npad, j0, Dinv);
     }
     {
-      KTimer t(ctx, "chol_syrk64_mfma");
-      hipLaunchKernelGGL(k_syrk64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, M, npad, j0, nt);
+      KTimer t(ctx, "chol_syrk_potrf_mfma");  // trailing update + factorisation of the next diagonal block
+      hipLaunchKernelGGL(k_syrk64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, M, npad, j0, nt, n, Dinv, fail);
     }
   }
   {
     KTimer t(ctx, "chol_backsolve");
+    hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB)), dim3(256), 0, s, M, npad, n, Dinv, Linv);
     hipLaunchKernelGGL(k_copy_row, dim3(cdiv(npad, 256)), dim3(256), 0, s, M, npad, n, n, w, npad);
     for (int jb = cdiv(n, NB) - 1; jb >= 0; jb--)
       hipLaunchKernelGGL(k_backsolve_step, dim3(jb > 0 ? jb : 1), dim3(256), 0, s, M, npad, n, jb, Linv, w, z);
