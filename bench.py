@@ -26,6 +26,7 @@ from metricsfm_amd import capi, scene, shard  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+I8_PEAK_TOPS = 5000.0          # MI355X_MICROARCH.md: I8 32x32x32 = 2x the bf16 rate per clock
 FP64_PEAK_TFLOPS = 78.6        # vendor FP64 vector = matrix figure (not in the micro-arch guide)
 
 
@@ -194,15 +195,19 @@ def main():
         flops = float(2 * 128 * (counts[pairs[:, 0]] * counts[pairs[:, 1]]).sum())
         my_flops = float(2 * 128 * (counts[my_pairs[:, 0]] * counts[my_pairs[:, 1]]).sum())
         na, ng = mres.counts()
-        kst = mstats.get("knn2_bf16_mfma") or mstats.get("knn2_exact_f64")
+        kname = next((k for k in ("knn2_i8_mfma", "knn2_bf16_mfma", "knn2_exact_f64") if k in mstats), None)
+        kst = mstats.get(kname)
+        peak = {"knn2_i8_mfma": I8_PEAK_TOPS, "knn2_bf16_mfma": BF16_PEAK_TFLOPS, "knn2_exact_f64": FP64_PEAK_TFLOPS}.get(kname)
         kern_tf = my_flops / (kst["total_ms"] * 1e-3) / 1e12 if kst else None
         out["matching"] = dict(metric="Mmatches_per_sec", value=1e-6 * queries * msteps / m_s, unit="Mmatches/s",
                                images=n_img, pairs=int(len(pairs)), feats_per_image=args.feats, steps=msteps,
                                ms_per_step=1e3 * m_s / msteps, tflops=flops * msteps / m_s / 1e12,
+                               dtype={"knn2_i8_mfma": "i8", "knn2_bf16_mfma": "bf16"}.get(kname, "f64"),
                                matches_all=int(na.sum()), matches_good=int(ng.sum()),
-                               roofline=dict(bound="mfma", achieved=kern_tf, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                                             frac=(kern_tf / BF16_PEAK_TFLOPS) if kern_tf else None, traffic=None,
-                                             kernel="knn2_bf16_mfma", avg_launch_ms=kst["total_ms"] if kst else None))
+                               roofline=dict(bound="mfma", achieved=kern_tf, peak=peak, unit="TFLOP/s",
+                                             frac=(kern_tf / peak) if kern_tf else None, traffic=None, kernel=kname,
+                                             avg_launch_ms=kst["total_ms"] if kst else None,
+                                             note="algorithmic 2*128*M1*M2 operations per pair / kernel time; int8 MFMA, exact integer distances"))
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if world == 1 and not args.no_cpu_baseline:

@@ -151,6 +151,17 @@ __global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ M, int ld, 
   __shared__ double L[NB * LDT];
   __shared__ double dv[4 * 16 * 18];
   const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lj = lane & 15, lq = lane >> 4;
+  const size_t row = (size_t)(j0 + NB + blockIdx.x * 64 + 16 * wave + lj);
+  double* mrow = M + row * ld + j0;
+  // this lane's 16 values of the 16 x 64 strip first: their latency hides behind the staging of
+  // L11, and the stores at the end must not be allowed to fence them
+  d4 Tin[4];
+#pragma unroll
+  for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) Tin[jb][i] = mrow[16 * jb + lq + 4 * i];
   for (int e = tid; e < NB * 32; e += 256) {
     const int r = e >> 5, c2 = (e & 31) * 2;
     const d2 v = *reinterpret_cast<const d2*>(&M[(size_t)(j0 + r) * ld + j0 + c2]);
@@ -160,16 +171,10 @@ __global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ M, int ld, 
   const double* Di = Dinv + (size_t)(j0 / NB) * 1024;
   for (int e = tid; e < 1024; e += 256) dv[(e >> 4) * 18 + (e & 15)] = Di[e];
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
-  const int lj = lane & 15, lq = lane >> 4;
-  const size_t row = (size_t)(j0 + NB + blockIdx.x * 64 + 16 * wave + lj);
-  double* mrow = M + row * ld + j0;
   d4 X[4];
 #pragma unroll
   for (int jb = 0; jb < 4; jb++) {
-    d4 T;
-#pragma unroll
-    for (int i = 0; i < 4; i++) T[i] = mrow[16 * jb + lq + 4 * i];
+    d4 T = Tin[jb];
 #pragma unroll
     for (int i2 = 0; i2 < jb; i2++) {
 #pragma unroll
@@ -185,9 +190,11 @@ __global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ M, int ld, 
       Y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s4], Y, 0, 0, 0);
     }
     X[jb] = Y;
-#pragma unroll
-    for (int i = 0; i < 4; i++) mrow[16 * jb + lq + 4 * i] = Y[i];
   }
+#pragma unroll
+  for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) mrow[16 * jb + lq + 4 * i] = X[jb][i];
 }
 
 // ---------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@
 // General path (any float32 descriptors): exact binary64 brute force, sequential in k —
 //   bit-identical to the oracle's definition; slow, used only when the data is not integral.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -25,7 +26,7 @@ typedef unsigned int u32;
 #define DIM 128
 #define TT 64          // train rows per LDS tile
 #define WIN 256        // rows per packed-key window
-#define QPB 128        // queries per workgroup
+#define QPB 256        // queries per workgroup (4 waves x 64)
 #define NORM_BIAS 8388608.0f  // 2^23: keeps a2 - 2ab positive for the integer key
 
 struct msfm_descset {
@@ -35,6 +36,10 @@ struct msfm_descset {
   std::vector<DevBuf<float>*> f32;       // [count][dim]
   std::vector<DevBuf<unsigned short>*> bf16;  // [count][dim], train copy (plain) — query copy is scaled by -2 on load
   std::vector<DevBuf<float>*> norm;      // [count]  |a|^2
+  // int8 forms for the i8 MFMA kernel: train rows a-128, query rows 127-b, and the per-row terms of
+  //   |a-b|^2 = 2 sum (a-128)(127-b) + sum (a-127)^2 + sum (128-b)^2 - 128
+  std::vector<DevBuf<signed char>*> ti8, qi8;   // [count][128]
+  std::vector<DevBuf<int>*> tcin, tpar, qbeta;  // (alpha>>1)+2^21 ; alpha&1 ; beta
   DevBuf<int> nonint;                    // OR of "not integer in [0,255]" over all uploads
   int h_nonint = 0;
 };
@@ -56,6 +61,26 @@ __global__ __launch_bounds__(256) void k_desc_prep(const float* __restrict__ d, 
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (lane == 0) norm[row] = s;
+}
+
+// int8 operands + the per-row integer terms (see msfm_descset).  One wave per row.
+__global__ __launch_bounds__(256) void k_desc_prep_i8(const float* __restrict__ d, int count, signed char* __restrict__ ti8,
+                                                       signed char* __restrict__ qi8, int* __restrict__ tcin, int* __restrict__ tpar,
+                                                       int* __restrict__ qbeta) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= count) return;
+  const float2 v = reinterpret_cast<const float2*>(d + (size_t)row * DIM)[lane];
+  const int a0 = (int)v.x, a1 = (int)v.y;  // only meaningful for integer-valued data in [0,255] (flag from k_desc_prep)
+  char2 t, q;
+  t.x = (signed char)(a0 - 128); t.y = (signed char)(a1 - 128);
+  q.x = (signed char)(127 - a0); q.y = (signed char)(127 - a1);
+  reinterpret_cast<char2*>(ti8 + (size_t)row * DIM)[lane] = t;
+  reinterpret_cast<char2*>(qi8 + (size_t)row * DIM)[lane] = q;
+  int alpha = (a0 - 127) * (a0 - 127) + (a1 - 127) * (a1 - 127);
+  int beta = (128 - a0) * (128 - a0) + (128 - a1) * (128 - a1);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { alpha += __shfl_xor(alpha, off, 64); beta += __shfl_xor(beta, off, 64); }
+  if (lane == 0) { tcin[row] = (alpha >> 1) + (1 << 21); tpar[row] = alpha & 1; qbeta[row] = beta - 128; }
 }
 
 // ---- fast path --------------------------------------------------------------------------
@@ -82,13 +107,40 @@ __device__ __forceinline__ void top2_insert(u32& d0, int& i0, u32& d1, int& i1, 
   else if (lt1) { d1 = d; i1 = i; }
 }
 
+// merge a window's two packed keys into the lane's running (distance, row) top-2
+__device__ __forceinline__ void flush_window(u32& k0, u32& k1, u32& D0, int& I0, u32& D1, int& I1, int base) {
+  if (k0 != 0xffffffffu) top2_insert(D0, I0, D1, I1, k0 >> 8, base + (int)(k0 & 255u));
+  if (k1 != 0xffffffffu) top2_insert(D0, I0, D1, I1, k1 >> 8, base + (int)(k1 & 255u));
+  k0 = k1 = 0xffffffffu;
+}
+
+__device__ __forceinline__ void load_query_frags(const unsigned short* qp, int h, bf16x8* bq) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(qp + ks * 16 + h * 8);
+    u32 w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      // each 16-bit half: bf16 v -> -2v (exponent + 1, sign set); v == 0 stays +0
+      u32 lo16 = w[j] & 0xffffu, hi16 = w[j] >> 16;
+      lo16 = lo16 ? ((lo16 + 0x0080u) | 0x8000u) : 0u;
+      hi16 = hi16 ? ((hi16 + 0x0080u) | 0x8000u) : 0u;
+      w[j] = lo16 | (hi16 << 16);
+    }
+    bq[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+  }
+}
+
+// 1 workgroup = 4 waves = 256 queries of one pair; each wave keeps 2 x 32 queries as B fragments
+// (every A fragment read from LDS feeds two MFMAs).  Train tiles of 64 rows are double-buffered:
+// the global loads of tile t+1 are issued before the MFMAs of tile t and written to the other LDS
+// buffer afterwards, one barrier per tile.
 __global__ __launch_bounds__(256, 2) void k_knn2_bf16(const PairTask* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
                                                        float ratio_good, float ratio_all, int32_t* __restrict__ code,
                                                        int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ n_all,
                                                        int* __restrict__ n_good) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds_a[TT * 256];
-  __shared__ __attribute__((aligned(16))) float lds_n[TT];
-  // which pair does this workgroup belong to (binary search on the tile prefix)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][TT * 256];
+  __shared__ __attribute__((aligned(16))) float lds_n[2][TT];
   int lo = 0, hi = n_pairs - 1;
   const int bid = blockIdx.x;
   while (lo < hi) {
@@ -100,100 +152,271 @@ __global__ __launch_bounds__(256, 2) void k_knn2_bf16(const PairTask* __restrict
   const int q0 = (bid - tile_first[pair]) * QPB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  // ---- this lane's query as B fragments, scaled by -2 (exact: exponent + 1, sign flip) ----
-  const int q = q0 + wave * 32 + r;
-  const bool qvalid = q < T.n_query;
-  bf16x8 bq[8];
-  {
-    const unsigned short* qp = T.query + (size_t)(qvalid ? q : 0) * DIM;
-#pragma unroll
-    for (int ks = 0; ks < 8; ks++) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(qp + ks * 16 + h * 8);
-      u32 w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        // each 16-bit half: bf16 v -> -2v  (v == 0 stays +0: adding to the exponent of zero would make garbage)
-        u32 lo16 = w[j] & 0xffffu, hi16 = w[j] >> 16;
-        lo16 = lo16 ? ((lo16 + 0x0080u) | 0x8000u) : 0u;
-        hi16 = hi16 ? ((hi16 + 0x0080u) | 0x8000u) : 0u;
-        w[j] = lo16 | (hi16 << 16);
-      }
-      bq[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
-    }
-  }
-  u32 D0 = 0xffffffffu, D1 = 0xffffffffu;  // global top-2 of this lane: biased distance, row
-  int I0 = 0x7fffffff, I1 = 0x7fffffff;
-  u32 k0 = 0xffffffffu, k1 = 0xffffffffu;  // packed keys of the current window
+  const int qa = q0 + wave * 64 + r, qb = qa + 32;
+  const bool va = qa < T.n_query, vb = qb < T.n_query;
+  bf16x8 bqa[8], bqb[8];
+  load_query_frags(T.query + (size_t)(va ? qa : 0) * DIM, h, bqa);
+  load_query_frags(T.query + (size_t)(vb ? qb : 0) * DIM, h, bqb);
+  u32 aD0 = 0xffffffffu, aD1 = 0xffffffffu, bD0 = 0xffffffffu, bD1 = 0xffffffffu;
+  int aI0 = 0x7fffffff, aI1 = 0x7fffffff, bI0 = 0x7fffffff, bI1 = 0x7fffffff;
+  u32 ak0 = 0xffffffffu, ak1 = 0xffffffffu, bk0 = 0xffffffffu, bk1 = 0xffffffffu;
   const int n_tiles = (T.n_train + TT - 1) / TT;
-  for (int tile = 0; tile < n_tiles; tile++) {
+  // staging assignment: thread -> 4 chunks of 16 B (row = c >> 4, chunk = c & 15), XOR-swizzled per row
+  uint4 stage[4];
+  float stage_n = 0.f;
+  auto fetch = [&](int tile) {
     const int t0 = tile * TT;
-    __syncthreads();  // previous tile fully consumed
-    // stage 64 train rows (16 KB): 1024 16-byte chunks, XOR-swizzled per row
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int c = tid + 256 * i;
-      const int row = c >> 4, ch = c & 15;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (t0 + row < T.n_train) v = *reinterpret_cast<const uint4*>(T.train + (size_t)(t0 + row) * DIM + ch * 8);
-      *reinterpret_cast<uint4*>(lds_a + row * 256 + ((ch ^ (row & 15)) << 4)) = v;
+      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+      stage[i] = make_uint4(0, 0, 0, 0);
+      if (t0 + row < T.n_train) stage[i] = *reinterpret_cast<const uint4*>(T.train + (size_t)(t0 + row) * DIM + ch * 8);
     }
-    if (tid < TT) lds_n[tid] = (t0 + tid < T.n_train) ? T.tnorm[t0 + tid] + NORM_BIAS : 16777215.0f;  // padding: above every real biased distance, still an exact integer
-    __syncthreads();
+    if (tid < TT) stage_n = (t0 + tid < T.n_train) ? T.tnorm[t0 + tid] + NORM_BIAS : 16777215.0f;  // padding rows lose every comparison
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+      *reinterpret_cast<uint4*>(&lds_a[buf][row * 256 + ((ch ^ (row & 15)) << 4)]) = stage[i];
+    }
+    if (tid < TT) lds_n[buf][tid] = stage_n;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = 0; tile < n_tiles; tile++) {
+    if (tile + 1 < n_tiles) fetch(tile + 1);
+    const unsigned char* la = lds_a[cur];
+    const float* ln = lds_n[cur];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-      // C-in = |a|^2 + 2^23 of the 16 rows this lane's accumulators cover
-      f32x16 acc;
+      f32x16 acca, accb;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const f32x4 nv = *reinterpret_cast<const f32x4*>(&lds_n[st * 32 + 8 * g + 4 * h]);
-        acc[4 * g + 0] = nv.x; acc[4 * g + 1] = nv.y; acc[4 * g + 2] = nv.z; acc[4 * g + 3] = nv.w;
+        const f32x4 nv = *reinterpret_cast<const f32x4*>(&ln[st * 32 + 8 * g + 4 * h]);
+        acca[4 * g + 0] = nv.x; acca[4 * g + 1] = nv.y; acca[4 * g + 2] = nv.z; acca[4 * g + 3] = nv.w;
       }
+      accb = acca;
       const int row = st * 32 + r;
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         const int ch = 2 * ks + h;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds_a + row * 256 + ((ch ^ (row & 15)) << 4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[ks], acc, 0, 0, 0);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(la + row * 256 + ((ch ^ (row & 15)) << 4));
+        acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bqa[ks], acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bqb[ks], accb, 0, 0, 0);
       }
-      // running top-2 on packed keys: (biased distance << 8) | row-in-window (without the 4h term)
       const int wbase = ((tile & 3) * 2 + st) * 32;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const u32 u = (u32)acc[reg];  // v_cvt_u32_f32 of an exact integer < 2^24
-        const u32 key = (u << 8) | (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
-        const u32 nk0 = min(k0, key);
-        k1 = umed3(k0, k1, key);
-        k0 = nk0;
+        const u32 idx = (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
+        const u32 keya = ((u32)acca[reg] << 8) | idx;  // v_cvt_u32_f32 of an exact integer < 2^24
+        const u32 keyb = ((u32)accb[reg] << 8) | idx;
+        const u32 na0 = min(ak0, keya);
+        ak1 = umed3(ak0, ak1, keya);
+        ak0 = na0;
+        const u32 nb0 = min(bk0, keyb);
+        bk1 = umed3(bk0, bk1, keyb);
+        bk0 = nb0;
       }
     }
     if ((tile & 3) == 3 || tile == n_tiles - 1) {
       const int base = (tile & ~3) * TT + 4 * h;
-      if (k0 != 0xffffffffu) top2_insert(D0, I0, D1, I1, k0 >> 8, base + (int)(k0 & 255u));
-      if (k1 != 0xffffffffu) top2_insert(D0, I0, D1, I1, k1 >> 8, base + (int)(k1 & 255u));
-      k0 = k1 = 0xffffffffu;
+      flush_window(ak0, ak1, aD0, aI0, aD1, aI1, base);
+      flush_window(bk0, bk1, bD0, bI0, bD1, bI1, base);
     }
+    if (tile + 1 < n_tiles) commit(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
-  // merge the two lane halves (rows 4h+..) of each query
-  {
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    u32 D0 = s ? bD0 : aD0, D1 = s ? bD1 : aD1;
+    int I0 = s ? bI0 : aI0, I1 = s ? bI1 : aI1;
+    const int q = s ? qb : qa;
+    const bool qvalid = s ? vb : va;
+    // merge the two lane halves (rows 4h+..) of each query
     const u32 pd0 = __shfl_xor(D0, 32, 64), pd1 = __shfl_xor(D1, 32, 64);
     const int pi0 = __shfl_xor(I0, 32, 64), pi1 = __shfl_xor(I1, 32, 64);
     top2_insert(D0, I0, D1, I1, pd0, pi0);
     top2_insert(D0, I0, D1, I1, pd1, pi1);
-  }
-  if (h == 0 && qvalid) {
-    const int b2 = (int)T.qnorm[q];
-    const float d0 = (float)((int)D0 - 8388608 + b2), d1 = (float)((int)D1 - 8388608 + b2);
-    const size_t o = (size_t)T.out_off + q;
-    if (ids) { ids[2 * o] = I0; ids[2 * o + 1] = I1; sqd[2 * o] = d0; sqd[2 * o + 1] = d1; }
-    if (code) {
-      const float ratio = d0 / d1;  // fine_matching_graph.cc:118
-      int32_t c = -1;
-      if (ratio < ratio_all) {
-        c = I0;
-        atomicAdd(&n_all[pair], 1);
-        if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
+    if (h == 0 && qvalid) {
+      const int b2 = (int)T.qnorm[q];
+      const float d0 = (float)((int)D0 - 8388608 + b2), d1 = (float)((int)D1 - 8388608 + b2);
+      const size_t o = (size_t)T.out_off + q;
+      if (ids) { ids[2 * o] = I0; ids[2 * o + 1] = I1; sqd[2 * o] = d0; sqd[2 * o + 1] = d1; }
+      if (code) {
+        const float ratio = d0 / d1;  // fine_matching_graph.cc:118
+        int32_t c = -1;
+        if (ratio < ratio_all) {
+          c = I0;
+          atomicAdd(&n_all[pair], 1);
+          if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
+        }
+        code[o] = c;
       }
-      code[o] = c;
+    }
+  }
+}
+
+// ---- int8 fast path ---------------------------------------------------------------------------
+// Same structure as k_knn2_bf16 on v_mfma_i32_32x32x32_i8 (twice the bf16 MFMA rate, K = 32 per
+// instruction, exact int32 accumulation).  With A = a-128 and B' = 127-b (both fit int8),
+//   |a-b|^2 = 2 A.B' + alpha(a) + beta(b),  alpha = sum (a-127)^2,  beta = sum (128-b)^2 - 128,
+// the accumulator is started at (alpha >> 1) + 2^21 so m = A.B' + (alpha>>1) + 2^21 >= 0 and
+// 2 m + (alpha & 1) orders the candidates of one query exactly like the distance.  The per-row word
+// c = (alpha & 1) << 8 | row-in-window comes from LDS, so a candidate costs three VALU ops:
+// v_lshl_or_b32 (key = m << 9 | c), v_min_u32, v_med3_u32.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+struct PairTask8 {
+  const signed char* train;  // [n_train][128]  a - 128
+  const signed char* query;  // [n_query][128]  127 - b
+  const int* tcin;
+  const int* tpar;
+  const int* qbeta;
+  int n_train, n_query, out_off;
+};
+
+__device__ __forceinline__ void flush_window8(u32& k0, u32& k1, u32& D0, int& I0, u32& D1, int& I1, int base) {
+  if (k0 != 0xffffffffu) top2_insert(D0, I0, D1, I1, ((k0 >> 9) << 1) | ((k0 >> 8) & 1u), base + (int)(k0 & 255u));
+  if (k1 != 0xffffffffu) top2_insert(D0, I0, D1, I1, ((k1 >> 9) << 1) | ((k1 >> 8) & 1u), base + (int)(k1 & 255u));
+  k0 = k1 = 0xffffffffu;
+}
+
+__global__ __launch_bounds__(256, 2) void k_knn2_i8(const PairTask8* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+                                                     float ratio_good, float ratio_all, int32_t* __restrict__ code,
+                                                     int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ n_all,
+                                                     int* __restrict__ n_good) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][TT * 128];
+  __shared__ __attribute__((aligned(16))) int lds_cin[2][TT];
+  __shared__ __attribute__((aligned(16))) int lds_c[2][TT];
+  int lo = 0, hi = n_pairs - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_first[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int pair = lo;
+  const PairTask8 T = tasks[pair];
+  const int q0 = (bid - tile_first[pair]) * QPB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int qa = q0 + wave * 64 + r, qb = qa + 32;
+  const bool va = qa < T.n_query, vb = qb < T.n_query;
+  i32x4 bqa[4], bqb[4];
+  {
+    const signed char* pa = T.query + (size_t)(va ? qa : 0) * DIM;
+    const signed char* pb = T.query + (size_t)(vb ? qb : 0) * DIM;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      bqa[ks] = *reinterpret_cast<const i32x4*>(pa + ks * 32 + h * 16);
+      bqb[ks] = *reinterpret_cast<const i32x4*>(pb + ks * 32 + h * 16);
+    }
+  }
+  u32 aD0 = 0xffffffffu, aD1 = 0xffffffffu, bD0 = 0xffffffffu, bD1 = 0xffffffffu;
+  int aI0 = 0x7fffffff, aI1 = 0x7fffffff, bI0 = 0x7fffffff, bI1 = 0x7fffffff;
+  u32 ak0 = 0xffffffffu, ak1 = 0xffffffffu, bk0 = 0xffffffffu, bk1 = 0xffffffffu;
+  const int n_tiles = (T.n_train + TT - 1) / TT;
+  // staging: 64 rows x 8 chunks of 16 B = 512 chunks, 2 per thread; chunk' = chunk ^ ((row >> 1) & 7)
+  uint4 stage[2];
+  int stage_cin = 0, stage_c = 0;
+  auto fetch = [&](int tile) {
+    const int t0 = tile * TT;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+      stage[i] = make_uint4(0, 0, 0, 0);
+      if (t0 + row < T.n_train) stage[i] = *reinterpret_cast<const uint4*>(T.train + (size_t)(t0 + row) * DIM + ch * 16);
+    }
+    if (tid < TT) {
+      const bool in = t0 + tid < T.n_train;
+      stage_cin = in ? T.tcin[t0 + tid] : 0x7fffff;  // padding rows (all-zero operands) lose every comparison
+      stage_c = ((in ? T.tpar[t0 + tid] : 0) << 8) | ((tile & 3) * TT + tid);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(&lds_a[buf][row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)]) = stage[i];
+    }
+    if (tid < TT) { lds_cin[buf][tid] = stage_cin; lds_c[buf][tid] = stage_c; }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = 0; tile < n_tiles; tile++) {
+    if (tile + 1 < n_tiles) fetch(tile + 1);
+    const unsigned char* la = lds_a[cur];
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+      i32x16 acca, accb, cc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const i32x4 nv = *reinterpret_cast<const i32x4*>(&lds_cin[cur][st * 32 + 8 * g + 4 * h]);
+        const i32x4 cv = *reinterpret_cast<const i32x4*>(&lds_c[cur][st * 32 + 8 * g + 4 * h]);
+        acca[4 * g + 0] = nv.x; acca[4 * g + 1] = nv.y; acca[4 * g + 2] = nv.z; acca[4 * g + 3] = nv.w;
+        cc[4 * g + 0] = cv.x; cc[4 * g + 1] = cv.y; cc[4 * g + 2] = cv.z; cc[4 * g + 3] = cv.w;
+      }
+      accb = acca;
+      const int row = st * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const int ch = 2 * ks + h;
+        const i32x4 a = *reinterpret_cast<const i32x4*>(la + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        acca = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bqa[ks], acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bqb[ks], accb, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const u32 keya = ((u32)acca[reg] << 9) | (u32)cc[reg];
+        const u32 keyb = ((u32)accb[reg] << 9) | (u32)cc[reg];
+        const u32 na0 = min(ak0, keya);
+        ak1 = umed3(ak0, ak1, keya);
+        ak0 = na0;
+        const u32 nb0 = min(bk0, keyb);
+        bk1 = umed3(bk0, bk1, keyb);
+        bk0 = nb0;
+      }
+    }
+    if ((tile & 3) == 3 || tile == n_tiles - 1) {
+      const int base = (tile & ~3) * TT;
+      flush_window8(ak0, ak1, aD0, aI0, aD1, aI1, base);
+      flush_window8(bk0, bk1, bD0, bI0, bD1, bI1, base);
+    }
+    if (tile + 1 < n_tiles) commit(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    u32 D0 = s ? bD0 : aD0, D1 = s ? bD1 : aD1;
+    int I0 = s ? bI0 : aI0, I1 = s ? bI1 : aI1;
+    const int q = s ? qb : qa;
+    const bool qvalid = s ? vb : va;
+    const u32 pd0 = __shfl_xor(D0, 32, 64), pd1 = __shfl_xor(D1, 32, 64);
+    const int pi0 = __shfl_xor(I0, 32, 64), pi1 = __shfl_xor(I1, 32, 64);
+    top2_insert(D0, I0, D1, I1, pd0, pi0);
+    top2_insert(D0, I0, D1, I1, pd1, pi1);
+    if (h == 0 && qvalid) {
+      const int beta = T.qbeta[q];
+      const float d0 = (float)((int)D0 - (1 << 22) + beta), d1 = (float)((int)D1 - (1 << 22) + beta);
+      const size_t o = (size_t)T.out_off + q;
+      if (ids) { ids[2 * o] = I0; ids[2 * o + 1] = I1; sqd[2 * o] = d0; sqd[2 * o + 1] = d1; }
+      if (code) {
+        const float ratio = d0 / d1;  // fine_matching_graph.cc:118
+        int32_t c = -1;
+        if (ratio < ratio_all) {
+          c = I0;
+          atomicAdd(&n_all[pair], 1);
+          if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
+        }
+        code[o] = c;
+      }
     }
   }
 }
@@ -273,6 +496,7 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
   s->ctx = ctx; s->n_images = n_images; s->dim = dim;
   s->count.assign(n_images, 0);
   s->f32.assign(n_images, nullptr); s->bf16.assign(n_images, nullptr); s->norm.assign(n_images, nullptr);
+  s->ti8.assign(n_images, nullptr); s->qi8.assign(n_images, nullptr); s->tcin.assign(n_images, nullptr); s->tpar.assign(n_images, nullptr); s->qbeta.assign(n_images, nullptr);
   if (s->nonint.alloc(1) != hipSuccess || hipMemsetAsync(s->nonint.p, 0, sizeof(int), ctx->stream) != hipSuccess) {
     delete s;
     return msfm_set_error(ctx, MSFM_E_NOMEM, "descset alloc");
@@ -287,6 +511,11 @@ MSFM_API void msfm_descset_destroy(msfm_descset* s) {
   for (auto p : s->f32) delete p;
   for (auto p : s->bf16) delete p;
   for (auto p : s->norm) delete p;
+  for (auto p : s->ti8) delete p;
+  for (auto p : s->qi8) delete p;
+  for (auto p : s->tcin) delete p;
+  for (auto p : s->tpar) delete p;
+  for (auto p : s->qbeta) delete p;
   delete s;
 }
 
@@ -301,15 +530,22 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   delete s->f32[image]; delete s->bf16[image]; delete s->norm[image];
+  delete s->ti8[image]; delete s->qi8[image]; delete s->tcin[image]; delete s->tpar[image]; delete s->qbeta[image];
   s->f32[image] = new DevBuf<float>(); s->bf16[image] = new DevBuf<unsigned short>(); s->norm[image] = new DevBuf<float>();
+  s->ti8[image] = new DevBuf<signed char>(); s->qi8[image] = new DevBuf<signed char>();
+  s->tcin[image] = new DevBuf<int>(); s->tpar[image] = new DevBuf<int>(); s->qbeta[image] = new DevBuf<int>();
   s->count[image] = count;
   if (count == 0) return MSFM_OK;
   HIP_TRY(ctx, s->f32[image]->alloc((size_t)count * DIM));
   HIP_TRY(ctx, s->bf16[image]->alloc((size_t)count * DIM));
   HIP_TRY(ctx, s->norm[image]->alloc(count));
+  HIP_TRY(ctx, s->ti8[image]->alloc((size_t)count * DIM)); HIP_TRY(ctx, s->qi8[image]->alloc((size_t)count * DIM));
+  HIP_TRY(ctx, s->tcin[image]->alloc(count)); HIP_TRY(ctx, s->tpar[image]->alloc(count)); HIP_TRY(ctx, s->qbeta[image]->alloc(count));
   HIP_TRY(ctx, s->f32[image]->upload(desc, (size_t)count * DIM, st));
   hipLaunchKernelGGL(k_desc_prep, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->bf16[image]->p,
                      s->norm[image]->p, s->nonint.p);
+  hipLaunchKernelGGL(k_desc_prep_i8, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->ti8[image]->p,
+                     s->qi8[image]->p, s->tcin[image]->p, s->tpar[image]->p, s->qbeta[image]->p);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(&s->h_nonint, s->nonint.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -327,7 +563,9 @@ struct msfm_match_result {
   DevBuf<int> ids, n_all, n_good, tile_first;
   DevBuf<float> sqd;
   DevBuf<PairTask> tasks;
+  DevBuf<PairTask8> tasks8;
   DevBuf<PairTaskF> tasksf;
+  bool use_bf16 = false;  // MSFM_KNN_BF16=1 selects the bf16 MFMA kernel instead of the int8 one
   int n_tiles = 0;
   bool exact_path = false;
 };
@@ -338,7 +576,12 @@ static int launch_match(msfm_match_result* R) {
   HIP_TRY(ctx, hipMemsetAsync(R->n_all.p, 0, sizeof(int) * R->n_pairs, st));
   HIP_TRY(ctx, hipMemsetAsync(R->n_good.p, 0, sizeof(int) * R->n_pairs, st));
   if (R->n_tiles == 0) return MSFM_OK;
-  if (!R->exact_path) {
+  if (!R->exact_path && !R->use_bf16) {
+    KTimer t(ctx, "knn2_i8_mfma");
+    hipLaunchKernelGGL(k_knn2_i8, dim3(R->n_tiles), dim3(256), 0, st, R->tasks8.p, R->tile_first.p, R->n_pairs, R->ratio_good,
+                       R->ratio_all, R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr,
+                       R->n_all.p, R->n_good.p);
+  } else if (!R->exact_path) {
     KTimer t(ctx, "knn2_bf16_mfma");
     hipLaunchKernelGGL(k_knn2_bf16, dim3(R->n_tiles), dim3(256), 0, st, R->tasks.p, R->tile_first.p, R->n_pairs, R->ratio_good,
                        R->ratio_all, R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr,
@@ -369,10 +612,12 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
   R->set = s; R->n_pairs = n_pairs; R->keep_knn = keep_knn != 0; R->ratio_good = ratio_good; R->ratio_all = ratio_all;
   R->pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
   R->exact_path = s->h_nonint != 0;
+  { const char* e = getenv("MSFM_KNN_BF16"); R->use_bf16 = e && e[0] == '1'; }
   const int qpb = R->exact_path ? 64 : QPB;
   std::vector<int> tile_first(n_pairs + 1, 0);
   std::vector<PairTask> tasks(n_pairs);
   std::vector<PairTaskF> tasksf(n_pairs);
+  std::vector<PairTask8> tasks8(n_pairs);
   long off = 0;
   long tiles = 0;
   for (int p = 0; p < n_pairs; p++) {
@@ -382,6 +627,7 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
     R->nq.push_back(nq);
     tile_first[p] = (int)tiles;
     tasks[p] = PairTask{s->bf16[a]->p, nq ? s->bf16[b]->p : nullptr, s->norm[a]->p, nq ? s->norm[b]->p : nullptr, s->count[a], nq, (int)off};
+    tasks8[p] = PairTask8{s->ti8[a]->p, nq ? s->qi8[b]->p : nullptr, s->tcin[a]->p, s->tpar[a]->p, nq ? s->qbeta[b]->p : nullptr, s->count[a], nq, (int)off};
     tasksf[p] = PairTaskF{s->f32[a]->p, nq ? s->f32[b]->p : nullptr, s->count[a], nq, (int)off};
     off += nq;
     tiles += cdiv(nq, qpb);
@@ -395,7 +641,7 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
   if (R->keep_knn) { HIP_TRY(ctx, R->ids.alloc(std::max<long>(1, 2 * off))); HIP_TRY(ctx, R->sqd.alloc(std::max<long>(1, 2 * off))); }
   HIP_TRY(ctx, R->n_all.alloc(std::max(1, n_pairs))); HIP_TRY(ctx, R->n_good.alloc(std::max(1, n_pairs)));
   HIP_TRY(ctx, R->tile_first.from(tile_first, st));
-  if (n_pairs) { HIP_TRY(ctx, R->tasks.from(tasks, st)); HIP_TRY(ctx, R->tasksf.from(tasksf, st)); }
+  if (n_pairs) { HIP_TRY(ctx, R->tasks.from(tasks, st)); HIP_TRY(ctx, R->tasksf.from(tasksf, st)); HIP_TRY(ctx, R->tasks8.from(tasks8, st)); }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   MSFM_TRY(launch_match(R));
   guard.p = nullptr;
