@@ -131,29 +131,56 @@ def main():
     for name, st in sorted(ba_stats.items(), key=lambda kv: -kv[1]["total_ms"]):
         kernels.append(dict(kernel=name, launches=st["launches"], ms_per_step=st["total_ms"] / args.steps,
                             avg_launch_us=1e3 * st["total_ms"] / max(1, st["launches"])))
-    # dominant kernel of the BA step and its roofline
-    dom = kernels[0]
-    syrk = ba_stats.get("chol_syrk64_mfma")
+    # per-kernel rooflines from the live HIP-event timings (profiled pass); algorithmic work per launch:
+    #   chol_panel_mfma : the panel launches carry the whole factorisation, n^3/3 flops per solve (FP64 MFMA)
+    #   ba_linearize    : No * (24 B indices + 16 B observation + 26 + 20 doubles written)          (HBM)
+    #   ba_point        : No * (20 doubles read + 24 written) + Np * 12 doubles                      (HBM)
+    #   ba_schur_pairs  : (pairs) * 2 * 144 B gathered                                               (HBM / L2)
+    #   ba_backsub      : No * 26 doubles read + Np * 9 doubles                                      (HBM)
     rooflines = {}
-    if syrk:
-        # the SYRK trailing updates carry n^3/3 of the factorisation's flops
-        fl = n_red ** 3 / 3.0 * (res_p["num_iterations"])
-        ach = fl / (syrk["total_ms"] * 1e-3) / 1e12
-        rooflines["chol_syrk64_mfma"] = dict(bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s",
-                                             frac=ach / FP64_PEAK_TFLOPS, traffic=None,
-                                             note="n^3/3 flops of the dense Cholesky / time in v_mfma_f64_16x16x4 SYRK tiles")
-    for kname, bytes_per_step in (("ba_linearize", sc.n_obs * (24 + 16 + 46 * 8)), ("ba_schur_pairs", None)):
+    n_solves = res_p["num_iterations"]
+
+    def add(kname, bound, work_per_launch, note):
         st = ba_stats.get(kname)
-        if st and bytes_per_step:
-            ach = bytes_per_step * st["launches"] / (st["total_ms"] * 1e-3) / 1e9
-            rooflines[kname] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None)
+        if not st or not st["launches"]:
+            return
+        t = st["total_ms"] * 1e-3 / st["launches"]
+        if bound == "mfma":
+            ach, peak, unit = work_per_launch / t / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = work_per_launch / t / 1e9, HBM_PEAK_GBS, "GB/s"
+        rooflines[kname] = dict(bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak, traffic=None,
+                                avg_launch_us=t * 1e6, launches=st["launches"], note=note)
+
+    k = np.bincount(sc.obs_pt, minlength=sc.n_points).astype(np.int64)
+    n_pairs_cc = int((k * (k + 1) // 2).sum())
+    st = ba_stats.get("chol_panel_mfma")
+    if st:
+        add("chol_panel_mfma", "mfma", (n_red ** 3 / 3.0) * n_solves / max(1, st["launches"]),
+            "n^3/3 = %.2f GFLOP per factorisation spread over %d panel launches (trailing update + next potrf + trsm fused)"
+            % (n_red ** 3 / 3.0 / 1e9, st["launches"] // max(1, n_solves)))
+    add("ba_linearize", "hbm", sc.n_obs * (24 + 16 + 46 * 8), "bytes read + written per linearisation")
+    add("ba_point", "hbm", sc.n_obs * 44 * 8 + sc.n_points * 12 * 8, "SoA Jacobians in, T / T.u records out")
+    add("ba_schur_pairs", "hbm", (n_pairs_cc + sc.n_obs) * 288 + sc.n_points * 144, "two 144-byte T records gathered per pair entry")
+    add("ba_backsub", "hbm", sc.n_obs * 26 * 8 + sc.n_points * 9 * 8, "SoA Jacobians in, candidate points out")
+    add("ba_ftf", "hbm", sc.n_obs * 26 * 8, "camera-major rows in")
+    dom = kernels[0]
     step_bw = alg_bytes / (ba_s / args.steps) / 1e9
-    roofline = dict(bound="hbm", achieved=step_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=step_bw / HBM_PEAK_GBS, traffic=None,
-                    kernel="lm_iteration (all kernels)", dominant_kernel=dom["kernel"],
-                    note="algorithmic bytes of one LM iteration (SURVEY 8d: %.0f MB) / measured time per iteration; "
-                         "FP64 side: %.2f GFLOP Cholesky per iteration" % (alg_bytes / 1e6, chol_flops / 1e9))
-    if dom["kernel"] in rooflines:
-        roofline = dict(rooflines[dom["kernel"]], kernel=dom["kernel"])
+    whole = dict(bound="hbm", achieved=step_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=step_bw / HBM_PEAK_GBS, traffic=None,
+                 kernel="lm_iteration (all kernels)",
+                 note="algorithmic bytes of one LM iteration (SURVEY 8d: %.0f MB) / measured time per iteration; "
+                      "FP64 side: %.2f GFLOP Cholesky per iteration" % (alg_bytes / 1e6, chol_flops / 1e9))
+    roofline = dict(rooflines[dom["kernel"]], kernel=dom["kernel"]) if dom["kernel"] in rooflines else whole
+    # HBM traffic of the dominant kernel from the rocprofv3 PMC passes (profiles/), per launch, if recorded
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            if roofline.get("kernel") in pmc:
+                roofline["traffic"] = pmc[roofline["kernel"]]["bytes_per_launch"]
+                roofline["traffic_source"] = pmc[roofline["kernel"]].get("source")
+        except Exception:
+            pass
 
     out = dict(metric="ba_lm_iterations_per_sec", value=it_s, unit="iterations/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * ba_s / args.steps, higher_is_better=True, scaling="strong",
@@ -163,7 +190,7 @@ def main():
                            parallelism="points sharded over %d rank(s), camera block all-reduced" % world,
                            successful_steps=res["num_successful_steps"], unsuccessful_steps=res["num_unsuccessful_steps"],
                            setup_ms=res["setup_ms"], scene_gen_s=gen_s),
-               roofline=roofline, kernel_rooflines=rooflines, ba_kernels=kernels,
+               roofline=roofline, roofline_whole_step=whole, kernel_rooflines=rooflines, ba_kernels=kernels,
                ba_cost=dict(initial=res["initial_cost"], final=res["final_cost"]))
 
     # ------------------------------------------------------------------ matching leg

@@ -451,7 +451,13 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
                                                 const double* __restrict__ TA, const double* __restrict__ TB,
                                                 const double* __restrict__ UA, double* __restrict__ partial) {
   constexpr int NOUT = DA * DB + (WITH_U ? DA : 0);
-  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // XCD-aware chunk order: workgroups b, b+8, ... share an XCD (and its L2), so hand each XCD a
+  // contiguous range of chunks — chunks are sorted by (row camera, col camera), a contiguous range
+  // keeps re-reading the same cameras' T segments (speed only; any mapping is correct)
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int qn = nwg >> 3, rm = nwg & 7;
+  const int swz = (xcd < rm ? xcd * (qn + 1) : rm * (qn + 1) + (xcd - rm) * qn) + loc;
+  const int chunk = swz * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (chunk >= nchunk) return;
   double acc[NOUT];
 #pragma unroll
@@ -461,10 +467,22 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
     double ta[DA * 3], tb[DB * 3];
     const double* pa_ = TA + (size_t)ia * (DA * 3);
     const double* pb_ = TB + (size_t)ib * (DB * 3);
+    if constexpr (DA == 6) {  // 144-byte records are 16-byte aligned: nine 16-byte loads
+      const double2* v = reinterpret_cast<const double2*>(pa_);
 #pragma unroll
-    for (int k = 0; k < DA * 3; k++) ta[k] = pa_[k];
+      for (int k = 0; k < 9; k++) { const double2 t = v[k]; ta[2 * k] = t.x; ta[2 * k + 1] = t.y; }
+    } else {
 #pragma unroll
-    for (int k = 0; k < DB * 3; k++) tb[k] = pb_[k];
+      for (int k = 0; k < DA * 3; k++) ta[k] = pa_[k];
+    }
+    if constexpr (DB == 6) {
+      const double2* v = reinterpret_cast<const double2*>(pb_);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { const double2 t = v[k]; tb[2 * k] = t.x; tb[2 * k + 1] = t.y; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < DB * 3; k++) tb[k] = pb_[k];
+    }
 #pragma unroll
     for (int a = 0; a < DA; a++)
 #pragma unroll
@@ -1026,7 +1044,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
   AL(ptL, 6 * (size_t)npb); AL(ptg, 3 * (size_t)npb);
   AL(f_partial, (size_t)ba->n_fchunks * PSTRIDE); AL(camftf, (size_t)ncb * PSTRIDE); AL(modelsum, 12 * (size_t)nmb);
-  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 80); /* 16x16 inverses + full 64x64 block inverses */ AL(w, ba->npad); AL(z, ba->npad);
+  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad);
   AL(g_r, 3 * (size_t)ncb); AL(g_J, 3 * (size_t)ncb);
   ba->nblk_obs = cdiv(As, 256);
   ba->nblk_pt = cdiv(std::max(1, npb), 32);  // 8 lanes per point

@@ -108,7 +108,8 @@ __device__ __forceinline__ void potrf64_lds(double* __restrict__ a /*[64][LDT]*/
   }
 }
 
-__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ M, int ld, int j0, int n, double* __restrict__ Dinv, int* fail) {
+__global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ M, int ld, int j0, int n, double* __restrict__ Dinv,
+                                                  double* __restrict__ Ldiag, int* fail) {
   __shared__ double a[NB * LDT];
   __shared__ double dinv[4 * 16 * 17];
   __shared__ double rdiag[NB];
@@ -136,6 +137,8 @@ __global__ __launch_bounds__(256) void k_potrf64(double* __restrict__ M, int ld,
   }
   double* out = Dinv + (size_t)(j0 / NB) * 1024;
   for (int e = tid; e < 1024; e += 256) out[e] = dinv[(e >> 4) * 17 + (e & 15)];
+  double* lo = Ldiag + (size_t)(j0 / NB) * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) lo[e] = ((e & 63) <= (e >> 6)) ? a[(e >> 6) * LDT + (e & 63)] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -198,27 +201,16 @@ __global__ __launch_bounds__(256) void k_trsm64(double* __restrict__ M, int ld, 
 }
 
 // ---------------------------------------------------------------------------------------
-// syrk: for every 64x64 tile (I >= J) of the trailing matrix, C_IJ -= P_I * P_J^T where
-// P = the 64-column panel just solved.  4 waves, each a 32x32 quadrant = 2x2 MFMA tiles.
-// blockIdx.x enumerates the lower-triangular tile pairs.
+// One launch per panel j:  trailing update  C_IJ -= P_I P_J^T  (64x64 tiles, K = 64, f64 MFMA),
+// with the next panel's factorisation and triangular solve folded in and NO cross-workgroup
+// dependency: every workgroup that owns a column-0 tile (I,0) also forms the updated diagonal tile
+// (0,0) for itself (P_0 is already in LDS as its B operand), factors it redundantly (potrf64_lds —
+// bit-identical in every workgroup) and then solves its own tile against it.  Workgroup (0,0)
+// publishes the factor (Ldiag, Dinv).  The diagonal tiles of M itself are never overwritten with L,
+// so late-starting column-0 workgroups always read the pre-factorisation values.
+// blockIdx.x < nt : tile (blockIdx.x, 0);  the rest enumerate (I, J >= 1) pairs.
 // ---------------------------------------------------------------------------------------
-// The workgroup that owns tile (0,0) — the next diagonal block — goes on to factor it (potrf64_lds)
-// while the other workgroups are still updating: the next panel's potrf costs no launch of its own.
-__global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, int j0, int ntile, int n,
-                                                 double* __restrict__ Dinv, int* fail) {
-  __shared__ double As[64 * LDT];
-  __shared__ double Bs[64 * LDT];
-  // tile pair from linear index: I = floor((sqrt(8b+1)-1)/2), J = b - I(I+1)/2
-  const int b = blockIdx.x;
-  int I = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
-  while ((I + 1) * (I + 2) / 2 <= b) I++;
-  while (I * (I + 1) / 2 > b) I--;
-  const int J = b - I * (I + 1) / 2;
-  (void)ntile;
-  const int t0 = j0 + NB;  // first trailing row
-  const int ri = t0 + I * 64, rj = t0 + J * 64;
-  const int tid = threadIdx.x;
-  // coalesced 16-byte loads: 64 rows x 64 cols
+__device__ __forceinline__ void load_tile_pair(const double* __restrict__ M, int ld, int ri, int rj, int j0, double* As, double* Bs, int tid) {
   for (int e = tid; e < 64 * 32; e += 256) {
     const int r = e >> 5, c2 = (e & 31) * 2;
     const d2 va = *reinterpret_cast<const d2*>(&M[(size_t)(ri + r) * ld + j0 + c2]);
@@ -228,60 +220,138 @@ __global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, 
     Bs[r * LDT + c2] = vb.x;
     Bs[r * LDT + c2 + 1] = vb.y;
   }
-  __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-  d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
-  const double* ap0 = &As[(32 * wr + lr) * LDT + lk];
+}
+
+// acc (2x2 MFMA tiles of this wave's 32x32 quadrant) = X_rows(32 wr..) * Y_rows(32 wc..)^T over K = 64
+__device__ __forceinline__ void quad_abt(const double* X, const double* Y, int wr, int wc, int lr, int lk, d4& a00, d4& a01, d4& a10, d4& a11) {
+  const double* ap0 = &X[(32 * wr + lr) * LDT + lk];
   const double* ap1 = ap0 + 16 * LDT;
-  const double* bp0 = &Bs[(32 * wc + lr) * LDT + lk];
+  const double* bp0 = &Y[(32 * wc + lr) * LDT + lk];
   const double* bp1 = bp0 + 16 * LDT;
 #pragma unroll
   for (int k0 = 0; k0 < NB; k0 += 4) {
     const double a0 = ap0[k0], a1 = ap1[k0], b0 = bp0[k0], b1 = bp1[k0];
-    acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc00, 0, 0, 0);
-    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc01, 0, 0, 0);
-    acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc10, 0, 0, 0);
-    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc11, 0, 0, 0);
+    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, a00, 0, 0, 0);
+    a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, a01, 0, 0, 0);
+    a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, a10, 0, 0, 0);
+    a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, a11, 0, 0, 0);
   }
+}
+
+__global__ __launch_bounds__(256) void k_panel64(double* __restrict__ M, int ld, int j0, int nt, int n, double* __restrict__ Dinv,
+                                                  double* __restrict__ Ldiag, int* fail) {
+  __shared__ double As[64 * LDT];
+  __shared__ double Bs[64 * LDT];
+  __shared__ double Cs[64 * LDT];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int t0 = j0 + NB;  // first trailing row
+  int I, J;
+  if ((int)blockIdx.x < nt) {
+    I = blockIdx.x; J = 0;
+  } else {
+    // pairs (I, J) with 1 <= J <= I < nt, enumerated row by row: index q = I(I-1)/2 + (J-1)
+    const int q = blockIdx.x - nt;
+    I = (int)((sqrt(8.0 * q + 1.0) + 1.0) * 0.5);
+    while (I * (I - 1) / 2 > q) I--;
+    while ((I + 1) * I / 2 <= q) I++;
+    J = q - I * (I - 1) / 2 + 1;
+  }
+  const int ri = t0 + I * 64, rj = t0 + J * 64;
+  load_tile_pair(M, ld, ri, rj, j0, As, Bs, tid);
+  __syncthreads();
+  d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  quad_abt(As, Bs, wr, wc, lr, lk, acc00, acc01, acc10, acc11);
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
-  const int crow = ri + 32 * wr + lk, ccol = rj + 32 * wc + lr;
+  const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;  // quadrant-local origin of this lane's values
   const int ncol_next = min(NB, n - t0);
-  if (b == 0 && ncol_next > 0) {
-    // updated diagonal tile -> LDS (As), then factor it in place
-    __syncthreads();  // every wave is done reading As / Bs
-    double* dinv = Bs;            // 4*16*17 doubles
-    double* rdiag = Bs + 4 * 16 * 17;
+  if (J != 0 || ncol_next <= 0) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int lrow = 32 * wr + lk + 4 * i, lcol = 32 * wc + lr;
-      As[lrow * LDT + lcol] = M[(size_t)(crow + 4 * i) * ld + ccol] - acc00[i];
-      As[lrow * LDT + lcol + 16] = M[(size_t)(crow + 4 * i) * ld + ccol + 16] - acc01[i];
-      As[(lrow + 16) * LDT + lcol] = M[(size_t)(crow + 16 + 4 * i) * ld + ccol] - acc10[i];
-      As[(lrow + 16) * LDT + lcol + 16] = M[(size_t)(crow + 16 + 4 * i) * ld + ccol + 16] - acc11[i];
+      double* c0 = &M[(size_t)(ri + qrow + 4 * i) * ld + rj + qcol];
+      double* c1 = &M[(size_t)(ri + qrow + 16 + 4 * i) * ld + rj + qcol];
+      c0[0] -= acc00[i];
+      c0[16] -= acc01[i];
+      c1[0] -= acc10[i];
+      c1[16] -= acc11[i];
     }
-    for (int e = tid; e < 4 * 16 * 17; e += 256) dinv[e] = ((e % 17) == ((e / 17) & 15)) ? 1.0 : 0.0;
-    __syncthreads();
-    if (ncol_next == NB) potrf64_lds<true>(As, dinv, rdiag, ncol_next, tid, fail);
-    else potrf64_lds<false>(As, dinv, rdiag, ncol_next, tid, fail);
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      if (c <= r) M[(size_t)(t0 + r) * ld + t0 + c] = As[r * LDT + c];
-    }
-    double* out = Dinv + (size_t)(t0 / NB) * 1024;
-    for (int e = tid; e < 1024; e += 256) out[e] = dinv[(e >> 4) * 17 + (e & 15)];
     return;
   }
+  // ---- column-0 workgroup: updated diagonal tile -> As, own updated tile -> Cs ----
+  d4 d00 = acc00, d01 = acc01, d10 = acc10, d11 = acc11;
+  if (I != 0) {
+    d00 = d4{0, 0, 0, 0}; d01 = d00; d10 = d00; d11 = d00;
+    quad_abt(Bs, Bs, wr, wc, lr, lk, d00, d01, d10, d11);  // P_0 P_0^T
+  }
+  __syncthreads();  // every wave is done reading As / Bs
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    double* c0 = &M[(size_t)(crow + 4 * i) * ld + ccol];
-    double* c1 = &M[(size_t)(crow + 16 + 4 * i) * ld + ccol];
-    c0[0] -= acc00[i];
-    c0[16] -= acc01[i];
-    c1[0] -= acc10[i];
-    c1[16] -= acc11[i];
+    const int r0 = qrow + 4 * i, r1 = r0 + 16;
+    As[r0 * LDT + qcol] = M[(size_t)(t0 + r0) * ld + t0 + qcol] - d00[i];
+    As[r0 * LDT + qcol + 16] = M[(size_t)(t0 + r0) * ld + t0 + qcol + 16] - d01[i];
+    As[r1 * LDT + qcol] = M[(size_t)(t0 + r1) * ld + t0 + qcol] - d10[i];
+    As[r1 * LDT + qcol + 16] = M[(size_t)(t0 + r1) * ld + t0 + qcol + 16] - d11[i];
+    if (I != 0) {
+      Cs[r0 * LDT + qcol] = M[(size_t)(ri + r0) * ld + t0 + qcol] - acc00[i];
+      Cs[r0 * LDT + qcol + 16] = M[(size_t)(ri + r0) * ld + t0 + qcol + 16] - acc01[i];
+      Cs[r1 * LDT + qcol] = M[(size_t)(ri + r1) * ld + t0 + qcol] - acc10[i];
+      Cs[r1 * LDT + qcol + 16] = M[(size_t)(ri + r1) * ld + t0 + qcol + 16] - acc11[i];
+    }
   }
+  double* dinv = Bs;  // 4*16*17 doubles
+  double* rdiag = Bs + 4 * 16 * 17;
+  for (int e = tid; e < 4 * 16 * 17; e += 256) dinv[e] = ((e % 17) == ((e / 17) & 15)) ? 1.0 : 0.0;
+  __syncthreads();
+  if (ncol_next == NB) potrf64_lds<true>(As, dinv, rdiag, ncol_next, tid, fail);
+  else potrf64_lds<false>(As, dinv, rdiag, ncol_next, tid, fail);
+  if (I == 0) {
+    double* lo = Ldiag + (size_t)(t0 / NB) * NB * NB;
+    for (int e = tid; e < NB * NB; e += 256) lo[e] = ((e & 63) <= (e >> 6)) ? As[(e >> 6) * LDT + (e & 63)] : 0.0;
+    double* out = Dinv + (size_t)(t0 / NB) * 1024;
+    for (int e = tid; e < 1024; e += 256) out[e] = dinv[(e >> 4) * 17 + (e & 15)];
+    if (ncol_next < NB) {
+      // last, partial block: it also holds the rhs row (row n), whose entries are the tail of
+      // w = L^-1 rhs that the back substitution reads from M.  This workgroup is the only one of the
+      // launch in that case (nt == 1), so writing the tile back cannot race with a reader.
+      for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (c <= r) M[(size_t)(t0 + r) * ld + t0 + c] = As[r * LDT + c];
+      }
+    }
+    return;
+  }
+  // ---- X = C_I0 L11^-T for this workgroup's 64 rows: wave-local blocked substitution (see k_trsm64) ----
+  const int lj = lane & 15, lq = lane >> 4;
+  const double* crow = &Cs[(16 * wave + lj) * LDT];
+  double* mrow = M + (size_t)(ri + 16 * wave + lj) * ld + t0;
+  d4 X[4];
+#pragma unroll
+  for (int jb = 0; jb < 4; jb++) {
+    d4 T;
+#pragma unroll
+    for (int i = 0; i < 4; i++) T[i] = crow[16 * jb + lq + 4 * i];
+#pragma unroll
+    for (int i2 = 0; i2 < jb; i2++) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        const double av = -As[(16 * jb + lj) * LDT + 16 * i2 + lq + 4 * s4];
+        T = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[i2][s4], T, 0, 0, 0);
+      }
+    }
+    d4 Y = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const double av = dinv[(16 * jb + lj) * 17 + lq + 4 * s4];
+      Y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, T[s4], Y, 0, 0, 0);
+    }
+    X[jb] = Y;
+  }
+#pragma unroll
+  for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) mrow[16 * jb + lq + 4 * i] = X[jb][i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -289,7 +359,7 @@ __global__ __launch_bounds__(256) void k_syrk64(double* __restrict__ M, int ld, 
 // factorisation, off the critical path): from the 16x16 inverses by two doubling steps
 //   inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1  C^-1].   Linv[blk] row-major 64x64.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ M, int ld, int n, const double* __restrict__ Dinv,
+__global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ Ldiag, int n, const double* __restrict__ Dinv,
                                                        double* __restrict__ Linv) {
   __shared__ double L[NB][NB + 1];
   __shared__ double v[NB][NB + 1];
@@ -298,7 +368,7 @@ __global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__
   const int ncol = min(NB, n - j0);
   for (int e = tid; e < NB * NB; e += 256) {
     const int r = e >> 6, c = e & 63;
-    L[r][c] = (c <= r && r < ncol) ? M[(size_t)(j0 + r) * ld + j0 + c] : 0.0;
+    L[r][c] = (c <= r && r < ncol) ? Ldiag[(size_t)blk * NB * NB + r * NB + c] : 0.0;
     const bool diag16 = (r >> 4) == (c >> 4);
     v[r][c] = diag16 ? Dinv[(size_t)blk * 1024 + ((r >> 4) * 16 + (r & 15)) * 16 + (c & 15)] : 0.0;
   }
@@ -379,7 +449,7 @@ __global__ void k_copy_row(const double* __restrict__ M, int ld, int row, int n,
 
 // Host driver.  M: npad x npad, row n = rhs.  On return z[0..n) solves S z = rhs.
 // `fail` (device int) is OR-ed with 1 when S is not positive definite.
-// work: npad*16 doubles for the 16x16 inverses followed by npad*64 for the full block inverses.
+// work: npad*16 doubles (16x16 inverses) + npad*64 (full block inverses) + npad*64 (diagonal blocks of L).
 int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z,
                            int* fail) {
   if (!M || !work || !w || !z || !fail || npad % NB != 0 || n < 1 || n + 1 > npad)
@@ -389,9 +459,14 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   const int nrows = n + 1;  // rows that carry data (S plus the rhs row)
   double* Dinv = work;
   double* Linv = work + (size_t)npad * 16;
+  double* Ldiag = work + (size_t)npad * 80;
   {
     KTimer t(ctx, "chol_potrf64");
-    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, 0, n, Dinv, fail);
+    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, 0, n, Dinv, Ldiag, fail);
+  }
+  if (nrows > NB) {
+    KTimer t(ctx, "chol_trsm_mfma");
+    hipLaunchKernelGGL(k_trsm64, dim3(cdiv(nrows - NB, 64)), dim3(256), 0, s, M, npad, 0, Dinv);
   }
   for (int jb = 0; jb < nblk; jb++) {
     const int j0 = jb * NB;
@@ -399,18 +474,12 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     const int rows_below = nrows - (j0 + NB);
     if (rows_below <= 0) continue;
     const int nt = cdiv(rows_below, 64);
-    {
-      KTimer t(ctx, "chol_trsm_mfma");
-      hipLaunchKernelGGL(k_trsm64, dim3(nt), dim3(256), 0, s, M, npad, j0, Dinv);
-    }
-    {
-      KTimer t(ctx, "chol_syrk_potrf_mfma");  // trailing update + factorisation of the next diagonal block
-      hipLaunchKernelGGL(k_syrk64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, M, npad, j0, nt, n, Dinv, fail);
-    }
+    KTimer t(ctx, "chol_panel_mfma");  // trailing update + next panel's potrf + trsm, one launch
+    hipLaunchKernelGGL(k_panel64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, M, npad, j0, nt, n, Dinv, Ldiag, fail);
   }
   {
     KTimer t(ctx, "chol_backsolve");
-    hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB)), dim3(256), 0, s, M, npad, n, Dinv, Linv);
+    hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB)), dim3(256), 0, s, Ldiag, n, Dinv, Linv);
     hipLaunchKernelGGL(k_copy_row, dim3(cdiv(npad, 256)), dim3(256), 0, s, M, npad, n, n, w, npad);
     for (int jb = cdiv(n, NB) - 1; jb >= 0; jb--)
       hipLaunchKernelGGL(k_backsolve_step, dim3(jb > 0 ? jb : 1), dim3(256), 0, s, M, npad, n, jb, Linv, w, z);
