@@ -108,6 +108,10 @@ int msfm_match_result_counts(msfm_match_result* res, int* n_all /*[n_pairs]*/,
 /* code[count(idx2)]; ids/sqdists may be NULL, and are only available with keep_knn. */
 int msfm_match_result_fetch(msfm_match_result* res, int pair, int32_t* code, int* ids,
                             float* sqdists);
+/* Non-integral descriptors go through an approximate shortlist + exact re-rank; queries whose
+ * shortlist could not be certified are redone by exact brute force.  n_slow_path counts them
+ * (0 for integer-valued data, which takes the exact int8 kernel). */
+int msfm_match_result_stats(msfm_match_result* res, int* n_queries, int* n_slow_path);
 void msfm_match_result_destroy(msfm_match_result* res);
 /* Re-run the same pair list into an existing result object (steady-state bench loop:
  * no allocation, no host transfer). */

@@ -18,7 +18,7 @@ SYMBOLS = [
     "msfm_version", "msfm_ctx_create", "msfm_ctx_destroy", "msfm_last_error", "msfm_ctx_stream",
     "msfm_ctx_synchronize", "msfm_ctx_profile_enable", "msfm_ctx_profile_reset", "msfm_ctx_profile_get",
     "msfm_knn2_f32", "msfm_descset_create", "msfm_descset_upload", "msfm_descset_count", "msfm_descset_destroy",
-    "msfm_match_pairs", "msfm_match_result_counts", "msfm_match_result_fetch", "msfm_match_result_destroy",
+    "msfm_match_pairs", "msfm_match_result_counts", "msfm_match_result_fetch", "msfm_match_result_stats", "msfm_match_result_destroy",
     "msfm_match_pairs_rerun", "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
     "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
@@ -63,6 +63,7 @@ def lib():
     L.msfm_match_pairs_rerun.argtypes = [vp, vp]
     L.msfm_match_result_counts.argtypes = [vp, A.c_int_p, A.c_int_p]
     L.msfm_match_result_fetch.argtypes = [vp, i, A.c_int_p, A.c_int_p, A.c_float_p]
+    L.msfm_match_result_stats.argtypes = [vp, A.c_int_p, A.c_int_p]
     L.msfm_match_result_destroy.argtypes = [vp]
     L.msfm_match_result_destroy.restype = None
     L.msfm_ba_options_default.argtypes = [C.POINTER(A.BaOptions)]
@@ -261,6 +262,11 @@ class MatchResult:
         na, ng = np.zeros(len(self.pairs), np.int32), np.zeros(len(self.pairs), np.int32)
         self.ctx.check(lib().msfm_match_result_counts(self._h, A.ptr(na, A.c_int_p), A.ptr(ng, A.c_int_p)))
         return na, ng
+
+    def stats(self):
+        nq, ns = C.c_int32(), C.c_int32()
+        self.ctx.check(lib().msfm_match_result_stats(self._h, C.byref(nq), C.byref(ns)))
+        return dict(queries=nq.value, slow_path=ns.value)
 
     def fetch(self, pair):
         nq = self.ds.counts[self.pairs[pair, 1]]

@@ -40,6 +40,11 @@ struct msfm_descset {
   //   |a-b|^2 = 2 sum (a-128)(127-b) + sum (a-127)^2 + sum (128-b)^2 - 128
   std::vector<DevBuf<signed char>*> ti8, qi8;   // [count][128]
   std::vector<DevBuf<int>*> tcin, tpar, qbeta;  // (alpha>>1)+2^21 ; alpha&1 ; beta
+  // split-bf16 forms for non-integral descriptors: v ~ hi + lo (two bf16 terms, 16 significant bits)
+  std::vector<DevBuf<unsigned short>*> shi, slo;  // [count][128]
+  std::vector<DevBuf<float>*> sn2;                // [count]  |v|^2 (binary64 sum rounded once)
+  std::vector<float> sn2max;                      // per image max |v|^2 (host copy)
+  DevBuf<unsigned> n2max_dev;
   DevBuf<int> nonint;                    // OR of "not integer in [0,255]" over all uploads
   int h_nonint = 0;
 };
@@ -487,6 +492,299 @@ __global__ __launch_bounds__(64) void k_knn2_exact(const PairTaskF* __restrict__
   }
 }
 
+// ---- split-bf16 path for non-integral descriptors ---------------------------------------------
+// v is split into two bf16 terms (hi + lo, 16 significant bits); a.b ~ ah.bh + ah.bl + al.bh on the
+// bf16 MFMA with fp32 accumulation gives every distance to within eps (bound below).  Each query
+// keeps its 4 best approximate candidates; k_rerank evaluates those 4 exactly (binary64, k
+// sequential, the oracle's definition) and accepts the answer only if no candidate outside the
+// shortlist can beat it:  d4_approx - eps > d2_exact.  Queries that fail the test (exact duplicates,
+// near ties) are redone by the exact brute force k_exact_flagged, so the result is exact for every
+// finite input; how many took the slow road is reported in the result object.
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v) {
+  const u32 u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // finite inputs only
+}
+
+__global__ __launch_bounds__(256) void k_desc_prep_split(const float* __restrict__ d, int count, unsigned short* __restrict__ hi,
+                                                          unsigned short* __restrict__ lo, float* __restrict__ n2,
+                                                          unsigned* __restrict__ n2max) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= count) return;
+  const float2 v = reinterpret_cast<const float2*>(d + (size_t)row * DIM)[lane];
+  ushort2 h, l;
+  h.x = f32_to_bf16_rne(v.x); h.y = f32_to_bf16_rne(v.y);
+  l.x = f32_to_bf16_rne(v.x - __uint_as_float((u32)h.x << 16));
+  l.y = f32_to_bf16_rne(v.y - __uint_as_float((u32)h.y << 16));
+  reinterpret_cast<ushort2*>(hi + (size_t)row * DIM)[lane] = h;
+  reinterpret_cast<ushort2*>(lo + (size_t)row * DIM)[lane] = l;
+  double s = (double)v.x * v.x + (double)v.y * v.y;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) {
+    const float f = (float)s;
+    n2[row] = f;
+    atomicMax(n2max, __float_as_uint(f));  // non-negative floats order like their bit patterns
+  }
+}
+
+struct PairTaskS {
+  const unsigned short *thi, *tlo, *qhi, *qlo;
+  const float *tn2, *qn2;
+  const float *tf32, *qf32;
+  float tn2max;
+  int n_train, n_query, out_off;
+};
+
+#define QPS 128  // queries per workgroup in the split kernel (4 waves x 32)
+
+__device__ __forceinline__ void load_query_frags_split(const unsigned short* qp, int h, bf16x8* bq) {
+#pragma unroll
+  for (int ks = 0; ks < 8; ks++) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(qp + ks * 16 + h * 8);
+    u32 w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      // bf16 x -> -2x: exponent + 1, sign flipped; zero / subnormal -> 0
+      u32 a = w[j] & 0xffffu, b = w[j] >> 16;
+      a = (a & 0x7F80u) ? (((a + 0x0080u) ^ 0x8000u) & 0xffffu) : 0u;
+      b = (b & 0x7F80u) ? (((b + 0x0080u) ^ 0x8000u) & 0xffffu) : 0u;
+      w[j] = a | (b << 16);
+    }
+    bq[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+  }
+}
+
+// sorted insert of key x into k0 <= k1 <= k2 <= k3
+__device__ __forceinline__ void top4_insert(u32& k0, u32& k1, u32& k2, u32& k3, u32 x) {
+  u32 t = max(k0, x); k0 = min(k0, x);
+  u32 t2 = max(k1, t); k1 = min(k1, t);
+  u32 t3 = max(k2, t2); k2 = min(k2, t2);
+  k3 = min(k3, t3);
+}
+// (value bits, index) lists, 4 entries, ordered by (value, index)
+__device__ __forceinline__ void list4_insert(u32 (&v)[4], int (&id)[4], u32 x, int xi) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const bool lt = x < v[j] || (x == v[j] && xi < id[j]);
+    const u32 tv = lt ? v[j] : x;
+    const int ti = lt ? id[j] : xi;
+    v[j] = lt ? x : v[j];
+    id[j] = lt ? xi : id[j];
+    x = tv; xi = ti;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_knn2_split(const PairTaskS* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+                                                        int* __restrict__ cand /*[q][4]*/, float* __restrict__ d4a /*[q]*/) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_hi[2 * TT * 256];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_lo[2 * TT * 256];
+  __shared__ __attribute__((aligned(16))) float lds_n[2 * TT];
+  int lo_ = 0, hi_ = n_pairs - 1;
+  const int bid = blockIdx.x;
+  while (lo_ < hi_) {
+    const int mid = (lo_ + hi_ + 1) >> 1;
+    if (tile_first[mid] <= bid) lo_ = mid; else hi_ = mid - 1;
+  }
+  const int pair = lo_;
+  const PairTaskS T = tasks[pair];
+  const int q0 = (bid - tile_first[pair]) * QPS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int q = q0 + wave * 32 + r;
+  const bool qvalid = q < T.n_query;
+  bf16x8 bh[8], bl[8];
+  load_query_frags_split(T.qhi + (size_t)(qvalid ? q : 0) * DIM, h, bh);
+  load_query_frags_split(T.qlo + (size_t)(qvalid ? q : 0) * DIM, h, bl);
+  const float b2 = T.qn2[qvalid ? q : 0];
+  // every approximate distance is within eps of the exact one; shifting by 2 eps keeps them positive
+  const float eps = 2.44140625e-4f * sqrtf(T.tn2max * b2) + 4.76837158e-7f * (T.tn2max + b2) + 1e-30f;
+  const float shift = b2 + 2.0f * eps;
+  u32 k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
+  u32 gv[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  int gi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  const int n_tiles = (T.n_train + TT - 1) / TT;
+  uint4 sh[4], sl[4];
+  float stage_n = 0.f;
+  auto fetch = [&](int tile) {
+    const int t0 = tile * TT;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+      sh[i] = make_uint4(0, 0, 0, 0); sl[i] = make_uint4(0, 0, 0, 0);
+      if (t0 + row < T.n_train) {
+        sh[i] = *reinterpret_cast<const uint4*>(T.thi + (size_t)(t0 + row) * DIM + ch * 8);
+        sl[i] = *reinterpret_cast<const uint4*>(T.tlo + (size_t)(t0 + row) * DIM + ch * 8);
+      }
+    }
+    if (tid < TT) stage_n = (t0 + tid < T.n_train) ? T.tn2[t0 + tid] : 3.0e38f;  // padding rows lose every comparison
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+      const int off = buf * TT * 256 + row * 256 + ((ch ^ (row & 15)) << 4);
+      *reinterpret_cast<uint4*>(lds_hi + off) = sh[i];
+      *reinterpret_cast<uint4*>(lds_lo + off) = sl[i];
+    }
+    if (tid < TT) lds_n[buf * TT + tid] = stage_n;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = 0; tile < n_tiles; tile++) {
+    if (tile + 1 < n_tiles) fetch(tile + 1);
+#pragma unroll
+    for (int st = 0; st < 2; st++) {
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const f32x4 nv = *reinterpret_cast<const f32x4*>(&lds_n[cur * TT + st * 32 + 8 * g + 4 * h]);
+        acc[4 * g + 0] = nv.x; acc[4 * g + 1] = nv.y; acc[4 * g + 2] = nv.z; acc[4 * g + 3] = nv.w;
+      }
+      const int row = st * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        const int ch = 2 * ks + h;
+        const int off = cur * TT * 256 + row * 256 + ((ch ^ (row & 15)) << 4);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds_hi + off);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds_lo + off);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
+      }
+      const int wbase = ((tile & 3) * 2 + st) * 32;
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        const float v = fmaxf(acc[reg] + shift, 0.0f);  // > 0 whenever eps is a valid bound; the clamp only guards NaN-free ordering
+        const u32 key = (__float_as_uint(v) & 0xffffff00u) | (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
+        top4_insert(k0, k1, k2, k3, key);
+      }
+    }
+    if ((tile & 3) == 3 || tile == n_tiles - 1) {
+      const int base = (tile & ~3) * TT + 4 * h;
+      const u32 ks4[4] = {k0, k1, k2, k3};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (ks4[j] != 0xffffffffu) list4_insert(gv, gi, ks4[j] & 0xffffff00u, base + (int)(ks4[j] & 255u));
+      k0 = k1 = k2 = k3 = 0xffffffffu;
+    }
+    if (tile + 1 < n_tiles) commit(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // merge the two lane halves of each query
+  {
+    u32 pv[4]; int pi[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { pv[j] = __shfl_xor(gv[j], 32, 64); pi[j] = __shfl_xor(gi[j], 32, 64); }
+#pragma unroll
+    for (int j = 0; j < 4; j++) list4_insert(gv, gi, pv[j], pi[j]);
+  }
+  if (h == 0 && qvalid) {
+    const size_t o = (size_t)T.out_off + q;
+#pragma unroll
+    for (int j = 0; j < 4; j++) cand[4 * o + j] = (gv[j] == 0xffffffffu || gi[j] >= T.n_train) ? -1 : gi[j];  // padding rows are not candidates
+    // approximate distance of the 4th candidate (lower end of its truncation bucket), un-shifted
+    d4a[o] = (gv[3] == 0xffffffffu) ? 3.0e38f : __uint_as_float(gv[3]) - 2.0f * eps;  // key value = approx distance + 2 eps
+  }
+}
+
+// exact distance, the oracle's definition: binary64, k sequential, one fma per term
+__device__ __forceinline__ double exact_sqdist(const float* __restrict__ a, const float* __restrict__ b) {
+  double s = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < DIM; k++) {
+    const double d = (double)a[k] - (double)b[k];
+    s = fma(d, d, s);
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_rerank(const PairTaskS* __restrict__ tasks, const int* __restrict__ qpair /*[total_q]*/,
+                                                 long total_q, const int* __restrict__ cand, const float* __restrict__ d4a,
+                                                 int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ flagged,
+                                                 int* __restrict__ n_flagged) {
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= total_q) return;
+  const int pair = qpair[o];
+  const PairTaskS T = tasks[pair];
+  const int q = (int)(o - T.out_off);
+  const float* qv = T.qf32 + (size_t)q * DIM;
+  double d0 = __builtin_inf(), d1 = __builtin_inf();
+  int i0 = -1, i1 = -1;
+  for (int j = 0; j < 4; j++) {
+    const int t = cand[4 * o + j];
+    if (t < 0) continue;
+    const double s = exact_sqdist(T.tf32 + (size_t)t * DIM, qv);
+    if (s < d0 || (s == d0 && t < i0)) { d1 = d0; i1 = i0; d0 = s; i0 = t; }
+    else if (s < d1 || (s == d1 && t < i1)) { d1 = s; i1 = t; }
+  }
+  ids[2 * o] = i0; ids[2 * o + 1] = i1;
+  sqd[2 * o] = (float)d0; sqd[2 * o + 1] = (float)d1;
+  if (T.n_train > 4) {
+    // can a row outside the shortlist beat the second best?  Its exact distance is at least
+    // d4_approx - eps (eps: split-bf16 products dropped, fp32 accumulation, key truncation).
+    const float b2 = T.qn2[q];
+    const double eps = 2.44140625e-4 * sqrt((double)T.tn2max * b2) + 4.76837158e-7 * ((double)T.tn2max + b2) + 1e-30;
+    const double d4 = (double)d4a[o];
+    // (d4a is the lower end of the 4th key's truncation bucket, so the dropped mantissa bits are already on the safe side;
+    //  the 2^-22 |d4| term covers the fp32 rounding of the shift itself)
+    const double bound = d4 - eps - 2.4e-7 * fabs(d4);
+    if (!(bound > d1)) flagged[atomicAdd(n_flagged, 1)] = (int)o;
+  }
+}
+
+// exact brute force for the queries the shortlist could not certify: one wave per flagged query
+__global__ __launch_bounds__(64) void k_exact_flagged(const PairTaskS* __restrict__ tasks, const int* __restrict__ qpair,
+                                                       const int* __restrict__ flagged, const int* __restrict__ n_flagged,
+                                                       int* __restrict__ ids, float* __restrict__ sqd) {
+  const int nf = *n_flagged, lane = threadIdx.x;
+  for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+    const long o = flagged[f];
+    const PairTaskS T = tasks[qpair[o]];
+    const int q = (int)(o - T.out_off);
+    const float* qv = T.qf32 + (size_t)q * DIM;
+    double d0 = __builtin_inf(), d1 = __builtin_inf();
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    for (int t = lane; t < T.n_train; t += 64) {
+      const double s = exact_sqdist(T.tf32 + (size_t)t * DIM, qv);
+      if (s < d0) { d1 = d0; i1 = i0; d0 = s; i0 = t; }
+      else if (s < d1) { d1 = s; i1 = t; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double e0 = __shfl_xor(d0, off, 64), e1 = __shfl_xor(d1, off, 64);
+      const int j0 = __shfl_xor(i0, off, 64), j1 = __shfl_xor(i1, off, 64);
+      // merge two sorted pairs, ties -> lower index
+      if (e0 < d0 || (e0 == d0 && j0 < i0)) {
+        const bool second_is_mine = d0 < e1 || (d0 == e1 && i0 < j1);
+        d1 = second_is_mine ? d0 : e1; i1 = second_is_mine ? i0 : j1;
+        d0 = e0; i0 = j0;
+      } else if (e0 < d1 || (e0 == d1 && j0 < i1)) {
+        d1 = e0; i1 = j0;
+      }
+    }
+    if (lane == 0) { ids[2 * o] = i0; ids[2 * o + 1] = i1; sqd[2 * o] = (float)d0; sqd[2 * o + 1] = (float)d1; }
+  }
+}
+
+// ratio tests on final (ids, sqd): fine_matching_graph.cc:116-133
+__global__ __launch_bounds__(256) void k_codes(const int* __restrict__ qpair, long total_q, const int* __restrict__ ids,
+                                                const float* __restrict__ sqd, float ratio_good, float ratio_all,
+                                                int32_t* __restrict__ code, int* __restrict__ n_all, int* __restrict__ n_good) {
+  const long o = (long)blockIdx.x * 256 + threadIdx.x;
+  if (o >= total_q) return;
+  const float ratio = sqd[2 * o] / sqd[2 * o + 1];
+  int32_t c = -1;
+  if (ratio < ratio_all) {
+    c = ids[2 * o];
+    atomicAdd(&n_all[qpair[o]], 1);
+    if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[qpair[o]], 1); }
+  }
+  code[o] = c;
+}
+
 // ---- host ---------------------------------------------------------------------------------
 MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_descset** out) {
   if (!ctx || !out || n_images <= 0) return MSFM_E_INVAL;
@@ -496,8 +794,9 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
   s->ctx = ctx; s->n_images = n_images; s->dim = dim;
   s->count.assign(n_images, 0);
   s->f32.assign(n_images, nullptr); s->bf16.assign(n_images, nullptr); s->norm.assign(n_images, nullptr);
+  s->shi.assign(n_images, nullptr); s->slo.assign(n_images, nullptr); s->sn2.assign(n_images, nullptr); s->sn2max.assign(n_images, 0.f);
   s->ti8.assign(n_images, nullptr); s->qi8.assign(n_images, nullptr); s->tcin.assign(n_images, nullptr); s->tpar.assign(n_images, nullptr); s->qbeta.assign(n_images, nullptr);
-  if (s->nonint.alloc(1) != hipSuccess || hipMemsetAsync(s->nonint.p, 0, sizeof(int), ctx->stream) != hipSuccess) {
+  if (s->n2max_dev.alloc(1) != hipSuccess || s->nonint.alloc(1) != hipSuccess || hipMemsetAsync(s->nonint.p, 0, sizeof(int), ctx->stream) != hipSuccess) {
     delete s;
     return msfm_set_error(ctx, MSFM_E_NOMEM, "descset alloc");
   }
@@ -511,6 +810,9 @@ MSFM_API void msfm_descset_destroy(msfm_descset* s) {
   for (auto p : s->f32) delete p;
   for (auto p : s->bf16) delete p;
   for (auto p : s->norm) delete p;
+  for (auto p : s->shi) delete p;
+  for (auto p : s->slo) delete p;
+  for (auto p : s->sn2) delete p;
   for (auto p : s->ti8) delete p;
   for (auto p : s->qi8) delete p;
   for (auto p : s->tcin) delete p;
@@ -530,6 +832,9 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   delete s->f32[image]; delete s->bf16[image]; delete s->norm[image];
+  delete s->shi[image]; delete s->slo[image]; delete s->sn2[image];
+  s->shi[image] = new DevBuf<unsigned short>(); s->slo[image] = new DevBuf<unsigned short>(); s->sn2[image] = new DevBuf<float>();
+  s->sn2max[image] = 0.f;
   delete s->ti8[image]; delete s->qi8[image]; delete s->tcin[image]; delete s->tpar[image]; delete s->qbeta[image];
   s->f32[image] = new DevBuf<float>(); s->bf16[image] = new DevBuf<unsigned short>(); s->norm[image] = new DevBuf<float>();
   s->ti8[image] = new DevBuf<signed char>(); s->qi8[image] = new DevBuf<signed char>();
@@ -546,9 +851,17 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
                      s->norm[image]->p, s->nonint.p);
   hipLaunchKernelGGL(k_desc_prep_i8, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->ti8[image]->p,
                      s->qi8[image]->p, s->tcin[image]->p, s->tpar[image]->p, s->qbeta[image]->p);
+  HIP_TRY(ctx, s->shi[image]->alloc((size_t)count * DIM)); HIP_TRY(ctx, s->slo[image]->alloc((size_t)count * DIM));
+  HIP_TRY(ctx, s->sn2[image]->alloc(count));
+  HIP_TRY(ctx, hipMemsetAsync(s->n2max_dev.p, 0, sizeof(unsigned), st));
+  hipLaunchKernelGGL(k_desc_prep_split, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->shi[image]->p,
+                     s->slo[image]->p, s->sn2[image]->p, s->n2max_dev.p);
   HIP_TRY(ctx, hipGetLastError());
+  unsigned n2bits = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&s->h_nonint, s->nonint.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&n2bits, s->n2max_dev.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  memcpy(&s->sn2max[image], &n2bits, sizeof(float));
   return MSFM_OK;
 }
 
@@ -565,6 +878,11 @@ struct msfm_match_result {
   DevBuf<PairTask> tasks;
   DevBuf<PairTask8> tasks8;
   DevBuf<PairTaskF> tasksf;
+  DevBuf<PairTaskS> taskss;
+  DevBuf<int> qpair, cand, flagged, n_flagged;
+  DevBuf<float> d4a;
+  int n_tiles_split = 0;
+  bool use_exact = false;  // MSFM_KNN_EXACT=1: brute-force FP64 kernel for non-integral data instead of split-bf16 + re-rank
   bool use_bf16 = false;  // MSFM_KNN_BF16=1 selects the bf16 MFMA kernel instead of the int8 one
   int n_tiles = 0;
   bool exact_path = false;
@@ -586,6 +904,23 @@ static int launch_match(msfm_match_result* R) {
     hipLaunchKernelGGL(k_knn2_bf16, dim3(R->n_tiles), dim3(256), 0, st, R->tasks.p, R->tile_first.p, R->n_pairs, R->ratio_good,
                        R->ratio_all, R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr,
                        R->n_all.p, R->n_good.p);
+  } else if (!R->use_exact) {
+    {
+      KTimer t(ctx, "knn2_split_bf16_mfma");
+      hipLaunchKernelGGL(k_knn2_split, dim3(R->n_tiles_split), dim3(256), 0, st, R->taskss.p, R->tile_first.p, R->n_pairs,
+                         R->cand.p, R->d4a.p);
+    }
+    {
+      KTimer t(ctx, "knn2_rerank_f64");
+      HIP_TRY(ctx, hipMemsetAsync(R->n_flagged.p, 0, sizeof(int), st));
+      const int nb = cdiv(R->total_q, 256);
+      hipLaunchKernelGGL(k_rerank, dim3(nb), dim3(256), 0, st, R->taskss.p, R->qpair.p, R->total_q, R->cand.p, R->d4a.p, R->ids.p,
+                         R->sqd.p, R->flagged.p, R->n_flagged.p);
+      hipLaunchKernelGGL(k_exact_flagged, dim3((int)std::min<long>(R->total_q, 4096)), dim3(64), 0, st, R->taskss.p, R->qpair.p,
+                         R->flagged.p, R->n_flagged.p, R->ids.p, R->sqd.p);
+      hipLaunchKernelGGL(k_codes, dim3(nb), dim3(256), 0, st, R->qpair.p, R->total_q, R->ids.p, R->sqd.p, R->ratio_good, R->ratio_all,
+                         R->code.p, R->n_all.p, R->n_good.p);
+    }
   } else {
     KTimer t(ctx, "knn2_exact_f64");
     hipLaunchKernelGGL(k_knn2_exact, dim3(R->n_tiles), dim3(64), 0, st, R->tasksf.p, R->tile_first.p, R->n_pairs, R->ratio_good,
@@ -613,7 +948,11 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
   R->pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
   R->exact_path = s->h_nonint != 0;
   { const char* e = getenv("MSFM_KNN_BF16"); R->use_bf16 = e && e[0] == '1'; }
-  const int qpb = R->exact_path ? 64 : QPB;
+  { const char* e = getenv("MSFM_KNN_EXACT"); R->use_exact = e && e[0] == '1'; }
+  const bool split = R->exact_path && !R->use_exact;
+  const int qpb = split ? QPS : (R->exact_path ? 64 : QPB);
+  std::vector<PairTaskS> taskss(n_pairs);
+  std::vector<int> qpair;
   std::vector<int> tile_first(n_pairs + 1, 0);
   std::vector<PairTask> tasks(n_pairs);
   std::vector<PairTaskF> tasksf(n_pairs);
@@ -629,6 +968,9 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
     tasks[p] = PairTask{s->bf16[a]->p, nq ? s->bf16[b]->p : nullptr, s->norm[a]->p, nq ? s->norm[b]->p : nullptr, s->count[a], nq, (int)off};
     tasks8[p] = PairTask8{s->ti8[a]->p, nq ? s->qi8[b]->p : nullptr, s->tcin[a]->p, s->tpar[a]->p, nq ? s->qbeta[b]->p : nullptr, s->count[a], nq, (int)off};
     tasksf[p] = PairTaskF{s->f32[a]->p, nq ? s->f32[b]->p : nullptr, s->count[a], nq, (int)off};
+    taskss[p] = PairTaskS{s->shi[a]->p, s->slo[a]->p, nq ? s->shi[b]->p : nullptr, nq ? s->slo[b]->p : nullptr, s->sn2[a]->p,
+                          nq ? s->sn2[b]->p : nullptr, s->f32[a]->p, nq ? s->f32[b]->p : nullptr, s->sn2max[a], s->count[a], nq, (int)off};
+    if (split) qpair.insert(qpair.end(), (size_t)nq, p);
     off += nq;
     tiles += cdiv(nq, qpb);
     if (off > 0x7fffffffL || tiles > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_INVAL, "too many queries in one call; split the pair list");
@@ -636,8 +978,16 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
   tile_first[n_pairs] = (int)tiles;
   R->total_q = off;
   R->n_tiles = (int)tiles;
+  R->n_tiles_split = split ? (int)tiles : 0;
   hipStream_t st = ctx->stream;
   HIP_TRY(ctx, R->code.alloc(std::max<long>(1, off)));
+  if (split) {
+    R->keep_knn = true;  // the re-rank stage produces (ids, sqd) anyway
+    HIP_TRY(ctx, R->qpair.from(qpair.empty() ? std::vector<int>(1, 0) : qpair, st));
+    HIP_TRY(ctx, R->cand.alloc(std::max<long>(1, 4 * off))); HIP_TRY(ctx, R->d4a.alloc(std::max<long>(1, off)));
+    HIP_TRY(ctx, R->flagged.alloc(std::max<long>(1, off))); HIP_TRY(ctx, R->n_flagged.alloc(1));
+    if (n_pairs) HIP_TRY(ctx, R->taskss.from(taskss, st));
+  }
   if (R->keep_knn) { HIP_TRY(ctx, R->ids.alloc(std::max<long>(1, 2 * off))); HIP_TRY(ctx, R->sqd.alloc(std::max<long>(1, 2 * off))); }
   HIP_TRY(ctx, R->n_all.alloc(std::max(1, n_pairs))); HIP_TRY(ctx, R->n_good.alloc(std::max(1, n_pairs)));
   HIP_TRY(ctx, R->tile_first.from(tile_first, st));
@@ -675,6 +1025,19 @@ MSFM_API int msfm_match_result_fetch(msfm_match_result* R, int pair, int32_t* co
   if (ids) HIP_TRY(ctx, hipMemcpyAsync(ids, R->ids.p + 2 * o, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, st));
   if (sqdists) HIP_TRY(ctx, hipMemcpyAsync(sqdists, R->sqd.p + 2 * o, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_match_result_stats(msfm_match_result* R, int* n_queries, int* n_slow_path) {
+  if (!R) return MSFM_E_INVAL;
+  msfm_ctx* ctx = R->set->ctx;
+  int nf = 0;
+  if (R->n_flagged.p) {
+    HIP_TRY(ctx, hipMemcpyAsync(&nf, R->n_flagged.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (n_queries) *n_queries = (int)R->total_q;
+  if (n_slow_path) *n_slow_path = nf;
   return MSFM_OK;
 }
 

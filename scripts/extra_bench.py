@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Side measurements that are not the headline bench line: the non-integral descriptor path and the
+largest BASELINE configuration (config 5: 2000 cameras / 1M points / 6M observations + GPS)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metricsfm_amd import _abi as A, capi, scene  # noqa: E402
+
+ctx = capi.Context(0)
+out = {}
+# ---- general float descriptors (VLFeat 512*x floats): exact FP64 path ----
+rng = np.random.default_rng(0)
+d = [(rng.gamma(0.6, 1.0, (4096, 128)) * 40).astype(np.float32) for _ in range(4)]
+ds = ctx.descset(d)
+pairs = scene.all_pairs(4)
+res = ds.match_pairs(pairs)
+ctx.synchronize()
+t0 = time.perf_counter()
+res.rerun()
+ctx.synchronize()
+dt = time.perf_counter() - t0
+out["float_descriptors"] = dict(pairs=len(pairs), ms=1e3 * dt, Mmatches_per_s=1e-6 * len(pairs) * 4096 / dt,
+                                path="MSFM_KNN_EXACT=%s" % os.environ.get("MSFM_KNN_EXACT", "0"))
+ctx.profile(True); ctx.profile_reset(); res.rerun(); ctx.synchronize(); out["float_kernels"] = ctx.profile_get(); ctx.profile(False)
+out["float_stats"] = res.stats()
+# ---- config 5 ----
+if "--c5" in sys.argv:
+    t0 = time.time()
+    sc = scene.config_scene(5)
+    gen = time.time() - t0
+    arr = A.BaArrays.from_scene(sc, gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams))
+    t0 = time.time()
+    ba = ctx.ba(arr)
+    setup = time.time() - t0
+    r = ba.run(capi.default_options(max_num_iterations=5, function_tolerance=-1.0, parameter_tolerance=-1.0, gradient_tolerance=-1.0))
+    out["config5"] = dict(cams=sc.n_cams, points=sc.n_points, obs=sc.n_obs, reduced_order=r["num_reduced_params"], scene_gen_s=gen,
+                          create_s=setup, solve_ms=r["solve_ms"], iterations=r["num_iterations"], ms_per_iteration=r["solve_ms"] / 5,
+                          cost=[float(c) for c in r["iterations"]["cost"]])
+print(json.dumps(out))

@@ -68,6 +68,59 @@ def test_knn2_general_floats(ctx, oracle):
     np.testing.assert_array_equal(d_g, d_r)
 
 
+def test_knn2_general_floats_hard_cases(ctx, oracle):
+    """The split-bf16 + re-rank path must stay exact where its shortlist cannot certify the answer:
+    many exact duplicates (more than the shortlist holds), near ties below the bf16x2 resolution,
+    tiny and huge magnitudes, fewer train rows than the shortlist."""
+    rng = np.random.default_rng(12)
+    base = (rng.gamma(0.6, 1.0, (500, 128)) * 40).astype(np.float32)
+    tr = base.copy()
+    tr[100:110] = tr[5]                      # 11 identical rows: ties beyond a shortlist of 4
+    tr[200] = tr[7] * np.float32(1 + 2e-7)   # near tie, far below 2^-16 relative
+    tr[300] = tr[9]; tr[300, 0] += np.float32(1e-3)
+    qu = np.concatenate([tr[[5, 7, 9, 100, 200]], (rng.gamma(0.6, 1.0, (300, 128)) * 40).astype(np.float32)])
+    for scale in (1.0, 1e-4, 3e3):
+        t, q = (tr * np.float32(scale)).astype(np.float32), (qu * np.float32(scale)).astype(np.float32)
+        ids_r, d_r = oracle.knn2(t, q)
+        ids_g, d_g = ctx.knn2(t, q)
+        np.testing.assert_array_equal(ids_g, ids_r)
+        np.testing.assert_array_equal(d_g, d_r)
+    assert (ids_g[0] == [5, 100]).all()
+    for n in (2, 3, 4, 5):                   # n_train around the shortlist size
+        ids_r, d_r = oracle.knn2(tr[:n], qu[:40])
+        ids_g, d_g = ctx.knn2(tr[:n], qu[:40])
+        np.testing.assert_array_equal(ids_g, ids_r)
+        np.testing.assert_array_equal(d_g, d_r)
+    # mixed signs (descriptors are non-negative in practice, the kernel must not rely on it)
+    t = rng.standard_normal((257, 128)).astype(np.float32); q = rng.standard_normal((65, 128)).astype(np.float32)
+    ids_r, d_r = oracle.knn2(t, q)
+    ids_g, d_g = ctx.knn2(t, q)
+    np.testing.assert_array_equal(ids_g, ids_r)
+    np.testing.assert_array_equal(d_g, d_r)
+
+
+def test_split_path_certifies_almost_everything(ctx, oracle):
+    """Random non-integral data: the shortlist is certified for (nearly) every query; exact
+    duplicates force the exact fallback for the affected queries only.  Integer data: no slow path."""
+    rng = np.random.default_rng(3)
+    d = [(rng.gamma(0.6, 1.0, (1500, 128)) * 40).astype(np.float32) for _ in range(3)]
+    d[0][700:706] = d[0][1]
+    d[1][:3] = d[0][1]
+    ds = ctx.descset(d)
+    res = ds.match_pairs(np.array([[0, 1], [1, 2], [2, 0]], np.int32), keep_knn=True)
+    st = res.stats()
+    assert st["queries"] == 4500 and 3 <= st["slow_path"] < 0.02 * st["queries"]
+    for p, (i, j) in enumerate([(0, 1), (1, 2), (2, 0)]):
+        code, ids, dist = res.fetch(p)
+        ids_r, d_r = oracle.knn2(d[i], d[j])
+        np.testing.assert_array_equal(ids, ids_r)
+        np.testing.assert_array_equal(dist, d_r)
+        code_r, _, _ = oracle.ratio_codes(ids_r, d_r, 0.6, 0.85)
+        np.testing.assert_array_equal(code, code_r)
+    ints = [scene._sift_like(rng, 300).astype(np.float32) for _ in range(2)]
+    assert ctx.descset(ints).match_pairs(np.array([[0, 1]], np.int32)).stats()["slow_path"] == 0
+
+
 def test_match_pairs_ratio_codes(ctx, oracle):
     """Batched pairs + fused ratio tests vs fine_matching_graph.cc:116-133 restated; ragged image sizes,
     an empty image, and the counts of matches_all / matches_good."""
