@@ -182,7 +182,7 @@ def main():
         except Exception:
             pass
 
-    out = dict(metric="ba_lm_iterations_per_sec", value=it_s, unit="iterations/s", n_gpus=world, steps=args.steps,
+    out = dict(metric="BA iterations/sec", value=it_s, unit="iterations/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * ba_s / args.steps, higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload="BASELINE config %d: %d cameras / %d points / %d observations, dense-Schur LM, Huber(1)" %
@@ -226,7 +226,8 @@ def main():
         kst = mstats.get(kname)
         peak = {"knn2_i8_mfma": I8_PEAK_TOPS, "knn2_bf16_mfma": BF16_PEAK_TFLOPS, "knn2_exact_f64": FP64_PEAK_TFLOPS}.get(kname)
         kern_tf = my_flops / (kst["total_ms"] * 1e-3) / 1e12 if kst else None
-        out["matching"] = dict(metric="Mmatches_per_sec", value=1e-6 * queries * msteps / m_s, unit="Mmatches/s",
+        out["mmatches_per_sec"] = 1e-6 * queries * msteps / m_s
+        out["matching"] = dict(metric="Mmatches/sec", value=1e-6 * queries * msteps / m_s, unit="Mmatches/s",
                                images=n_img, pairs=int(len(pairs)), feats_per_image=args.feats, steps=msteps,
                                ms_per_step=1e3 * m_s / msteps, tflops=flops * msteps / m_s / 1e12,
                                dtype={"knn2_i8_mfma": "i8", "knn2_bf16_mfma": "bf16"}.get(kname, "f64"),

@@ -63,14 +63,22 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, double* __restrict_
     for (int j = 0; j < 6; j++) pose[j] = P.cam[6 * (size_t)c + j];
 #pragma unroll
     for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; X[j] = P.pt[3 * (size_t)p + j]; }
+    const double ox = P.o_x[i], oy = P.o_y[i], ow = P.o_w[i];
+    const int cb = P.o_cb[i], mb = P.o_mb[i], pb = P.o_pb[i], cp = P.o_cpos[i];
+    double sc[6], sm[3], sp[3];
+    if (WRITE_JAC) {  // column scales fetched together with the parameters, not one by one at the stores
+#pragma unroll
+      for (int j = 0; j < 6; j++) sc[j] = cb >= 0 ? P.scale_c[6 * cb + j] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; j++) { sm[j] = mb >= 0 ? P.scale_m[3 * mb + j] : 0.0; sp[j] = pb >= 0 ? P.scale_p[3 * (size_t)pb + j] : 0.0; }
+    }
     double r[2], J[24];
-    msfm_reproj(pose, cm, X, P.o_x[i], P.o_y[i], P.o_w[i], r, WRITE_JAC ? J : nullptr);
+    msfm_reproj(pose, cm, X, ox, oy, ow, r, WRITE_JAC ? J : nullptr);
     double rho0, rho1;
     msfm_huber(P.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
     cost = 0.5 * rho0;
     if (WRITE_JAC) {
       const double sq = sqrt(rho1);
-      const int cb = P.o_cb[i], mb = P.o_mb[i], pb = P.o_pb[i];
       const size_t A = P.A;
       const double r0 = sq * r[0], r1 = sq * r[1];
       P.lin_r[i] = r0;
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, double* __restrict_
       double jc[12], jm[6];
 #pragma unroll
       for (int j = 0; j < 6; j++) {
-        const double s = cb >= 0 ? sq * P.scale_c[6 * cb + j] : 0.0;
+        const double s = sq * sc[j];
         jc[j] = s * J[j];
         jc[6 + j] = s * J[12 + j];
         P.lin_Jc[(size_t)j * A + i] = jc[j];
@@ -86,16 +94,15 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, double* __restrict_
       }
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        const double s = mb >= 0 ? sq * P.scale_m[3 * mb + j] : 0.0;
+        const double s = sq * sm[j];
         jm[j] = s * J[6 + j];
         jm[3 + j] = s * J[12 + 6 + j];
         P.lin_Jm[(size_t)j * A + i] = jm[j];
         P.lin_Jm[(size_t)(3 + j) * A + i] = jm[3 + j];
-        const double sp = pb >= 0 ? sq * P.scale_p[3 * (size_t)pb + j] : 0.0;
-        P.lin_Jp[(size_t)j * A + i] = sp * J[9 + j];
-        P.lin_Jp[(size_t)(3 + j) * A + i] = sp * J[12 + 9 + j];
+        const double spj = sq * sp[j];
+        P.lin_Jp[(size_t)j * A + i] = spj * J[9 + j];
+        P.lin_Jp[(size_t)(3 + j) * A + i] = spj * J[12 + 9 + j];
       }
-      const int cp = P.o_cpos[i];
       if (cp >= 0) {
         double* row = P.camrow + 20 * (size_t)cp;
 #pragma unroll
@@ -258,11 +265,13 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
             a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
             b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
           }
-          double T[18];
+          double T[18], jc[12];
+#pragma unroll
+          for (int a = 0; a < 12; a++) jc[a] = P.lin_Jc[(size_t)a * A + i];  // all loads before the first use
           double* Tu = P.Tu + 6 * (size_t)cp;
 #pragma unroll
           for (int a = 0; a < 6; a++) {
-            const double ja = P.lin_Jc[(size_t)a * A + i], jb = P.lin_Jc[(size_t)(6 + a) * A + i];
+            const double ja = jc[a], jb = jc[6 + a];
             const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
             const double t0 = w0 * i00;
             const double t1 = (w1 - l10 * t0) * i11;
@@ -291,9 +300,12 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
             a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
             b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
           }
+          double jm[6];
+#pragma unroll
+          for (int a = 0; a < 6; a++) jm[a] = P.lin_Jm[(size_t)a * A + i];
 #pragma unroll
           for (int a = 0; a < 3; a++) {
-            const double ja = P.lin_Jm[(size_t)a * A + i], jb = P.lin_Jm[(size_t)(3 + a) * A + i];
+            const double ja = jm[a], jb = jm[3 + a];
             W[a * 3 + 0] += ja * a0 + jb * b0; W[a * 3 + 1] += ja * a1 + jb * b1; W[a * 3 + 2] += ja * a2 + jb * b2;
           }
         }
@@ -632,27 +644,29 @@ __global__ __launch_bounds__(256) void k_backsub(BackPtrs P, double* __restrict_
   for (int base = f; base < l; base += 8) {
     const int i = base + sub;
     if (i < l) {
-      const double r0 = P.lin_r[i], r1 = P.lin_r[A + i];
-      double q0 = 0.0, q1 = 0.0;
+      // every load of this observation is issued before the first use (hipcc otherwise waits after
+      // each one inside the predicated region); rows of frozen blocks hold zeros, so no branches
       const int cb = P.o_cb[i], mb = P.o_mb[i];
-      if (cb >= 0) {
+      double jc[12], jm[6], jp[6], zc[6], zm[3];
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          const double zj = P.z[6 * cb + j];
-          q0 -= P.lin_Jc[(size_t)j * A + i] * zj;
-          q1 -= P.lin_Jc[(size_t)(6 + j) * A + i] * zj;
-        }
-      }
-      if (mb >= 0) {
+      for (int j = 0; j < 12; j++) jc[j] = P.lin_Jc[(size_t)j * A + i];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-          const double zj = P.z[6 * P.ncb + 3 * mb + j];
-          q0 -= P.lin_Jm[(size_t)j * A + i] * zj;
-          q1 -= P.lin_Jm[(size_t)(3 + j) * A + i] * zj;
-        }
-      }
-      const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
-      const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
+      for (int j = 0; j < 6; j++) jm[j] = P.lin_Jm[(size_t)j * A + i];
+#pragma unroll
+      for (int j = 0; j < 6; j++) jp[j] = P.lin_Jp[(size_t)j * A + i];
+      const double r0 = P.lin_r[i], r1 = P.lin_r[A + i];
+      const double* zcp = P.z + 6 * (cb >= 0 ? cb : 0);
+      const double* zmp = P.z + 6 * P.ncb + 3 * (mb >= 0 ? mb : 0);
+#pragma unroll
+      for (int j = 0; j < 6; j++) zc[j] = zcp[j];
+#pragma unroll
+      for (int j = 0; j < 3; j++) zm[j] = zmp[j];
+      double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) { q0 -= jc[j] * zc[j]; q1 -= jc[6 + j] * zc[j]; }
+#pragma unroll
+      for (int j = 0; j < 3; j++) { q0 -= jm[j] * zm[j]; q1 -= jm[3 + j] * zm[j]; }
+      const double a0 = jp[0], a1 = jp[1], a2 = jp[2], b0 = jp[3], b1 = jp[4], b2 = jp[5];
       V00 += a0 * a0 + b0 * b0; V10 += a1 * a0 + b1 * b0; V11 += a1 * a1 + b1 * b1;
       V20 += a2 * a0 + b2 * b0; V21 += a2 * a1 + b2 * b1; V22 += a2 * a2 + b2 * b2;
       g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
@@ -1044,7 +1058,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
   AL(ptL, 6 * (size_t)npb); AL(ptg, 3 * (size_t)npb);
   AL(f_partial, (size_t)ba->n_fchunks * PSTRIDE); AL(camftf, (size_t)ncb * PSTRIDE); AL(modelsum, 12 * (size_t)nmb);
-  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad);
+  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad + 8);
   AL(g_r, 3 * (size_t)ncb); AL(g_J, 3 * (size_t)ncb);
   ba->nblk_obs = cdiv(As, 256);
   ba->nblk_pt = cdiv(std::max(1, npb), 32);  // 8 lanes per point
@@ -1066,6 +1080,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   }
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_scal, 16 * sizeof(double)));
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_fail, 4 * sizeof(int)));
+  HIP_TRY(ctx, hipMemsetAsync(ba->z.p, 0, sizeof(double) * (size_t)(ba->npad + 8), s));  // tail entries are read (times zero) by frozen blocks
   HIP_TRY(ctx, hipMemsetAsync(ba->camrow.p, 0, sizeof(double) * std::max<size_t>(1, 20 * (size_t)NCR), s));
   HIP_TRY(ctx, hipMemsetAsync(ba->T.p, 0, sizeof(double) * std::max<size_t>(1, 18 * (size_t)NCR), s));
   HIP_TRY(ctx, hipMemsetAsync(ba->Tu.p, 0, sizeof(double) * std::max<size_t>(1, 6 * (size_t)NCR), s));
