@@ -155,14 +155,28 @@ __global__ __launch_bounds__(256) void k_gps(int ncb, const int* __restrict__ cb
   if (threadIdx.x == 0) cost_partial[blockIdx.x] = t;
 }
 
-// Sum `n` partials in a fixed order into scal[slot] (single workgroup).
-__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ scal,
-                                                       int slot, int is_max) {
-  __shared__ double sh[4];
-  double v = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) v = is_max ? fmax(v, partial[i]) : v + partial[i];
-  const double t = is_max ? block_max256(v, sh) : block_sum256(v, sh);
-  if (threadIdx.x == 0) scal[slot] = t;
+// Sum (or max) `n` partials in a fixed order into scal[slot]: one workgroup of 1024 threads, each
+// thread a fixed strided subset (independent loads in flight), then a fixed wave / block tree.
+__global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ scal,
+                                                        int slot, int is_max) {
+  __shared__ double sh[16];
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3072 < n; i += 4096) {
+    const double a = partial[i], b = partial[i + 1024], c = partial[i + 2048], d = partial[i + 3072];
+    if (is_max) { v0 = fmax(v0, a); v1 = fmax(v1, b); v2 = fmax(v2, c); v3 = fmax(v3, d); }
+    else { v0 += a; v1 += b; v2 += c; v3 += d; }
+  }
+  for (; i < n; i += 1024) v0 = is_max ? fmax(v0, partial[i]) : v0 + partial[i];
+  double v = is_max ? fmax(fmax(v0, v1), fmax(v2, v3)) : (v0 + v1) + (v2 + v3);
+  v = is_max ? wave_max(v) : wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sh[0];
+    for (int w = 1; w < 16; w++) t = is_max ? fmax(t, sh[w]) : t + sh[w];
+    scal[slot] = t;
+  }
 }
 
 // --------------------------------------------------------------------------------------
@@ -1159,7 +1173,7 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber) {
       if (jac) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
       else hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->scal.p, S_COST, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->scal.p, S_COST, 0);
   }
   return MSFM_OK;
 }
@@ -1204,7 +1218,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
                          ba->diag_m.p, ba->scale_m.p, reuse_diag ? 1 : 0, mode, opt->min_lm_diagonal, opt->max_lm_diagonal, gmax_m);
   }
   if (mode == 1) return MSFM_OK;
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, ba->scal.p,
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, ba->scal.p,
                      S_GMAX, 1);
   hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->scal.p, S_FAIL);
   {
@@ -1286,9 +1300,9 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
                          ba->lin_Jc.p, ba->lin_Jm.p, ba->z.p, ngps ? 1 : 0, ba->g_r.p, ba->g_J.p, ba->partial.p + moff);
       moff += cdiv(nrest, 256);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial.p, moff, ba->scal.p, S_MCC, 0);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial2.p, off, ba->scal.p, S_DX2, 0);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, ba->partial3.p, off, ba->scal.p, S_X2, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, moff, ba->scal.p, S_MCC, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial2.p, off, ba->scal.p, S_DX2, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial3.p, off, ba->scal.p, S_X2, 0);
   }
   MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/false, opt->huber_delta));
   hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->scal.p, S_FAIL);

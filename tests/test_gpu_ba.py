@@ -109,3 +109,34 @@ def test_ba_rejects_bad_input(ctx):
     a.obs_cam[3] = 99
     with pytest.raises(capi.MsfmError):
         ctx.ba_solve(a)
+
+
+def test_ba_degenerate_structures(ctx, oracle):
+    """Structures the gather can produce: a camera nobody observes, a track that sees the same camera
+    twice (two features of one image in one track), a single free camera, and nothing free at all."""
+    from metricsfm_amd import capi
+    sc = scene.make_ring_scene(6, 200, seed=17, rot_sigma=0.02, trans_sigma=0.2, point_sigma=0.2)
+    # (a) camera 5 loses all its observations -> it is not a parameter block (Ceres drops unused blocks)
+    keep = sc.obs_cam != 5
+    mk = lambda: A.BaArrays(sc.cam_pose, sc.cam_model, sc.cam_model_of_cam, sc.point, sc.obs_cam[keep], sc.obs_pt[keep],
+                            sc.obs_xy[keep], sc.pt_weight)
+    r, _, a = check_parity(ctx, oracle, mk, dict(max_num_iterations=15))
+    assert r["num_reduced_params"] == 5 * 6 + 3 and (a.cam_pose[5] == sc.cam_pose[5]).all()
+    # (b) duplicate camera inside a track: observation 1 of every 10th point is re-pointed at the camera of observation 0
+    oc = sc.obs_cam.copy()
+    off = sc.track_offsets()
+    oc[off[:-1][::10] + 1] = oc[off[:-1][::10]]
+    mk = lambda: A.BaArrays(sc.cam_pose, sc.cam_model, sc.cam_model_of_cam, sc.point, oc, sc.obs_pt, sc.obs_xy, sc.pt_weight)
+    check_parity(ctx, oracle, mk, dict(max_num_iterations=10), tol_param=1e-6, tol_cost=1e-8)
+    # (c) only camera 2 and the points are free
+    cm = np.zeros(6, np.uint8); cm[2] = 1
+    mk = lambda: A.BaArrays.from_scene(sc, cam_mutable=cm)
+    check_parity(ctx, oracle, mk, dict(max_num_iterations=15))
+    # (d) nothing is free: no residual blocks at all -> zero cost, gradient tolerance fires at iteration 0
+    mk = lambda: A.BaArrays.from_scene(sc, cam_mutable=np.zeros(6, np.uint8), pt_mutable=np.zeros(sc.n_points, np.uint8))
+    a_ref, a_gpu = mk(), mk()
+    r_ref = oracle.ba_solve(a_ref, oracle.default_options())
+    r_gpu = ctx.ba_solve(a_gpu, capi.default_options())
+    assert r_gpu["num_residuals"] == r_ref["num_residuals"] == 0
+    assert r_gpu["termination"] == r_ref["termination"] and r_gpu["num_iterations"] == r_ref["num_iterations"] == 0
+    assert (a_gpu.point == sc.point).all() and (a_gpu.cam_pose == sc.cam_pose).all()
