@@ -2,6 +2,7 @@
 #include "objectsfm.h"
 
 #include <cstdio>
+#include <fstream>
 #include <cstdlib>
 #include <limits>
 #include <stdexcept>
@@ -329,6 +330,41 @@ std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& 
   msfm_match_result_destroy(res);
   msfm_descset_destroy(set);
   return out;
+}
+
+// ---- match files ---------------------------------------------------------------------------------
+void WriteOutMatches(const std::string& fold, int idx1, int idx2, const std::vector<std::pair<int, int>>& matches) {
+  const int num_match = (int)matches.size();
+  if (!num_match) return;
+  std::vector<int> tmp(2 * (size_t)num_match);
+  for (int m = 0; m < num_match; m++) { tmp[2 * m] = matches[m].first; tmp[2 * m + 1] = matches[m].second; }
+  std::ofstream ofs(fold + "/" + std::to_string(idx1) + "_match", std::ios::out | std::ios::app | std::ios::binary);
+  ofs.write((const char*)&idx2, sizeof(int));
+  ofs.write((const char*)&num_match, sizeof(int));
+  ofs.write((const char*)tmp.data(), tmp.size() * sizeof(int));
+}
+
+void WriteOutMatchGraph(const std::string& fold, const std::vector<std::vector<int>>& match_graph) {
+  std::ofstream ofs(fold + "/graph_matching.txt", std::ios::binary);
+  for (auto& row : match_graph) {
+    for (int v : row) ofs << v << " ";
+    ofs << std::endl;
+  }
+}
+
+void QueryMatch(const std::string& fold, int idx, std::vector<int>& image_ids,
+                std::vector<std::vector<std::pair<int, int>>>& match_pts) {
+  std::ifstream ifs(fold + "/" + std::to_string(idx) + "_match", std::ios::in | std::ios::binary);
+  int id, num_match;
+  while (ifs.read((char*)&id, sizeof(int))) {
+    ifs.read((char*)&num_match, sizeof(int));
+    std::vector<int> tmp(2 * (size_t)num_match);
+    ifs.read((char*)tmp.data(), tmp.size() * sizeof(int));
+    image_ids.push_back(id);
+    std::vector<std::pair<int, int>> mt(num_match);
+    for (int i = 0; i < num_match; i++) mt[i] = std::make_pair(tmp[2 * i], tmp[2 * i + 1]);
+    match_pts.push_back(mt);
+  }
 }
 
 }  // namespace objectsfm

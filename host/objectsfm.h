@@ -141,4 +141,12 @@ std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& 
                                          const std::vector<std::pair<int, int>>& pairs, float thRatio_good = 0.6f,
                                          float thRatio_all = 0.85f);
 
+// The reference's stage boundary is a set of files: per image `<idx1>_match` (binary records
+// int idx2, int n, int[2n]) and `graph_matching.txt`.  Same bytes as FineMatchingGraph::WriteOutMatches /
+// WriteOutMatchGraph (fine_matching_graph.cc:247-292) and Graph::QueryMatch (graph.cc:92-137).
+void WriteOutMatches(const std::string& output_fold, int idx1, int idx2, const std::vector<std::pair<int, int>>& matches);
+void WriteOutMatchGraph(const std::string& output_fold, const std::vector<std::vector<int>>& match_graph);
+void QueryMatch(const std::string& output_fold, int idx, std::vector<int>& image_ids,
+                std::vector<std::vector<std::pair<int, int>>>& match_pts);
+
 }  // namespace objectsfm

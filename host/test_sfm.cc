@@ -6,6 +6,7 @@
 // `int main`, no hard-coded Windows paths; exits non-zero if a stage misbehaves.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <random>
 
@@ -80,11 +81,24 @@ int main() {
     for (auto& m : pm.matches_good) { good++; good_right += feat_pt[pm.idx1][m.first] == feat_pt[pm.idx2][m.second]; }
   std::printf("matching: %zu pairs, %ld good matches, %.2f%% correct\n", pairs.size(), good, 100.0 * good_right / std::max(1L, good));
   if (good < 0.8 * pairs.size() * n_pts || good_right < 0.99 * good) { std::printf("FAIL: matching\n"); return 1; }
+  // the reference hands matches to the SfM stage through files: write them, read image 0's back
+  char tmpl[] = "/tmp/msfm_test_sfm_XXXXXX";
+  const std::string fold = mkdtemp(tmpl) ? std::string(tmpl) : std::string("/tmp");
+  std::vector<std::vector<int>> match_graph(n_cams, std::vector<int>(n_cams, 0));
+  for (auto& pm : matches) {
+    WriteOutMatches(fold, pm.idx1, pm.idx2, pm.matches_good);
+    match_graph[pm.idx1][pm.idx2] = (int)pm.matches_good.size();
+  }
+  WriteOutMatchGraph(fold, match_graph);
+  std::vector<int> ids0;
+  std::vector<std::vector<std::pair<int, int>>> m0;
+  QueryMatch(fold, 0, ids0, m0);  // Graph::QueryMatch, graph.cc:92-121
+  if ((int)ids0.size() != n_cams - 1) { std::printf("FAIL: match files\n"); return 1; }
   // --- stage 2: tracks from the matches against image 0 (union over pairs (0, j)), Trianglate2 ---
   std::vector<Point3D> pts(n_pts);
   std::vector<char> has0(n_pts, 0);
-  for (auto& pm : matches) {
-    if (pm.idx1 != 0) continue;
+  for (size_t rec = 0; rec < ids0.size(); rec++) {
+    PairMatches pm; pm.idx1 = 0; pm.idx2 = ids0[rec]; pm.matches_good = m0[rec];
     for (auto& m : pm.matches_good) {
       const int id = m.first;  // feature id in image 0 names the track
       if (!has0[id]) { pts[id].AddObservation(&cams[0], kp[0][id].x, kp[0][id].y, id); has0[id] = 1; }
