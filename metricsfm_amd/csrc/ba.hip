@@ -36,7 +36,9 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* Li
 #define F_TU 72      // 6
 
 // scalar slots (device `scal` array)
-enum { S_COST = 0, S_MCC, S_DX2, S_X2, S_GMAX, S_FAIL, S_N };  // [0,4) are sums, [4,6) are maxima
+// [0,5) are sums, [5,7) are maxima.  S_XCOST is the cost at x (kept across the speculative solve),
+// S_COST the cost at the candidate.
+enum { S_COST = 0, S_MCC, S_DX2, S_X2, S_XCOST, S_GMAX, S_FAIL, S_N };
 
 struct BaPtrs {
   int A, AE, ncb, nmb, npb, NCR;
@@ -795,6 +797,7 @@ struct msfm_ba {
   DevBuf<double> partial, partial2, partial3, gmax_buf, scal;
   DevBuf<int> fail;
   double* h_scal = nullptr;  // pinned
+  hipEvent_t ev_scal = nullptr;
   int* h_fail = nullptr;
   int nblk_obs = 0, nblk_pt = 0;
   double setup_ms = 0;
@@ -855,6 +858,7 @@ MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
   if (!ba) return;
   (void)hipStreamSynchronize(ba->ctx->stream);
   if (ba->h_scal) (void)hipHostFree(ba->h_scal);
+  if (ba->ev_scal) (void)hipEventDestroy(ba->ev_scal);
   if (ba->h_fail) (void)hipHostFree(ba->h_fail);
   delete ba;
 }
@@ -1093,6 +1097,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
       if (!q) return msfm_set_error(ctx, MSFM_E_NOMEM, "msfm_ba_create: a device buffer was not allocated");
   }
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_scal, 16 * sizeof(double)));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ba->ev_scal, hipEventDisableTiming));
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_fail, 4 * sizeof(int)));
   HIP_TRY(ctx, hipMemsetAsync(ba->z.p, 0, sizeof(double) * (size_t)(ba->npad + 8), s));  // tail entries are read (times zero) by frozen blocks
   HIP_TRY(ctx, hipMemsetAsync(ba->camrow.p, 0, sizeof(double) * std::max<size_t>(1, 20 * (size_t)NCR), s));
@@ -1155,9 +1160,9 @@ static int allreduce(msfm_ba* ba, double* buf, size_t count, int op) {
   return MSFM_OK;
 }
 
-// cost (and, with jac, the stored linearisation) at x or at the candidate -> scal[S_COST]
+// cost (and, with jac, the stored linearisation) at x or at the candidate -> scal[slot]
 // (local partial; summed over ranks by the caller together with the other scalars)
-static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber) {
+static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int slot) {
   msfm_ctx* ctx = ba->ctx;
   hipStream_t s = ctx->stream;
   const bool lead = ctx->rank == 0;
@@ -1173,7 +1178,7 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber) {
       if (jac) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
       else hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->scal.p, S_COST, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->scal.p, slot, 0);
   }
   return MSFM_OK;
 }
@@ -1258,7 +1263,10 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
 static int read_scalars(msfm_ba* ba) {
   msfm_ctx* ctx = ba->ctx;
   HIP_TRY(ctx, hipMemcpyAsync(ba->h_scal, ba->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ba->ev_scal, ctx->stream));
+  hipError_t q;
+  while ((q = hipEventQuery(ba->ev_scal)) == hipErrorNotReady) {}  // spin: the wake-up of a blocking wait costs more than the copy
+  HIP_TRY(ctx, q);
   return MSFM_OK;
 }
 
@@ -1304,7 +1312,7 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial2.p, off, ba->scal.p, S_DX2, 0);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial3.p, off, ba->scal.p, S_X2, 0);
   }
-  MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/false, opt->huber_delta));
+  MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/false, opt->huber_delta, S_COST));
   hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->scal.p, S_FAIL);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "solve launch: %s", hipGetErrorString(e));
@@ -1347,25 +1355,33 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
   bool reuse_diag = false;
   // ---- IterationZero ----
-  MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta));
+  MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
   if (opt->jacobi_scaling) {
     // squared column norms of the corrected, unscaled Jacobian -> scaling -> re-linearise scaled
     MSFM_TRY(run_assemble(ba, opt, radius, false, /*mode=*/1));
     if (ncb) hipLaunchKernelGGL(k_make_scale, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, 6 * ncb, ba->diag_c.p, ba->scale_c.p);
     if (nmb) hipLaunchKernelGGL(k_make_scale, dim3(cdiv(3 * nmb, 256)), dim3(256), 0, s, 3 * nmb, ba->diag_m.p, ba->scale_m.p);
     if (npb) hipLaunchKernelGGL(k_make_scale, dim3(cdiv(3 * npb, 256)), dim3(256), 0, s, 3 * npb, ba->diag_p.p, ba->scale_p.p);
-    MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta));
+    MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
   }
-  MSFM_TRY(allreduce(ba, ba->scal.p + S_COST, 1, MSFM_REDUCE_SUM));
-  MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0));
-  MSFM_TRY(read_scalars(ba));
-  double x_cost = ba->h_scal[S_COST];
+  MSFM_TRY(allreduce(ba, ba->scal.p + S_XCOST, 1, MSFM_REDUCE_SUM));
+  int iteration = 0, num_invalid = 0, termination = 0;
+  // The reduced system and the trust-region step computed from it are enqueued back to back and
+  // their scalars read with ONE host synchronisation per LM iteration: the step is speculative
+  // only in that a gradient-tolerance stop discards it (it writes the candidate buffers only).
+  auto assemble_and_step = [&]() -> int {
+    MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0));
+    if (iteration < opt->max_num_iterations && radius > opt->min_trust_region_radius) MSFM_TRY(run_solve(ba, opt));
+    MSFM_TRY(read_scalars(ba));
+    return MSFM_OK;
+  };
+  MSFM_TRY(assemble_and_step());
+  double x_cost = ba->h_scal[S_XCOST];
   msfm_ba_iteration it;
   memset(&it, 0, sizeof it);
   it.cost = x_cost; it.gradient_max_norm = ba->h_scal[S_GMAX]; it.trust_region_radius = radius;
   it.step_is_valid = 1; it.step_is_successful = 1;
   sum->initial_cost = x_cost;
-  int iteration = 0, num_invalid = 0, termination = 0;
   for (;;) {
     if (it.step_is_successful && iteration > 0) sum->num_successful_steps++;
     it.trust_region_radius = radius;
@@ -1380,15 +1396,10 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     memset(&it, 0, sizeof it);
     iteration++;
     // ---- ComputeTrustRegionStep ----
-    const bool assembled_ok = ((int)ba->h_scal[S_FAIL] & 2) == 0;  // every 3x3 point block was positive definite
-    bool solved = false;
-    double mcc = 0, cand_cost = 0, dx2 = 0, x2 = 0;
-    if (assembled_ok) {
-      MSFM_TRY(run_solve(ba, opt));
-      MSFM_TRY(read_scalars(ba));
-      solved = (int)ba->h_scal[S_FAIL] == 0;
-      mcc = ba->h_scal[S_MCC]; cand_cost = ba->h_scal[S_COST]; dx2 = ba->h_scal[S_DX2]; x2 = ba->h_scal[S_X2];
-    }
+    // (already enqueued with the reduced system; S_FAIL carries both the 3x3 point-block and the
+    // Cholesky / finiteness failures, and any of them makes the step invalid)
+    const bool solved = (int)ba->h_scal[S_FAIL] == 0;
+    const double mcc = ba->h_scal[S_MCC], cand_cost = ba->h_scal[S_COST], dx2 = ba->h_scal[S_DX2], x2 = ba->h_scal[S_X2];
     it.step_is_valid = solved && (mcc > 0.0);
     bool relinearise = false;
     if (!it.step_is_valid) {
@@ -1420,13 +1431,12 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     // ---- next reduced system (new Jacobian after a successful step, else new radius only) ----
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
     if (relinearise) {
-      MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta));
-      MSFM_TRY(allreduce(ba, ba->scal.p + S_COST, 1, MSFM_REDUCE_SUM));
+      MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
+      MSFM_TRY(allreduce(ba, ba->scal.p + S_XCOST, 1, MSFM_REDUCE_SUM));
     }
-    MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0));
-    MSFM_TRY(read_scalars(ba));
+    MSFM_TRY(assemble_and_step());
     if (relinearise) {
-      x_cost = ba->h_scal[S_COST];
+      x_cost = ba->h_scal[S_XCOST];
       it.cost = x_cost;
       it.gradient_max_norm = ba->h_scal[S_GMAX];
     }
