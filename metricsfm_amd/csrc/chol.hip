@@ -11,12 +11,20 @@
 // v_mfma_f64_16x16x4_f64 from padded LDS tiles).  The back substitution L^T z = w runs block
 // by block with explicitly inverted diagonal blocks (k_trinv) so each step is a mat-vec.
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 #define NB 64
 #define LDT 66  // LDS row stride in doubles: 132 dwords = 4 mod 64 -> conflict-free ds_read_b64 fragments
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+// cycle-counter probes for scripts/chol_probe.hip (compiled out of the library)
+#ifndef MSFM_PROBE
+#define MSFM_PROBE(i)
+#define MSFM_PROBE_ARM(j0)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // potrf of the 64x64 diagonal block at (j0,j0), plus the inverses of its four 16x16 diagonal
@@ -68,6 +76,7 @@ __device__ __forceinline__ void potrf64_lds(double* __restrict__ a /*[64][LDT]*/
       for (int k = 0; k < 16; k++) a[lane * LDT + c0 + k] = p[k];
     }
     __syncthreads();
+    MSFM_PROBE(8 + 2 * jb);
     const int tr = 3 - jb;  // 16-row tiles below the panel's diagonal block
     if (wave < 3) {
       // tiles (I >= J) of the trailing block, dealt round-robin to waves 0..2
@@ -105,6 +114,7 @@ __device__ __forceinline__ void potrf64_lds(double* __restrict__ a /*[64][LDT]*/
       for (int r = 0; r < 16; r++) dinv[(jb * 16 + r) * 17 + lane] = x[r];
     }
     __syncthreads();
+    MSFM_PROBE(9 + 2 * jb);
   }
 }
 
@@ -260,8 +270,11 @@ __global__ __launch_bounds__(256) void k_panel64(double* __restrict__ M, int ld,
     J = q - I * (I - 1) / 2 + 1;
   }
   const int ri = t0 + I * 64, rj = t0 + J * 64;
+  MSFM_PROBE_ARM(j0);
+  MSFM_PROBE(0);
   load_tile_pair(M, ld, ri, rj, j0, As, Bs, tid);
   __syncthreads();
+  MSFM_PROBE(1);
   d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
   quad_abt(As, Bs, wr, wc, lr, lk, acc00, acc01, acc10, acc11);
   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(256) void k_panel64(double* __restrict__ M, int ld,
     return;
   }
   // ---- column-0 workgroup: updated diagonal tile -> As, own updated tile -> Cs ----
+  MSFM_PROBE(2);
   d4 d00 = acc00, d01 = acc01, d10 = acc10, d11 = acc11;
   if (I != 0) {
     d00 = d4{0, 0, 0, 0}; d01 = d00; d10 = d00; d11 = d00;
@@ -304,8 +318,10 @@ __global__ __launch_bounds__(256) void k_panel64(double* __restrict__ M, int ld,
   double* rdiag = Bs + 4 * 16 * 17;
   for (int e = tid; e < 4 * 16 * 17; e += 256) dinv[e] = ((e % 17) == ((e / 17) & 15)) ? 1.0 : 0.0;
   __syncthreads();
+  MSFM_PROBE(3);
   if (ncol_next == NB) potrf64_lds<true>(As, dinv, rdiag, ncol_next, tid, fail);
   else potrf64_lds<false>(As, dinv, rdiag, ncol_next, tid, fail);
+  MSFM_PROBE(4);
   if (I == 0) {
     double* lo = Ldiag + (size_t)(t0 / NB) * NB * NB;
     for (int e = tid; e < NB * NB; e += 256) lo[e] = ((e & 63) <= (e >> 6)) ? As[(e >> 6) * LDT + (e & 63)] : 0.0;
@@ -320,6 +336,7 @@ __global__ __launch_bounds__(256) void k_panel64(double* __restrict__ M, int ld,
         if (c <= r) M[(size_t)(t0 + r) * ld + t0 + c] = As[r * LDT + c];
       }
     }
+    MSFM_PROBE(5);
     return;
   }
   // ---- X = C_I0 L11^-T for this workgroup's 64 rows: wave-local blocked substitution (see k_trsm64) ----
@@ -352,6 +369,454 @@ __global__ __launch_bounds__(256) void k_panel64(double* __restrict__ M, int ld,
   for (int jb = 0; jb < 4; jb++)
 #pragma unroll
     for (int i = 0; i < 4; i++) mrow[16 * jb + lq + 4 * i] = X[jb][i];
+  MSFM_PROBE(6);
+}
+
+// =======================================================================================
+// v2 panel kernel.  Same algorithm and data layout as k_panel64 (right-looking, one launch per
+// 64-column panel, next panel's potrf + trsm folded into the launch, no cross-workgroup dependency),
+// re-organised around the only thing that bounds the launch: the dependent chain of a column-0
+// workgroup.  Measured on MI355X (scripts/chol_probe.hip) the old chain was ~65 k ticks, of which
+// 4 x 5.9 k were the 16-column factorisations and ~25 k exposed load / MFMA latency.
+//
+//  * A column-0 workgroup owns THREE 16-row tiles of the new panel (waves 1..3, one tile each);
+//    wave 0 owns no rows and only runs the pivot chain.  All global loads are issued up front.
+//  * The own rows live in registers as transposed accumulator tiles from the first load to the
+//    final store (P_R fragments loaded straight from global in MFMA operand layout) - no third LDS
+//    tile, so two workgroups fit on a CU (2 x 76.3 KB).
+//  * Only the lower 16x16 tiles of the updated diagonal block are formed; column 0 first (all four
+//    waves), the rest while wave 0 already factors.
+//  * potrf16 is left-looking on UNSCALED columns (S = U D^-1 U^T): the multipliers of all but the
+//    newest column come back from LDS as uniform-address (broadcast) reads issued one column ahead;
+//    only the newest column's multiplier and the pivot travel by v_readlane.  The reciprocal (rcp +
+//    one cubic correction) is the only transcendental on the chain, rsqrt is off it.  The inverse
+//    of the 16x16 diagonal block falls out of the same column operations applied to identity rows
+//    (spare lanes; a second register set for the first sub-panel, which has no spare lanes).
+//  * The triangular solve of the own rows is pipelined behind the sub-panels: when sub-panel jb
+//    is being factored the helpers already compute X_(jb-1) and subtract it from the later blocks,
+//    so only X_3 = T_3 Dinv_3^T (4 MFMAs) and the store follow the last pivot.
+// j0 = -64 means "no previous panel" (first block: t0 = 0, nothing to subtract).
+// =======================================================================================
+#define DV 17  // row stride of the 16x16 inverse blocks in LDS
+
+__device__ __forceinline__ double rcp3(double d) {  // v_rcp_f64 is good to 2^-24; one cubic step -> < 2^-60
+  const double x = __builtin_amdgcn_rcp(d);
+  const double e = fma(-d, x, 1.0);
+  const double t = fma(e, e, e);
+  return fma(x, t, x);
+}
+__device__ __forceinline__ double rsq3(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-d * y, y, 1.0);
+  const double h = fma(e, 0.375, 0.5);
+  return fma(y * e, h, y);
+}
+
+// Factor sub-panel JB (columns 16 JB .. 16 JB + 15, rows >= 16 JB) of the 64 x 64 block in Ls, in
+// place, and write the inverse of its 16 x 16 diagonal block to dinv.  ONE wave; lane = row.
+template <int JB, bool FULL>
+__device__ __forceinline__ void potrf16_v2(double* Ls, double* dinv, double* dvec /*[64 + 16]*/, int ncol, int lane, int* fail) {
+  constexpr int c0 = 16 * JB;
+  const bool isrow = lane >= c0;
+  double p[16], u[16], keep[16], rs[16];
+  {
+    const d2* prow = reinterpret_cast<const d2*>(&Ls[lane * LDT + c0]);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+      const d2 v = prow[k2];
+      p[2 * k2] = v.x;
+      p[2 * k2 + 1] = v.y;
+    }
+  }
+  if (JB > 0) {
+    // lanes 0..15 carry the identity rows that end up as L_jj^-T; lanes 16..c0-1 idle (zero rows)
+#pragma unroll
+    for (int k = 0; k < 16; k++) p[k] = isrow ? p[k] : ((lane == k) ? 1.0 : 0.0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; k++) u[k] = (lane == k) ? 1.0 : 0.0;
+  }
+  bool bad = false;
+  double inv_prev = 0.0;
+  if (JB == 1) MSFM_PROBE(11);
+  // Software pipeline.  Column q receives the contributions of columns k < q from three places:
+  //   k <= q-3 : at step q-1, multipliers m_k[row q] fetched from LDS (uniform address = broadcast)
+  //              at the end of step q-3, i.e. a full step before they are used;
+  //   k  = q-2 : at step q-1, v_readlane of m_(q-2) (known since step q-2; off the chain);
+  //   k  = q-1 : at step q, v_readlane of the unscaled entry times 1/d_(q-1)  (the chain).
+  // (All LDS stores of this function are unpredicated - lanes above the sub-panel write into the
+  // never-read upper triangle - so that the whole factorisation is one basic block to schedule.)
+  double b0[16], b1[16], b2[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) b0[k] = b1[k] = b2[k] = 0.0;
+  double m_prev = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const int piv = c0 + c;
+    const bool real = FULL || piv < ncol;  // uniform
+    // The pivot is formed on uniform values (the same arithmetic as the vector update below, so it
+    // is bit-identical to p[c] in lane piv): both readlanes are off the chain, which is then
+    //   inv_(c-1) -> v = t inv -> d = q - t v -> rcp -> 3 fma.
+    const double q = readlane_f64(p[c], piv);
+    double d = q, v = 0.0;
+    if (c >= 1) {
+      const double t = readlane_f64(p[c - 1], piv);
+      v = t * inv_prev;
+      d = fma(-t, v, q);
+    }
+    if (!real) d = 1.0;
+    bad |= !(d > 0.0);
+    const double inv = rcp3(d);
+    if (c >= 1) {
+      p[c] = fma(-p[c - 1], v, p[c]);
+      if (JB == 0) u[c] = fma(-u[c - 1], v, u[c]);
+    }
+    if (c >= 1 && c < 15) {
+      // p[c+1] -= p[c-1] m_(c-1)[piv+1] + sum_{k <= c-2} p[k] m_k[piv+1]
+      const double e = readlane_f64(m_prev, piv + 1);
+      double s0 = p[c - 1] * e, s1 = 0.0, w0 = 0.0, w1 = 0.0;
+      if (JB == 0) w0 = u[c - 1] * e;
+#pragma unroll
+      for (int k = 0; k + 2 <= c; k++) {
+        if (k & 1) { s0 = fma(p[k], b0[k], s0); if (JB == 0) w0 = fma(u[k], b0[k], w0); }
+        else { s1 = fma(p[k], b0[k], s1); if (JB == 0) w1 = fma(u[k], b0[k], w1); }
+      }
+      p[c + 1] -= s0 + s1;
+      if (JB == 0) u[c + 1] -= w0 + w1;
+    }
+    dvec[piv] = d;  // every lane, same value: the scaling 1/sqrt(d) is computed for all 16 columns at once below
+    if (!FULL) {
+      keep[c] = p[c];
+      if (!real) p[c] = 0.0;  // padding / rhs columns are left alone and feed nothing
+    }
+    m_prev = p[c] * inv;
+    Ls[lane * LDT + piv] = m_prev;  // broadcast source for the later columns
+    inv_prev = inv;
+    if (c < 13) {
+      // multipliers m_k[piv + 3], k <= c, used during step c+2
+      const double* mrow = &Ls[(piv + 3) * LDT + c0];
+#pragma unroll
+      for (int k = 0; k + 1 <= c; k += 2) {
+        const d2 v2 = *reinterpret_cast<const d2*>(&mrow[k]);
+        b2[k] = v2.x;
+        b2[k + 1] = v2.y;
+      }
+      if (!(c & 1)) b2[c] = mrow[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetch here, a full step ahead of its use
+#pragma unroll
+    for (int k = 0; k < 16; k++) { b0[k] = b1[k]; b1[k] = b2[k]; }
+  }
+  if (JB == 1) MSFM_PROBE(12);
+  // 1/sqrt(d) of the 16 pivots in one vector operation, then back as uniform values
+  {
+    const double dl = dvec[c0 + (lane & 15)];
+    dvec[64 + (lane & 15)] = rsq3(dl);
+    const d2* rv = reinterpret_cast<const d2*>(&dvec[64]);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++) {
+      const d2 r2 = rv[k2];
+      rs[2 * k2] = r2.x;
+      rs[2 * k2 + 1] = r2.y;
+    }
+  }
+  if (JB == 1) MSFM_PROBE(13);
+  if (bad && lane == 0) atomicOr(fail, 1);
+  // L = U D^-1/2, zero above the diagonal
+#pragma unroll
+  for (int k2 = 0; k2 < 8; k2++) {
+    d2 o;
+    double l0 = p[2 * k2] * rs[2 * k2], l1 = p[2 * k2 + 1] * rs[2 * k2 + 1];
+    l0 = (lane >= c0 + 2 * k2) ? l0 : 0.0;
+    l1 = (lane >= c0 + 2 * k2 + 1) ? l1 : 0.0;
+    if (!FULL) {
+      if (c0 + 2 * k2 >= ncol) l0 = keep[2 * k2];
+      if (c0 + 2 * k2 + 1 >= ncol) l1 = keep[2 * k2 + 1];
+    }
+    o.x = l0; o.y = l1;
+    *reinterpret_cast<d2*>(&Ls[lane * LDT + c0 + 2 * k2]) = o;
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) dinv[(c0 + r) * DV + lane] = ((JB == 0) ? u[r] : p[r]) * rs[r];
+  }
+}
+
+// acc += sum_{s < NS} A_s B_s with A[m][k] = -X[(ra + m) * LDT + k0 + 4 s + k], B[k][n] = Y[(rb + n) * LDT + k0 + 4 s + k]
+template <int NS>
+__device__ __forceinline__ d4 mm_nt_neg(const double* X, int ra, const double* Y, int rb, int k0, int lr, int lk, d4 acc) {
+  const double* ap = &X[(ra + lr) * LDT + k0 + lk];
+  const double* bp = &Y[(rb + lr) * LDT + k0 + lk];
+#pragma unroll
+  for (int s = 0; s < NS; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ap[4 * s], bp[4 * s], acc, 0, 0, 0);
+  return acc;
+}
+// 16x16 tile (a, b) of the block in Ls, accumulator layout
+__device__ __forceinline__ d4 tile_ld(const double* Ls, int a, int b, int lr, int lk) {
+  d4 v;
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = Ls[(16 * a + lk + 4 * i) * LDT + 16 * b + lr];
+  return v;
+}
+__device__ __forceinline__ void tile_st(double* Ls, int a, int b, int lr, int lk, d4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) Ls[(16 * a + lk + 4 * i) * LDT + 16 * b + lr] = v[i];
+}
+
+__device__ __forceinline__ void p0_load(const double* __restrict__ M, int ld, int t0, int j0, int tid, d2 (&pv)[8]) {
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+    pv[it] = *reinterpret_cast<const d2*>(&M[(size_t)(t0 + r) * ld + j0 + c2]);
+  }
+}
+__device__ __forceinline__ void p0_store(double* Bs, int tid, const d2 (&pv)[8]) {
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+    Bs[r * LDT + c2] = pv[it].x;
+    Bs[r * LDT + c2 + 1] = pv[it].y;
+  }
+}
+
+// Column-0 workgroup.  Wave 0 and the helper waves run two different programs with the same number
+// of barriers (the branch is wave-uniform), so that the register file of a wave holds either the
+// pivot chain's state or a helper's tiles, never both.
+template <bool FULL>
+__device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, int j0, int n, int nrt, double* __restrict__ Dinv,
+                                           double* __restrict__ Ldiag, int* fail, double* Bs, double* Ls, double* dinv) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const bool upd = j0 >= 0;
+  const int t0 = j0 + NB;
+  const int ncol = min(NB, n - t0);
+  const int b = blockIdx.x;
+  if (wave == 0) {
+    // ================= pivot-chain wave =================
+    d2 pv[8];
+    if (upd) p0_load(M, ld, t0, j0, tid, pv);
+    d4 D0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) D0[i] = M[(size_t)(t0 + lk + 4 * i) * ld + t0 + lr];
+    if (upd) p0_store(Bs, tid, pv);
+    __syncthreads();
+    MSFM_PROBE(1);
+    if (upd) D0 = mm_nt_neg<16>(Bs, 0, Bs, 0, 0, lr, lk, D0);
+    tile_st(Ls, 0, 0, lr, lk, D0);
+    __syncthreads();
+    MSFM_PROBE(2);
+    potrf16_v2<0, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    __syncthreads();
+    MSFM_PROBE(3);
+    __syncthreads();  // A1
+    MSFM_PROBE(4);
+    potrf16_v2<1, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    __syncthreads();
+    MSFM_PROBE(5);
+    __syncthreads();  // A2
+    MSFM_PROBE(6);
+    potrf16_v2<2, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    __syncthreads();
+    MSFM_PROBE(7);
+    __syncthreads();  // A3
+    MSFM_PROBE(8);
+    potrf16_v2<3, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    __syncthreads();
+    MSFM_PROBE(9);
+  } else {
+    // ================= helper waves: one 16-row tile of the new panel each =================
+    d2 pv[8];
+    if (upd) p0_load(M, ld, t0, j0, tid, pv);
+    const int rt = 4 + 3 * b + wave - 1;
+    const bool own = rt < nrt;
+    const size_t r0 = (size_t)t0 + 16 * (own ? rt : 0);
+    double preg[16];
+    d4 T[4];
+    if (own) {
+      const double* src = M + (r0 + lr) * ld;
+      if (upd) {
+#pragma unroll
+        for (int s = 0; s < 16; s++) preg[s] = src[j0 + 4 * s + lk];
+      }
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) T[jb][i] = src[t0 + 16 * jb + lk + 4 * i];
+    }
+    // tiles of the diagonal block this wave forms: (wave, 0) now, then (ta, 1) and (tb, tc):
+    // wave 1: (1,1),(2,2)   wave 2: (2,1),(3,2)   wave 3: (3,1),(3,3)
+    const int ta = wave, tb = wave == 1 ? 2 : 3, tc = wave == 3 ? 3 : 2;
+    d4 D0, D1, D2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      D0[i] = M[(size_t)(t0 + 16 * wave + lk + 4 * i) * ld + t0 + lr];
+      D1[i] = M[(size_t)(t0 + 16 * ta + lk + 4 * i) * ld + t0 + 16 + lr];
+      D2[i] = M[(size_t)(t0 + 16 * tb + lk + 4 * i) * ld + t0 + 16 * tc + lr];
+    }
+    if (upd) p0_store(Bs, tid, pv);
+    __syncthreads();
+    // ---- column 0 of the updated diagonal block: one 16x16 tile per wave ----
+    if (upd) D0 = mm_nt_neg<16>(Bs, 16 * wave, Bs, 0, 0, lr, lk, D0);
+    tile_st(Ls, wave, 0, lr, lk, D0);
+    __syncthreads();
+    d4 X[4];
+    // ---- B0 (wave 0 factors sub-panel 0): tile (h,1) and block 0 of the own rows ----
+    if (upd) D1 = mm_nt_neg<16>(Bs, 16 * ta, Bs, 16, 0, lr, lk, D1);
+    tile_st(Ls, ta, 1, lr, lk, D1);
+    if (own && upd) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) T[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[lr * LDT + 4 * s + lk], preg[s], T[0], 0, 0, 0);
+    }
+    __syncthreads();
+    // ---- A1: (h,1) -= L_h0 L_10^T ----
+    tile_st(Ls, ta, 1, lr, lk, mm_nt_neg<4>(Ls, 16 * ta, Ls, 16, 0, lr, lk, tile_ld(Ls, ta, 1, lr, lk)));
+    __syncthreads();
+    // ---- B1 ----
+    if (upd) D2 = mm_nt_neg<16>(Bs, 16 * tb, Bs, 16 * tc, 0, lr, lk, D2);
+    D2 = mm_nt_neg<4>(Ls, 16 * tb, Ls, 16 * tc, 0, lr, lk, D2);
+    tile_st(Ls, tb, tc, lr, lk, D2);
+    if (own) {
+      d4 Y = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[lr * DV + lk + 4 * s], T[0][s], Y, 0, 0, 0);
+      X[0] = Y;
+      if (upd) {
+#pragma unroll
+        for (int s = 0; s < 16; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(16 + lr) * LDT + 4 * s + lk], preg[s], T[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(16 + lr) * LDT + lk + 4 * s], X[0][s], T[1], 0, 0, 0);
+    }
+    __syncthreads();
+    // ---- A2: (2,2), (3,2) -= L_x1 L_21^T ----
+    if (wave != 3) tile_st(Ls, tb, 2, lr, lk, mm_nt_neg<4>(Ls, 16 * tb, Ls, 32, 16, lr, lk, tile_ld(Ls, tb, 2, lr, lk)));
+    __syncthreads();
+    // ---- B2 ----
+    if (wave == 3) tile_st(Ls, 3, 3, lr, lk, mm_nt_neg<4>(Ls, 48, Ls, 48, 16, lr, lk, tile_ld(Ls, 3, 3, lr, lk)));
+    if (own) {
+      d4 Y = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(16 + lr) * DV + lk + 4 * s], T[1][s], Y, 0, 0, 0);
+      X[1] = Y;
+      if (upd) {
+#pragma unroll
+        for (int s = 0; s < 16; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(32 + lr) * LDT + 4 * s + lk], preg[s], T[2], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(32 + lr) * LDT + 16 * i2 + lk + 4 * s], X[i2][s], T[2], 0, 0, 0);
+    }
+    __syncthreads();
+    // ---- A3: (3,3) -= L_32 L_32^T ----
+    if (wave == 3) tile_st(Ls, 3, 3, lr, lk, mm_nt_neg<4>(Ls, 48, Ls, 48, 32, lr, lk, tile_ld(Ls, 3, 3, lr, lk)));
+    __syncthreads();
+    // ---- B3 ----
+    if (own) {
+      d4 Y = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(32 + lr) * DV + lk + 4 * s], T[2][s], Y, 0, 0, 0);
+      X[2] = Y;
+      if (upd) {
+#pragma unroll
+        for (int s = 0; s < 16; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(48 + lr) * LDT + 4 * s + lk], preg[s], T[3], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(48 + lr) * LDT + 16 * i2 + lk + 4 * s], X[i2][s], T[3], 0, 0, 0);
+    }
+    __syncthreads();
+    // ---- tail: X_3 = T_3 Dinv_3^T, store the own rows ----
+    if (own) {
+      d4 Y = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(48 + lr) * DV + lk + 4 * s], T[3][s], Y, 0, 0, 0);
+      X[3] = Y;
+      double* dst = M + (r0 + lr) * ld + t0;
+#pragma unroll
+      for (int jb = 0; jb < 4; jb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[16 * jb + lk + 4 * i] = X[jb][i];
+    }
+  }
+  if (b == 0) {
+    // workgroup 0 publishes the factor of the diagonal block
+    double* lo = Ldiag + (size_t)(t0 / NB) * NB * NB;
+    for (int e = tid; e < NB * NB; e += 256) lo[e] = ((e & 63) <= (e >> 6)) ? Ls[(e >> 6) * LDT + (e & 63)] : 0.0;
+    double* out = Dinv + (size_t)(t0 / NB) * 1024;
+    for (int e = tid; e < 1024; e += 256) out[e] = dinv[(e >> 4) * DV + (e & 15)];
+    if (!FULL) {
+      // last, partial block: it also holds the rhs row (row n), whose entries are the tail of
+      // w = L^-1 rhs that the back substitution reads from M.  No other workgroup reads this tile
+      // in this launch (there are no rows below it).
+      for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        if (c <= r) M[(size_t)(t0 + r) * ld + t0 + c] = Ls[r * LDT + c];
+      }
+    }
+  }
+  MSFM_PROBE(10);
+}
+
+// grid: ncw column-0 workgroups, then (for j0 >= 0) the 64x64 tiles (I, J), 1 <= J <= I < nt, of the
+// trailing update  C_IJ -= P_I P_J^T.
+template <bool FULL>
+__global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld, int j0, int n, int nrt, int ncw, int nt,
+                                                      double* __restrict__ Dinv, double* __restrict__ Ldiag, int* fail) {
+  __shared__ double sm[2 * 64 * LDT + 64 * DV + 80];
+  double* As = sm;
+  double* Bs = sm + 64 * LDT;
+  const int tid = threadIdx.x;
+  MSFM_PROBE_ARM(j0);
+  MSFM_PROBE(0);
+  if ((int)blockIdx.x < ncw) {
+    panel_col0<FULL>(M, ld, j0, n, nrt, Dinv, Ldiag, fail, As, Bs, sm + 2 * 64 * LDT);
+    return;
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int t0 = j0 + NB;
+  // pairs (I, J) with 1 <= J <= I < nt, enumerated row by row: index q = I(I-1)/2 + (J-1)
+  const int q = blockIdx.x - ncw;
+  int I = (int)((sqrt(8.0 * q + 1.0) + 1.0) * 0.5);
+  while (I * (I - 1) / 2 > q) I--;
+  while ((I + 1) * I / 2 <= q) I++;
+  const int J = q - I * (I - 1) / 2 + 1;
+  const int ri = t0 + I * 64, rj = t0 + J * 64;
+  // all loads first: the two panel tiles and this wave's quadrant of C (the accumulators start from it)
+  d2 va[8], vb[8];
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+    va[it] = *reinterpret_cast<const d2*>(&M[(size_t)(ri + r) * ld + j0 + c2]);
+    vb[it] = *reinterpret_cast<const d2*>(&M[(size_t)(rj + r) * ld + j0 + c2]);
+  }
+  const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;
+  d4 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const double* c0 = &M[(size_t)(ri + qrow + 4 * i) * ld + rj + qcol];
+    const double* c1 = &M[(size_t)(ri + qrow + 16 + 4 * i) * ld + rj + qcol];
+    acc00[i] = c0[0]; acc01[i] = c0[16]; acc10[i] = c1[0]; acc11[i] = c1[16];
+  }
+#pragma unroll
+  for (int it = 0; it < 8; it++) {
+    const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+    As[r * LDT + c2] = -va[it].x;  // negated once here: the MFMAs then accumulate C - P_I P_J^T directly
+    As[r * LDT + c2 + 1] = -va[it].y;
+    Bs[r * LDT + c2] = vb[it].x;
+    Bs[r * LDT + c2 + 1] = vb[it].y;
+  }
+  __syncthreads();
+  quad_abt(As, Bs, wr, wc, lr, lk, acc00, acc01, acc10, acc11);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double* c0 = &M[(size_t)(ri + qrow + 4 * i) * ld + rj + qcol];
+    double* c1 = &M[(size_t)(ri + qrow + 16 + 4 * i) * ld + rj + qcol];
+    c0[0] = acc00[i]; c0[16] = acc01[i]; c1[0] = acc10[i]; c1[16] = acc11[i];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -460,22 +925,36 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   double* Dinv = work;
   double* Linv = work + (size_t)npad * 16;
   double* Ldiag = work + (size_t)npad * 80;
+  static const bool v1 = getenv("MSFM_CHOL_V1") != nullptr;  // previous panel kernels, kept for A/B timing
+  if (!v1) {
+    for (int t0 = 0; t0 < n; t0 += NB) {
+      const int j0 = t0 - NB;
+      const int nrt = cdiv(nrows - t0, 16);            // 16-row tiles from t0 down that carry data
+      const int ncw = std::max(1, cdiv(nrt - 4, 3));   // column-0 workgroups: three row tiles each
+      const int nt = cdiv(nrows - t0, 64);
+      const int nbulk = j0 >= 0 ? nt * (nt - 1) / 2 : 0;
+      KTimer t(ctx, "chol_panel_mfma");  // trailing update with panel j0 + potrf / trsm of the panel at t0
+      if (n - t0 >= NB) hipLaunchKernelGGL(k_panel_v2<true>, dim3(ncw + nbulk), dim3(256), 0, s, M, npad, j0, n, nrt, ncw, nt, Dinv, Ldiag, fail);
+      else hipLaunchKernelGGL(k_panel_v2<false>, dim3(ncw + nbulk), dim3(256), 0, s, M, npad, j0, n, nrt, ncw, nt, Dinv, Ldiag, fail);
+    }
+  } else {
   {
-    KTimer t(ctx, "chol_potrf64");
-    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, 0, n, Dinv, Ldiag, fail);
-  }
-  if (nrows > NB) {
-    KTimer t(ctx, "chol_trsm_mfma");
-    hipLaunchKernelGGL(k_trsm64, dim3(cdiv(nrows - NB, 64)), dim3(256), 0, s, M, npad, 0, Dinv);
-  }
-  for (int jb = 0; jb < nblk; jb++) {
-    const int j0 = jb * NB;
-    if (j0 >= n) break;
-    const int rows_below = nrows - (j0 + NB);
-    if (rows_below <= 0) continue;
-    const int nt = cdiv(rows_below, 64);
-    KTimer t(ctx, "chol_panel_mfma");  // trailing update + next panel's potrf + trsm, one launch
-    hipLaunchKernelGGL(k_panel64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, M, npad, j0, nt, n, Dinv, Ldiag, fail);
+      KTimer t(ctx, "chol_potrf64");
+      hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, M, npad, 0, n, Dinv, Ldiag, fail);
+    }
+    if (nrows > NB) {
+      KTimer t(ctx, "chol_trsm_mfma");
+      hipLaunchKernelGGL(k_trsm64, dim3(cdiv(nrows - NB, 64)), dim3(256), 0, s, M, npad, 0, Dinv);
+    }
+    for (int jb = 0; jb < nblk; jb++) {
+      const int j0 = jb * NB;
+      if (j0 >= n) break;
+      const int rows_below = nrows - (j0 + NB);
+      if (rows_below <= 0) continue;
+      const int nt = cdiv(rows_below, 64);
+      KTimer t(ctx, "chol_panel_mfma");  // trailing update + next panel's potrf + trsm, one launch
+      hipLaunchKernelGGL(k_panel64, dim3(nt * (nt + 1) / 2), dim3(256), 0, s, M, npad, j0, nt, n, Dinv, Ldiag, fail);
+    }
   }
   {
     KTimer t(ctx, "chol_backsolve");
