@@ -436,9 +436,7 @@ __device__ __forceinline__ void potrf16_v2(double* Ls, double* dinv, double* dve
 #pragma unroll
     for (int k = 0; k < 16; k++) u[k] = (lane == k) ? 1.0 : 0.0;
   }
-  bool bad = false;
   double inv_prev = 0.0;
-  if (JB == 1) MSFM_PROBE(11);
   // Software pipeline.  Column q receives the contributions of columns k < q from three places:
   //   k <= q-3 : at step q-1, multipliers m_k[row q] fetched from LDS (uniform address = broadcast)
   //              at the end of step q-3, i.e. a full step before they are used;
@@ -450,39 +448,56 @@ __device__ __forceinline__ void potrf16_v2(double* Ls, double* dinv, double* dve
 #pragma unroll
   for (int k = 0; k < 16; k++) b0[k] = b1[k] = b2[k] = 0.0;
   double m_prev = 0.0;
+  // One step is hand-interleaved (the wave is alone on its SIMD and issues in order): after each
+  // instruction of the dependent chain  v -> d -> rcp -> e1 -> e2 -> inv  come a few independent
+  // terms of the next column's running sums.  sched_barrier pins that order.
+#define MSFM_SB() __builtin_amdgcn_sched_barrier(0)
+#define MSFM_CT(k)                                                            \
+  do {                                                                        \
+    if (cterms && (k) + 2 <= c) {                                             \
+      if ((k) & 1) { s0 = fma(p[k], b0[k], s0); if (JB == 0) w0 = fma(u[k], b0[k], w0); } \
+      else { p[c + 1] = fma(-p[k], b0[k], p[c + 1]); if (JB == 0) u[c + 1] = fma(-u[k], b0[k], u[c + 1]); } \
+    }                                                                         \
+  } while (0)
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const int piv = c0 + c;
     const bool real = FULL || piv < ncol;  // uniform
-    // The pivot is formed on uniform values (the same arithmetic as the vector update below, so it
-    // is bit-identical to p[c] in lane piv): both readlanes are off the chain, which is then
-    //   inv_(c-1) -> v = t inv -> d = q - t v -> rcp -> 3 fma.
+    const bool cterms = c >= 1 && c < 15;  // p[c+1] -= p[c-1] m_(c-1)[piv+1] + sum_{k <= c-2} p[k] m_k[piv+1]
+    // The pivot is formed on uniform values (the same arithmetic as the vector update of p[c], so
+    // it is bit-identical to p[c] in lane piv): every readlane is off the chain.
     const double q = readlane_f64(p[c], piv);
-    double d = q, v = 0.0;
-    if (c >= 1) {
-      const double t = readlane_f64(p[c - 1], piv);
-      v = t * inv_prev;
-      d = fma(-t, v, q);
-    }
+    const double t = c >= 1 ? readlane_f64(p[c - 1], piv) : 0.0;
+    const double e = cterms ? readlane_f64(m_prev, piv + 1) : 0.0;
+    double s0 = 0.0, w0 = 0.0;
+    MSFM_SB();
+    const double v = t * inv_prev;
+    if (cterms) { s0 = p[c - 1] * e; if (JB == 0) w0 = u[c - 1] * e; }
+    MSFM_CT(0);
+    MSFM_SB();
+    double d = c >= 1 ? fma(-t, v, q) : q;
     if (!real) d = 1.0;
-    bad |= !(d > 0.0);
-    const double inv = rcp3(d);
+    MSFM_CT(1); MSFM_CT(2);
+    MSFM_SB();
+    const double x = __builtin_amdgcn_rcp(d);
+    MSFM_CT(3); MSFM_CT(4);
     if (c >= 1) {
       p[c] = fma(-p[c - 1], v, p[c]);
       if (JB == 0) u[c] = fma(-u[c - 1], v, u[c]);
     }
-    if (c >= 1 && c < 15) {
-      // p[c+1] -= p[c-1] m_(c-1)[piv+1] + sum_{k <= c-2} p[k] m_k[piv+1]
-      const double e = readlane_f64(m_prev, piv + 1);
-      double s0 = p[c - 1] * e, s1 = 0.0, w0 = 0.0, w1 = 0.0;
-      if (JB == 0) w0 = u[c - 1] * e;
-#pragma unroll
-      for (int k = 0; k + 2 <= c; k++) {
-        if (k & 1) { s0 = fma(p[k], b0[k], s0); if (JB == 0) w0 = fma(u[k], b0[k], w0); }
-        else { s1 = fma(p[k], b0[k], s1); if (JB == 0) w1 = fma(u[k], b0[k], w1); }
-      }
-      p[c + 1] -= s0 + s1;
-      if (JB == 0) u[c + 1] -= w0 + w1;
+    MSFM_SB();
+    const double e1 = fma(-d, x, 1.0);
+    MSFM_CT(5); MSFM_CT(6);
+    MSFM_SB();
+    const double e2 = fma(e1, e1, e1);
+    MSFM_CT(7); MSFM_CT(8); MSFM_CT(9);
+    MSFM_SB();
+    const double inv = fma(x, e2, x);
+    MSFM_CT(10); MSFM_CT(11); MSFM_CT(12);
+    MSFM_SB();
+    if (cterms) {
+      p[c + 1] -= s0;
+      if (JB == 0) u[c + 1] -= w0;
     }
     dvec[piv] = d;  // every lane, same value: the scaling 1/sqrt(d) is computed for all 16 columns at once below
     if (!FULL) {
@@ -503,14 +518,16 @@ __device__ __forceinline__ void potrf16_v2(double* Ls, double* dinv, double* dve
       }
       if (!(c & 1)) b2[c] = mrow[c];
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the fetch here, a full step ahead of its use
+    MSFM_SB();  // keep the fetch here, a full step ahead of its use
 #pragma unroll
     for (int k = 0; k < 16; k++) { b0[k] = b1[k]; b1[k] = b2[k]; }
   }
-  if (JB == 1) MSFM_PROBE(12);
+#undef MSFM_CT
+#undef MSFM_SB
   // 1/sqrt(d) of the 16 pivots in one vector operation, then back as uniform values
   {
     const double dl = dvec[c0 + (lane & 15)];
+    if (!(dl > 0.0)) atomicOr(fail, 1);  // Eigen LLT: info() != Success
     dvec[64 + (lane & 15)] = rsq3(dl);
     const d2* rv = reinterpret_cast<const d2*>(&dvec[64]);
 #pragma unroll
@@ -520,15 +537,11 @@ __device__ __forceinline__ void potrf16_v2(double* Ls, double* dinv, double* dve
       rs[2 * k2 + 1] = r2.y;
     }
   }
-  if (JB == 1) MSFM_PROBE(13);
-  if (bad && lane == 0) atomicOr(fail, 1);
-  // L = U D^-1/2, zero above the diagonal
+  // L = U D^-1/2 (the entries above the diagonal of the 16x16 block are never read by anyone)
 #pragma unroll
   for (int k2 = 0; k2 < 8; k2++) {
     d2 o;
     double l0 = p[2 * k2] * rs[2 * k2], l1 = p[2 * k2 + 1] * rs[2 * k2 + 1];
-    l0 = (lane >= c0 + 2 * k2) ? l0 : 0.0;
-    l1 = (lane >= c0 + 2 * k2 + 1) ? l1 : 0.0;
     if (!FULL) {
       if (c0 + 2 * k2 >= ncol) l0 = keep[2 * k2];
       if (c0 + 2 * k2 + 1 >= ncol) l1 = keep[2 * k2 + 1];
@@ -584,7 +597,7 @@ __device__ __forceinline__ void p0_store(double* Bs, int tid, const d2 (&pv)[8])
 // pivot chain's state or a helper's tiles, never both.
 template <bool FULL>
 __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, int j0, int n, int nrt, double* __restrict__ Dinv,
-                                           double* __restrict__ Ldiag, int* fail, double* Bs, double* Ls, double* dinv) {
+                                           double* __restrict__ Ldiag, int* fail, double* Bs, double* Ls, double* dinv, double* dvec) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const bool upd = j0 >= 0;
@@ -605,22 +618,22 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, int j
     tile_st(Ls, 0, 0, lr, lk, D0);
     __syncthreads();
     MSFM_PROBE(2);
-    potrf16_v2<0, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    potrf16_v2<0, FULL>(Ls, dinv, dvec, ncol, lane, fail);
     __syncthreads();
     MSFM_PROBE(3);
     __syncthreads();  // A1
     MSFM_PROBE(4);
-    potrf16_v2<1, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    potrf16_v2<1, FULL>(Ls, dinv, dvec, ncol, lane, fail);
     __syncthreads();
     MSFM_PROBE(5);
     __syncthreads();  // A2
     MSFM_PROBE(6);
-    potrf16_v2<2, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    potrf16_v2<2, FULL>(Ls, dinv, dvec, ncol, lane, fail);
     __syncthreads();
     MSFM_PROBE(7);
     __syncthreads();  // A3
     MSFM_PROBE(8);
-    potrf16_v2<3, FULL>(Ls, dinv, dinv + 64 * DV, ncol, lane, fail);
+    potrf16_v2<3, FULL>(Ls, dinv, dvec, ncol, lane, fail);
     __syncthreads();
     MSFM_PROBE(9);
   } else {
@@ -764,14 +777,15 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, int j
 template <bool FULL>
 __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld, int j0, int n, int nrt, int ncw, int nt,
                                                       double* __restrict__ Dinv, double* __restrict__ Ldiag, int* fail) {
-  __shared__ double sm[2 * 64 * LDT + 64 * DV + 80];
-  double* As = sm;
-  double* Bs = sm + 64 * LDT;
+  // small arrays and the diagonal block first: their uniform-address reads then fit the 16-bit DS offset
+  __shared__ double sm[80 + 64 * DV + 2 * 64 * LDT];
+  double* As = sm + 80 + 64 * DV;
+  double* Bs = As + 64 * LDT;
   const int tid = threadIdx.x;
   MSFM_PROBE_ARM(j0);
   MSFM_PROBE(0);
   if ((int)blockIdx.x < ncw) {
-    panel_col0<FULL>(M, ld, j0, n, nrt, Dinv, Ldiag, fail, As, Bs, sm + 2 * 64 * LDT);
+    panel_col0<FULL>(M, ld, j0, n, nrt, Dinv, Ldiag, fail, /*Bs=*/Bs, /*Ls=*/As, /*dinv=*/sm + 80, /*dvec=*/sm);
     return;
   }
   const int wave = tid >> 6, lane = tid & 63;
