@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--feats", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matching", action="store_true")
+    ap.add_argument("--verify-pairs", type=int, default=2048, help="image pairs in the geometric-verification leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL)")
     args = ap.parse_args()
 
@@ -236,6 +237,48 @@ def main():
                                              frac=(kern_tf / peak) if kern_tf else None, traffic=None, kernel=kname,
                                              avg_launch_ms=kst["total_ms"] if kst else None,
                                              note="algorithmic 2*128*M1*M2 operations per pair / kernel time; int8 MFMA, exact integer distances"))
+
+    # ------------------------------------------------------------------ geometric-verification leg
+    if not args.no_matching and rank == 0:
+        rng = np.random.default_rng(0x4D53464D)
+        n_vp, n_vm = args.verify_pairs, 256
+
+        def two_view(n):
+            X = np.column_stack([rng.uniform(-40, 40, n), rng.uniform(-30, 30, n), rng.uniform(80, 120, n)])
+            a = rng.normal(0, 0.05, 3)
+            th = np.linalg.norm(a)
+            K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]]) / th
+            R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+            Xc = X @ R.T + np.array([10.0, 1.0, 0.5])
+            x1 = 4800 * X[:, :2] / X[:, 2:3] + rng.normal(0, 0.5, (n, 2))
+            x2 = 4800 * Xc[:, :2] / Xc[:, 2:3] + rng.normal(0, 0.5, (n, 2))
+            bad = rng.choice(n, int(0.3 * n), replace=False)
+            x2[bad] = np.column_stack([rng.uniform(-2000, 2000, len(bad)), rng.uniform(-1500, 1500, len(bad))])
+            return x1.astype(np.float32), x2.astype(np.float32)
+
+        tv = [two_view(n_vm) for _ in range(64)]   # 64 distinct geometries, tiled to n_vp pairs
+        v1 = np.concatenate([tv[p % 64][0] for p in range(n_vp)])
+        v2 = np.concatenate([tv[p % 64][1] for p in range(n_vp)])
+        voff = (np.arange(n_vp + 1) * n_vm).astype(np.int32)
+        ctx.fundamental_ransac(voff[:9], v1[:8 * n_vm], v2[:8 * n_vm])   # warm-up
+        ctx.profile(True)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        _, _, vnin, vok = ctx.fundamental_ransac(voff, v1, v2)
+        v_s = time.perf_counter() - t0
+        vst = ctx.profile_get()
+        ctx.profile(False)
+        kms = sum(vst[k]["total_ms"] for k in ("geo_fransac_score", "geo_fransac_select") if k in vst)
+        out["geo_verification"] = dict(metric="pairs verified/sec", value=n_vp / v_s, unit="pairs/s", pairs=n_vp, matches_per_pair=n_vm,
+                                       outlier_fraction=0.3, samples_per_pair=2000, accepted=int(vok.sum()), mean_inliers=float(vnin.mean()),
+                                       kernel_ms=kms, kernel_pairs_per_sec=(n_vp / (kms * 1e-3)) if kms else None, dtype="f64",
+                                       note="host arrays in, host arrays out (PCIe inclusive); FM_RANSAC restatement, 7-point, 2000 samples scored per pair")
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            t0 = time.perf_counter()
+            O.fundamental_ransac(voff[:5], v1[:4 * n_vm], v2[:4 * n_vm])
+            out["geo_verification"]["cpu_baseline"] = dict(value=4 / (time.perf_counter() - t0), unit="pairs/s", cores=1, kind="port",
+                                                           sample="4 pairs by the sequential CPU oracle (adaptive stop active)")
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if world == 1 and not args.no_cpu_baseline:

@@ -332,6 +332,75 @@ std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& 
   return out;
 }
 
+// ---- geometric verification ----------------------------------------------------------------------
+static void flatten(const std::vector<Point2f>& v, std::vector<float>& out) {
+  out.resize(2 * v.size());
+  for (size_t i = 0; i < v.size(); i++) { out[2 * i] = v[i].x; out[2 * i + 1] = v[i].y; }
+}
+
+bool GeoVerification::GeoVerificationFundamental(std::vector<Point2f>& pt1, std::vector<Point2f>& pt2, std::vector<int>& match_inliers,
+                                                 Mat3& FMatrix) {
+  if (pt1.size() < 30) return false;
+  std::vector<float> a, b;
+  flatten(pt1, a); flatten(pt2, b);
+  const int off[2] = {0, (int)pt1.size()};
+  msfm_fransac_options o;
+  msfm_fransac_default_options(&o);
+  std::vector<uint8_t> status(pt1.size());
+  int nin = 0;
+  uint8_t ok = 0;
+  check(msfm_fundamental_ransac_batch(Context(), 1, off, a.data(), b.data(), &o, FMatrix.m, status.data(), &nin, &ok), "fundamental_ransac");
+  for (size_t i = 0; i < status.size(); i++) if (status[i]) match_inliers.push_back((int)i);
+  return match_inliers.size() >= 30;
+}
+
+bool GeoVerification::GeoVerificationFundamental(std::vector<Point2f>& pt1, std::vector<Point2f>& pt2, Mat3 FMatrix,
+                                                 std::vector<int>& match_inliers) {
+  match_inliers.clear();
+  if (pt1.empty()) return true;
+  std::vector<float> a, b;
+  flatten(pt1, a); flatten(pt2, b);
+  std::vector<uint8_t> in(pt1.size());
+  check(msfm_epipolar_filter(Context(), a.data(), b.data(), (int)pt1.size(), FMatrix.m, 3.0, in.data()), "epipolar_filter");
+  for (size_t i = 0; i < in.size(); i++) if (in[i]) match_inliers.push_back((int)i);
+  return true;
+}
+
+std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<PairMatches>& matches,
+                                                          const std::vector<std::vector<Point2f>>& keypoints) {
+  const int np = (int)matches.size();
+  std::vector<int> off_g(np + 1, 0), off_a(np + 1, 0);
+  for (int p = 0; p < np; p++) {
+    off_g[p + 1] = off_g[p] + (int)matches[p].matches_good.size();
+    off_a[p + 1] = off_a[p] + (int)matches[p].matches_all.size();
+  }
+  std::vector<float> g1(2 * (size_t)off_g[np]), g2(g1.size()), a1(2 * (size_t)off_a[np]), a2(a1.size());
+  for (int p = 0; p < np; p++) {
+    const auto& k1 = keypoints[matches[p].idx1];
+    const auto& k2 = keypoints[matches[p].idx2];
+    size_t e = off_g[p];
+    for (auto& m : matches[p].matches_good) { g1[2 * e] = k1[m.first].x; g1[2 * e + 1] = k1[m.first].y; g2[2 * e] = k2[m.second].x; g2[2 * e + 1] = k2[m.second].y; e++; }
+    e = off_a[p];
+    for (auto& m : matches[p].matches_all) { a1[2 * e] = k1[m.first].x; a1[2 * e + 1] = k1[m.first].y; a2[2 * e] = k2[m.second].x; a2[2 * e + 1] = k2[m.second].y; e++; }
+  }
+  msfm_fransac_options o;
+  msfm_fransac_default_options(&o);
+  std::vector<double> F(9 * (size_t)std::max(1, np));
+  std::vector<uint8_t> in_g(std::max(1, off_g[np])), ok(std::max(1, np)), in_a(std::max(1, off_a[np]));
+  std::vector<int> nin(std::max(1, np));
+  check(msfm_fundamental_ransac_batch(Context(), np, off_g.data(), g1.data(), g2.data(), &o, F.data(), in_g.data(), nin.data(), ok.data()),
+        "fundamental_ransac_batch");
+  check(msfm_epipolar_filter_batch(Context(), np, off_a.data(), a1.data(), a2.data(), F.data(), ok.data(), 3.0, in_a.data()),
+        "epipolar_filter_batch");
+  std::vector<std::vector<std::pair<int, int>>> out(np);
+  for (int p = 0; p < np; p++) {
+    if (!ok[p]) continue;  // isOK == false: the pair writes nothing (fine_matching_graph.cc:182-186)
+    for (int e = off_a[p]; e < off_a[p + 1]; e++)
+      if (in_a[e]) out[p].push_back(matches[p].matches_all[e - off_a[p]]);
+  }
+  return out;
+}
+
 // ---- match files ---------------------------------------------------------------------------------
 void WriteOutMatches(const std::string& fold, int idx1, int idx2, const std::vector<std::pair<int, int>>& matches) {
   const int num_match = (int)matches.size();

@@ -141,6 +141,24 @@ std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& 
                                          const std::vector<std::pair<int, int>>& pairs, float thRatio_good = 0.6f,
                                          float thRatio_all = 0.85f);
 
+// Geometric verification (SfM/src/utils/geo_verification.h/.cc:30-79).  cv::Point2f / cv::Mat become Point2f / Mat3.
+struct Point2f { float x = 0, y = 0; };
+class GeoVerification {
+ public:
+  // cv::findFundamentalMat(FM_RANSAC, 3.0) + the 30-point / 30-inlier gates            (geo_verification.cc:30-58)
+  static bool GeoVerificationFundamental(std::vector<Point2f>& pt1, std::vector<Point2f>& pt2, std::vector<int>& match_inliers,
+                                         Mat3& FMatrix);
+  // closed-form filter of a second match set with a given F                            (geo_verification.cc:60-79)
+  static bool GeoVerificationFundamental(std::vector<Point2f>& pt1, std::vector<Point2f>& pt2, Mat3 FMatrix,
+                                         std::vector<int>& match_inliers);
+};
+// The verification half of FineMatchingGraph::BuildMatchGraph (fine_matching_graph.cc:138-187) for every pair in two
+// batched calls: RANSAC on the "good" matches, then the F filter on the "all" matches of the pairs that passed.
+// keypoints[image][feature] are the centred pixel coordinates of database.cc:522-527.
+// Returns per pair the surviving matches_all entries (empty when the pair failed: nothing is written for it).
+std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<PairMatches>& matches,
+                                                          const std::vector<std::vector<Point2f>>& keypoints);
+
 // The reference's stage boundary is a set of files: per image `<idx1>_match` (binary records
 // int idx2, int n, int[2n]) and `graph_matching.txt`.  Same bytes as FineMatchingGraph::WriteOutMatches /
 // WriteOutMatchGraph (fine_matching_graph.cc:247-292) and Graph::QueryMatch (graph.cc:92-137).

@@ -81,11 +81,35 @@ int main() {
     for (auto& m : pm.matches_good) { good++; good_right += feat_pt[pm.idx1][m.first] == feat_pt[pm.idx2][m.second]; }
   std::printf("matching: %zu pairs, %ld good matches, %.2f%% correct\n", pairs.size(), good, 100.0 * good_right / std::max(1L, good));
   if (good < 0.8 * pairs.size() * n_pts || good_right < 0.99 * good) { std::printf("FAIL: matching\n"); return 1; }
-  // the reference hands matches to the SfM stage through files: write them, read image 0's back
+  // geometric verification (fine_matching_graph.cc:138-153): F by RANSAC on the good set, filter of the all set
+  std::vector<std::vector<Point2f>> kpf(n_cams);
+  for (int i = 0; i < n_cams; i++) {
+    kpf[i].resize(kp[i].size());
+    for (size_t m = 0; m < kp[i].size(); m++) { kpf[i][m].x = (float)kp[i][m].x; kpf[i][m].y = (float)kp[i][m].y; }
+  }
+  std::vector<std::vector<std::pair<int, int>>> verified = VerifyPairs(matches, kpf);
+  long kept = 0, kept_right = 0, all_right = 0;
+  for (size_t p = 0; p < matches.size(); p++) {
+    for (auto& m : matches[p].matches_all) all_right += feat_pt[matches[p].idx1][m.first] == feat_pt[matches[p].idx2][m.second];
+    for (auto& m : verified[p]) { kept++; kept_right += feat_pt[matches[p].idx1][m.first] == feat_pt[matches[p].idx2][m.second]; }
+  }
+  std::printf("verification: %ld matches kept, %.2f%% correct, %.2f%% of the correct ones kept\n", kept, 100.0 * kept_right / std::max(1L, kept),
+              100.0 * kept_right / std::max(1L, all_right));
+  if (kept_right < 0.95 * all_right || kept_right < 0.995 * kept) { std::printf("FAIL: geometric verification\n"); return 1; }
+  {  // the single-pair members agree with the batch
+    std::vector<Point2f> a, b;
+    for (auto& m : matches[0].matches_good) { a.push_back(kpf[matches[0].idx1][m.first]); b.push_back(kpf[matches[0].idx2][m.second]); }
+    std::vector<int> inl;
+    Mat3 Fm;
+    if (!GeoVerification::GeoVerificationFundamental(a, b, inl, Fm)) { std::printf("FAIL: GeoVerificationFundamental\n"); return 1; }
+  }
+  // the reference hands matches to the SfM stage through files: write the verified ones, read image 0's back
   char tmpl[] = "/tmp/msfm_test_sfm_XXXXXX";
   const std::string fold = mkdtemp(tmpl) ? std::string(tmpl) : std::string("/tmp");
   std::vector<std::vector<int>> match_graph(n_cams, std::vector<int>(n_cams, 0));
-  for (auto& pm : matches) {
+  for (size_t p = 0; p < matches.size(); p++) {
+    auto& pm = matches[p];
+    pm.matches_good = verified[p];  // matches_inliers of fine_matching_graph.cc:153-156 feed the next stage
     WriteOutMatches(fold, pm.idx1, pm.idx2, pm.matches_good);
     match_graph[pm.idx1][pm.idx2] = (int)pm.matches_good.size();
   }

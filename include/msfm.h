@@ -286,6 +286,34 @@ int msfm_reproject_mse_batch(msfm_ctx* ctx, const msfm_tracks* tracks, const dou
 int msfm_epipolar_filter(msfm_ctx* ctx, const float* pt1, const float* pt2, int n,
                          const double F[9], double th, uint8_t* inlier);
 
+/* GeoVerification::GeoVerificationFundamental (SfM/src/utils/geo_verification.cc:30-58), batched over image
+ * pairs: cv::findFundamentalMat(pt1, pt2, status, cv::FM_RANSAC, 3.0) followed by the >= 30 inliers gate
+ * (:34-36, :54-56).  OpenCV 2.4's FM_RANSAC restated: 7-point minimal solver (up to 3 models per sample),
+ * error = max of the two squared point-to-epipolar-line distances <= threshold^2, confidence 0.99, at most
+ * 2000 samples with the adaptive stop of cvRANSACUpdateNumIters, best model returned without refit.  The
+ * sampler is counter based: sample h of pair p (its index in this call) depends only on (seed, p, h).
+ * Pair p owns matches [offsets[p], offsets[p+1]); pt1/pt2 are cv::Point2f pairs (centred pixels).
+ * Out: F[p][9] row-major (x2^T F x1 = 0, F[8] = 1 when possible; zeros when no model), inlier[total] 0/1
+ * against the returned F, n_inliers[p], ok[p] = the bool GeoVerificationFundamental returns. */
+typedef struct msfm_fransac_options {
+  double threshold;      /* 3.0  (th_epipolar1, geo_verification.cc:44) */
+  double confidence;     /* 0.99 (findFundamentalMat default param2)    */
+  int max_iterations;    /* 2000 (CvModelEstimator2::runRANSAC default) */
+  int min_points;        /* 30   (geo_verification.cc:34)               */
+  int min_inliers;       /* 30   (geo_verification.cc:54)               */
+  uint64_t seed;
+} msfm_fransac_options;
+void msfm_fransac_default_options(msfm_fransac_options* opt);
+int msfm_fundamental_ransac_batch(msfm_ctx* ctx, int n_pairs, const int* offsets, const float* pt1,
+                                  const float* pt2, const msfm_fransac_options* opt, double* F,
+                                  uint8_t* inlier, int* n_inliers, uint8_t* ok);
+/* The closed-form filter above for many pairs at once (fine_matching_graph.cc:148-150: applied to the
+ * "all" match set only when the pair's RANSAC succeeded): pairs with ok[p] == 0 get all-zero masks
+ * (ok may be NULL = every pair). */
+int msfm_epipolar_filter_batch(msfm_ctx* ctx, int n_pairs, const int* offsets, const float* pt1,
+                               const float* pt2, const double* F, const uint8_t* ok, double th,
+                               uint8_t* inlier);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,12 @@ class BaProblem(C.Structure):
                 ("pt_mutable", c_u8_p), ("gps_xyz", c_double_p), ("gps_weight", C.c_double)]
 
 
+class FransacOptions(C.Structure):
+    """msfm_fransac_options (include/msfm.h)."""
+    _fields_ = [("threshold", C.c_double), ("confidence", C.c_double), ("max_iterations", C.c_int),
+                ("min_points", C.c_int), ("min_inliers", C.c_int), ("seed", C.c_uint64)]
+
+
 class BaOptions(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int), ("num_threads", C.c_int), ("progress_to_stdout", C.c_int),
                 ("huber_delta", C.c_double), ("function_tolerance", C.c_double),

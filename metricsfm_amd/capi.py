@@ -22,7 +22,8 @@ SYMBOLS = [
     "msfm_match_pairs_rerun", "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
     "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
-    "msfm_epipolar_filter",
+    "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
+    "msfm_epipolar_filter_batch",
 ]
 
 
@@ -80,6 +81,11 @@ def lib():
         fn.argtypes = [vp, C.POINTER(A.Tracks), d, d, A.c_double_p, A.c_double_p, A.c_u8_p]
     L.msfm_reproject_mse_batch.argtypes = [vp, C.POINTER(A.Tracks), A.c_double_p, A.c_double_p]
     L.msfm_epipolar_filter.argtypes = [vp, A.c_float_p, A.c_float_p, i, A.c_double_p, d, A.c_u8_p]
+    L.msfm_fransac_default_options.argtypes = [C.POINTER(A.FransacOptions)]
+    L.msfm_fransac_default_options.restype = None
+    L.msfm_fundamental_ransac_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, C.POINTER(A.FransacOptions),
+                                                A.c_double_p, A.c_u8_p, A.c_int_p, A.c_u8_p]
+    L.msfm_epipolar_filter_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, A.c_double_p, A.c_u8_p, d, A.c_u8_p]
     _lib = L
     return L
 
@@ -87,6 +93,16 @@ def lib():
 def default_options(**kw):
     o = A.BaOptions()
     lib().msfm_ba_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def fransac_options(**kw):
+    o = A.FransacOptions()
+    lib().msfm_fransac_default_options(C.byref(o))
     for k, v in kw.items():
         if not hasattr(o, k):
             raise AttributeError(k)
@@ -216,6 +232,36 @@ class Context:
         self.check(lib().msfm_epipolar_filter(self._h, A.ptr(pt1, A.c_float_p), A.ptr(pt2, A.c_float_p), len(pt1),
                                               A.ptr(F, A.c_double_p), th, A.ptr(out, A.c_u8_p)))
         return out
+
+    def fundamental_ransac(self, offsets, pt1, pt2, **opts):
+        """GeoVerification::GeoVerificationFundamental for a batch of pairs (geo_verification.cc:30-58).
+        offsets[n_pairs+1] delimit each pair's matches in pt1/pt2 (float32 [total][2]).
+        Returns F [n_pairs][3][3], inlier mask [total], n_inliers [n_pairs], ok [n_pairs]."""
+        offsets = A.as_c(offsets, np.int32)
+        pt1, pt2 = A.as_c(np.asarray(pt1, dtype=np.float32).reshape(-1, 2), np.float32), A.as_c(np.asarray(pt2, dtype=np.float32).reshape(-1, 2), np.float32)
+        n_pairs = len(offsets) - 1
+        o = fransac_options(**opts)
+        F = np.zeros((n_pairs, 3, 3), dtype=np.float64)
+        inl = np.zeros(max(1, len(pt1)), dtype=np.uint8)
+        nin = np.zeros(max(1, n_pairs), dtype=np.int32)
+        ok = np.zeros(max(1, n_pairs), dtype=np.uint8)
+        self.check(lib().msfm_fundamental_ransac_batch(self._h, n_pairs, A.ptr(offsets, A.c_int_p), A.ptr(pt1, A.c_float_p),
+                                                       A.ptr(pt2, A.c_float_p), C.byref(o), A.ptr(F, A.c_double_p),
+                                                       A.ptr(inl, A.c_u8_p), A.ptr(nin, A.c_int_p), A.ptr(ok, A.c_u8_p)))
+        return F, inl[:len(pt1)], nin[:n_pairs], ok[:n_pairs]
+
+    def epipolar_filter_batch(self, offsets, pt1, pt2, F, ok=None, th=3.0):
+        offsets = A.as_c(offsets, np.int32)
+        pt1, pt2 = A.as_c(np.asarray(pt1, dtype=np.float32).reshape(-1, 2), np.float32), A.as_c(np.asarray(pt2, dtype=np.float32).reshape(-1, 2), np.float32)
+        F = A.as_c(np.asarray(F, dtype=np.float64).reshape(-1, 9), np.float64)
+        okp = None
+        if ok is not None:
+            ok = A.as_c(ok, np.uint8)
+            okp = A.ptr(ok, A.c_u8_p)
+        out = np.zeros(max(1, len(pt1)), dtype=np.uint8)
+        self.check(lib().msfm_epipolar_filter_batch(self._h, len(offsets) - 1, A.ptr(offsets, A.c_int_p), A.ptr(pt1, A.c_float_p),
+                                                    A.ptr(pt2, A.c_float_p), A.ptr(F, A.c_double_p), okp, th, A.ptr(out, A.c_u8_p)))
+        return out[:len(pt1)]
 
 
 class DescSet:

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <array>
 #include <vector>
 
 #include "../include/msfm.h"
@@ -1057,6 +1058,206 @@ ORC_API int orc_epipolar_filter(const float* pt1, const float* pt2, int n, const
   }
   return MSFM_OK;
 }
+
+// =====================================================================================
+// GeoVerification::GeoVerificationFundamental, geo_verification.cc:30-58:
+//   cv::findFundamentalMat(pt1, pt2, status, cv::FM_RANSAC, 3.0), then "fewer than 30 inliers -> false".
+// OpenCV 2.4 is not in the tree; its FM_RANSAC is restated from the published algorithm
+// (CvFMEstimator::run7Point / computeReprojError / CvModelEstimator2::runRANSAC / cvRANSACUpdateNumIters):
+// a plain SEQUENTIAL loop here — draw 7 matches, solve, score every model, keep the best, shrink the
+// iteration budget.  OpenCV's own random stream cannot be reproduced, so the sampler is the counter-based
+// one documented in DESIGN.md (sample h of pair p depends only on (seed, p, h)).  Contraction is off in
+// this section so that the arithmetic is the same sequence of IEEE operations everywhere.
+// =====================================================================================
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
+namespace fr {
+static uint64_t next64(uint64_t& s) {
+  s += 0x9E3779B97F4A7C15ull;
+  uint64_t z = s;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static double det3(const double* m) {
+  return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+static void cofactors(const double* m, double* c) {
+  c[0] = m[4] * m[8] - m[5] * m[7];    c[1] = -(m[3] * m[8] - m[5] * m[6]); c[2] = m[3] * m[7] - m[4] * m[6];
+  c[3] = -(m[1] * m[8] - m[2] * m[7]); c[4] = m[0] * m[8] - m[2] * m[6];    c[5] = -(m[0] * m[7] - m[1] * m[6]);
+  c[6] = m[1] * m[5] - m[2] * m[4];    c[7] = -(m[0] * m[5] - m[2] * m[3]); c[8] = m[0] * m[4] - m[1] * m[3];
+}
+static bool finite(double v) { return std::fabs(v) <= DBL_MAX; }
+// one real root by bisection in the Cauchy bound + 2 Newton steps, the others from the deflated quadratic
+static std::vector<double> cubic_roots(double c3, double c2, double c1, double c0) {
+  std::vector<double> out;
+  const double a = c2 / c3, b = c1 / c3, c = c0 / c3;
+  if (!(finite(a) && finite(b) && finite(c))) {
+    if (c2 != 0.0) {
+      const double p = c1 / c2, q = c0 / c2, disc = p * p - 4.0 * q;
+      if (!(disc >= 0.0)) return out;
+      const double sq = std::sqrt(disc), t = -0.5 * (p + (p >= 0.0 ? sq : -sq));
+      out.push_back(t);
+      if (t != 0.0) out.push_back(q / t);
+    } else if (c1 != 0.0) {
+      out.push_back(-c0 / c1);
+    }
+    return out;
+  }
+  double R = std::fabs(a);
+  if (std::fabs(b) > R) R = std::fabs(b);
+  if (std::fabs(c) > R) R = std::fabs(c);
+  R = 1.0 + R;
+  double lo = -R, hi = R;
+  for (int it = 0; it < 100; it++) {
+    const double mid = 0.5 * (lo + hi);
+    const double f = ((mid + a) * mid + b) * mid + c;
+    if (f <= 0.0) lo = mid; else hi = mid;
+  }
+  double r = 0.5 * (lo + hi);
+  for (int it = 0; it < 2; it++) {
+    const double f = ((r + a) * r + b) * r + c;
+    const double fp = (3.0 * r + 2.0 * a) * r + b;
+    if (fp != 0.0) {
+      const double rn = r - f / fp;
+      if (finite(rn)) r = rn;
+    }
+  }
+  out.push_back(r);
+  const double p = a + r, q = b + r * p, disc = p * p - 4.0 * q;
+  if (disc >= 0.0) {
+    const double sq = std::sqrt(disc), t = -0.5 * (p + (p >= 0.0 ? sq : -sq));
+    out.push_back(t);
+    if (t != 0.0) out.push_back(q / t);
+  }
+  return out;
+}
+// models of sample h of pair `pair`
+static std::vector<std::array<double, 9>> seven_point(uint64_t seed, int pair, int h, int N, const float* p1, const float* p2) {
+  std::vector<std::array<double, 9>> models;
+  uint64_t s = seed ^ ((uint64_t)pair * 0xD1342543DE82EF95ull) ^ ((uint64_t)h * 0xA24BAED4963EE407ull);
+  int pick[7];
+  for (int k = 0; k < 7; k++) {
+    for (;;) {
+      const int v = (int)(next64(s) % (uint64_t)N);
+      bool dup = false;
+      for (int j = 0; j < k; j++) dup = dup || pick[j] == v;
+      if (!dup) { pick[k] = v; break; }
+    }
+  }
+  double A[7][9];
+  for (int k = 0; k < 7; k++) {
+    const double x1 = p1[2 * pick[k]], y1 = p1[2 * pick[k] + 1], x2 = p2[2 * pick[k]], y2 = p2[2 * pick[k] + 1];
+    const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+    for (int c = 0; c < 9; c++) A[k][c] = row[c];
+  }
+  int perm[9];
+  for (int c = 0; c < 9; c++) perm[c] = c;
+  for (int i = 0; i < 7; i++) {  // Gauss-Jordan, full pivoting, first maximum in row-major order
+    int pr = i, pc = i;
+    double best = -1.0;
+    for (int r = i; r < 7; r++)
+      for (int c = i; c < 9; c++)
+        if (std::fabs(A[r][c]) > best) { best = std::fabs(A[r][c]); pr = r; pc = c; }
+    if (!(best > 0.0)) return models;
+    if (pr != i) for (int c = 0; c < 9; c++) std::swap(A[i][c], A[pr][c]);
+    if (pc != i) { for (int r = 0; r < 7; r++) std::swap(A[r][i], A[r][pc]); std::swap(perm[i], perm[pc]); }
+    const double piv = A[i][i];
+    for (int c = i; c < 9; c++) A[i][c] = A[i][c] / piv;
+    for (int r = 0; r < 7; r++) {
+      if (r == i) continue;
+      const double f = A[r][i];
+      for (int c = i; c < 9; c++) A[r][c] = A[r][c] - f * A[i][c];
+    }
+  }
+  double f1[9], f2[9];
+  for (int j = 0; j < 9; j++) {
+    f1[perm[j]] = j < 7 ? -A[j][7] : (j == 7 ? 1.0 : 0.0);
+    f2[perm[j]] = j < 7 ? -A[j][8] : (j == 8 ? 1.0 : 0.0);
+  }
+  double G[9], cf[9];
+  for (int k = 0; k < 9; k++) G[k] = f1[k] - f2[k];
+  const double c0 = det3(f2), c3 = det3(G);
+  cofactors(f2, cf);
+  double c1 = 0.0;
+  for (int k = 0; k < 9; k++) c1 = c1 + cf[k] * G[k];
+  cofactors(G, cf);
+  double c2 = 0.0;
+  for (int k = 0; k < 9; k++) c2 = c2 + cf[k] * f2[k];
+  for (double lam : cubic_roots(c3, c2, c1, c0)) {
+    std::array<double, 9> F;
+    bool fin = true;
+    for (int k = 0; k < 9; k++) { F[k] = f2[k] + lam * G[k]; fin = fin && finite(F[k]); }
+    if (!fin) continue;
+    const double mu = F[8];
+    if (std::fabs(mu) > DBL_EPSILON) {
+      const double inv = 1.0 / mu;
+      for (int k = 0; k < 9; k++) F[k] = F[k] * inv;
+    }
+    models.push_back(F);
+  }
+  return models;
+}
+static bool is_inlier(const double* F, double x1, double y1, double x2, double y2, double th2) {
+  double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+  const double s2 = 1.0 / (a * a + b * b), d2 = x2 * a + y2 * b + c;
+  a = F[0] * x2 + F[3] * y2 + F[6]; b = F[1] * x2 + F[4] * y2 + F[7]; c = F[2] * x2 + F[5] * y2 + F[8];
+  const double s1 = 1.0 / (a * a + b * b), d1 = x1 * a + y1 * b + c;
+  const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+  return (e1 > e2 ? e1 : e2) <= th2;
+}
+static int update_num_iters(double p, double ep, int model_points, int max_iters) {  // cvRANSACUpdateNumIters
+  p = std::min(std::max(p, 0.0), 1.0);
+  ep = std::min(std::max(ep, 0.0), 1.0);
+  double num = std::max(1.0 - p, DBL_MIN);
+  double denom = 1.0 - std::pow(1.0 - ep, model_points);
+  if (denom < DBL_MIN) return 0;
+  num = std::log(num);
+  denom = std::log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+}  // namespace fr
+
+ORC_API int orc_fundamental_ransac(int n_pairs, const int* off, const float* pt1, const float* pt2, double threshold,
+                                   double confidence, int max_iterations, int min_points, int min_inliers, uint64_t seed,
+                                   double* Fout, uint8_t* inlier, int* n_inliers, uint8_t* ok) {
+  const double th2 = threshold * threshold;
+  for (int p = 0; p < n_pairs; p++) {
+    const int o = off[p], N = off[p + 1] - o;
+    const float* a = pt1 + 2 * (size_t)o;
+    const float* b = pt2 + 2 * (size_t)o;
+    for (int k = 0; k < 9; k++) Fout[9 * (size_t)p + k] = 0.0;
+    for (int e = 0; e < N; e++) inlier[o + e] = 0;
+    n_inliers[p] = 0;
+    ok[p] = 0;
+    if (N < min_points || N < 8) continue;  // pt1.size() < 30 -> return false
+    int niters = max_iterations, best = 6;  // maxGoodCount starts below modelPoints
+    std::array<double, 9> Fbest{};
+    bool have = false;
+    for (int h = 0; h < niters; h++) {
+      for (const auto& F : fr::seven_point(seed, p, h, N, a, b)) {
+        int good = 0;
+        for (int e = 0; e < N; e++) good += fr::is_inlier(F.data(), a[2 * e], a[2 * e + 1], b[2 * e], b[2 * e + 1], th2);
+        if (good > best) {
+          best = good; Fbest = F; have = true;
+          niters = std::min(niters, fr::update_num_iters(confidence, (double)(N - good) / N, 7, max_iterations));
+        }
+      }
+    }
+    if (!have) continue;
+    int c = 0;
+    for (int e = 0; e < N; e++) {
+      const bool in = fr::is_inlier(Fbest.data(), a[2 * e], a[2 * e + 1], b[2 * e], b[2 * e + 1], th2);
+      inlier[o + e] = in;
+      c += in;
+    }
+    for (int k = 0; k < 9; k++) Fout[9 * (size_t)p + k] = Fbest[k];
+    n_inliers[p] = c;
+    ok[p] = c >= min_inliers;
+  }
+  return MSFM_OK;
+}
+#pragma GCC pop_options
 
 // =====================================================================================
 // Matching — exact brute-force 2-NN on squared L2 (the quantity FLANN's L2 functor

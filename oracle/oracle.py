@@ -159,6 +159,27 @@ def epipolar_filter(pt1, pt2, F, th=3.0):
     return out
 
 
+def fundamental_ransac(offsets, pt1, pt2, threshold=3.0, confidence=0.99, max_iterations=2000, min_points=30, min_inliers=30,
+                       seed=0x4D53464D46):
+    """Sequential restatement of cv::findFundamentalMat(FM_RANSAC, 3.0) + the 30-inlier gate (geo_verification.cc:30-58)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    pt1 = np.ascontiguousarray(np.asarray(pt1, dtype=np.float32).reshape(-1, 2))
+    pt2 = np.ascontiguousarray(np.asarray(pt2, dtype=np.float32).reshape(-1, 2))
+    n = len(offsets) - 1
+    F = np.zeros((n, 3, 3), dtype=np.float64)
+    inl = np.zeros(max(1, len(pt1)), dtype=np.uint8)
+    nin = np.zeros(max(1, n), dtype=np.int32)
+    ok = np.zeros(max(1, n), dtype=np.uint8)
+    f = lib().orc_fundamental_ransac
+    f.argtypes = [C.c_int, A.c_int_p, A.c_float_p, A.c_float_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                  A.c_double_p, A.c_u8_p, A.c_int_p, A.c_u8_p]
+    rc = f(n, A.ptr(offsets, A.c_int_p), A.ptr(pt1, A.c_float_p), A.ptr(pt2, A.c_float_p), threshold, confidence, max_iterations,
+           min_points, min_inliers, seed, A.ptr(F, A.c_double_p), A.ptr(inl, A.c_u8_p), A.ptr(nin, A.c_int_p), A.ptr(ok, A.c_u8_p))
+    if rc != 0:
+        raise ValueError("orc_fundamental_ransac rc=%d" % rc)
+    return F, inl[:len(pt1)], nin[:n], ok[:n]
+
+
 def knn2(train, query, fast=False):
     train, query = np.ascontiguousarray(train, dtype=np.float32), np.ascontiguousarray(query, dtype=np.float32)
     ids = np.zeros((len(query), 2), dtype=np.int32)

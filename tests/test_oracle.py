@@ -190,3 +190,42 @@ def test_golden_vectors(oracle):
     np.testing.assert_array_equal(ok, t["ok_mid"])
     X, mse, ok = oracle.triangulate_dlt(tr, 3.0, float(t["th_angle"]))
     np.testing.assert_allclose(X, t["X_dlt"], rtol=1e-10, atol=1e-10)
+
+
+# ---- geometric verification: FM_RANSAC restatement ----
+def test_fundamental_ransac_recovers_two_view_geometry(oracle):
+    O = oracle
+    from tests.twoview import make_batch
+    sizes = [400, 60, 29, 0, 1500]
+    off, p1, p2, good = make_batch(11, sizes, outlier_frac=0.35)
+    F, inl, nin, ok = O.fundamental_ransac(off, p1, p2)
+    assert list(ok) == [1, 1, 0, 0, 1]          # < 30 points -> false (geo_verification.cc:34)
+    assert nin[2] == 0 and not inl[off[2]:off[3]].any() and not F[2].any()
+    for p in (0, 1, 4):
+        s = slice(off[p], off[p + 1])
+        g = good[s]
+        # nearly every true correspondence is kept and nearly every gross outlier rejected
+        assert inl[s][g].mean() > 0.9
+        assert inl[s][~g].mean() < 0.1
+        assert nin[p] == inl[s].sum()
+        assert abs(np.linalg.det(F[p])) < 1e-6 * np.abs(F[p]).max() ** 3 + 1e-12   # rank 2
+        # the closed-form filter of geo_verification.cc:60-79 agrees with the RANSAC mask up to its one-sided error
+        one_sided = O.epipolar_filter(p1[s], p2[s], F[p], 3.0)
+        assert (one_sided >= inl[s]).all()
+
+
+def test_fundamental_ransac_gates_and_determinism(oracle):
+    O = oracle
+    from tests.twoview import make_batch
+    # 40 matches but only ~20 consistent ones: a model is found, the 30-inlier gate says no (geo_verification.cc:54-56)
+    off, p1, p2, good = make_batch(5, [40], outlier_frac=0.5)
+    F, inl, nin, ok = O.fundamental_ransac(off, p1, p2)
+    assert ok[0] == 0 and 7 <= nin[0] < 30 and F[0].any()
+    F2, inl2, nin2, ok2 = O.fundamental_ransac(off, p1, p2)
+    assert (F == F2).all() and (inl == inl2).all()
+    F3, inl3, _, _ = O.fundamental_ransac(off, p1, p2, seed=99)
+    assert not (F == F3).all()
+    # degenerate input: every match identical -> no model, no crash
+    z1 = np.ones((50, 2), np.float32)
+    Fz, inz, nz, okz = O.fundamental_ransac(np.array([0, 50], np.int32), z1, z1)
+    assert okz[0] == 0 and nz[0] == 0 and not Fz.any()
