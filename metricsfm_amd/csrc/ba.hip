@@ -106,13 +106,12 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, double* __restrict_
         P.lin_Jp[(size_t)(3 + j) * A + i] = spj * J[12 + 9 + j];
       }
       if (cp >= 0) {
-        double* row = P.camrow + 20 * (size_t)cp;
+        double2* row = reinterpret_cast<double2*>(P.camrow + 20 * (size_t)cp);  // 160-byte rows: ten 16-byte stores
 #pragma unroll
-        for (int j = 0; j < 12; j++) row[j] = jc[j];
+        for (int j = 0; j < 6; j++) row[j] = make_double2(jc[2 * j], jc[2 * j + 1]);
 #pragma unroll
-        for (int j = 0; j < 6; j++) row[12 + j] = jm[j];
-        row[18] = r0;
-        row[19] = r1;
+        for (int j = 0; j < 3; j++) row[6 + j] = make_double2(jm[2 * j], jm[2 * j + 1]);
+        row[9] = make_double2(r0, r1);
       }
     }
   }
@@ -281,10 +280,9 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
             a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
             b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
           }
-          double T[18], jc[12];
+          double T[18], jc[12], tu[6];
 #pragma unroll
           for (int a = 0; a < 12; a++) jc[a] = P.lin_Jc[(size_t)a * A + i];  // all loads before the first use
-          double* Tu = P.Tu + 6 * (size_t)cp;
 #pragma unroll
           for (int a = 0; a < 6; a++) {
             const double ja = jc[a], jb = jc[6 + a];
@@ -293,8 +291,11 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
             const double t1 = (w1 - l10 * t0) * i11;
             const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
             T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
-            Tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+            tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
           }
+          double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cp);
+#pragma unroll
+          for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
           double2* To = reinterpret_cast<double2*>(P.T + 18 * (size_t)cp);  // camera-major: the pair kernel's gathers stay inside one camera's segment
 #pragma unroll
           for (int k = 0; k < 9; k++) To[k] = make_double2(T[2 * k], T[2 * k + 1]);
@@ -368,13 +369,17 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
 #pragma unroll
   for (int k = 0; k < 78; k++) acc[k] = 0.0;
   for (int e = ch_start[chunk] + lane; e < ch_end[chunk]; e += 64) {
-    const double* row = camrow + 20 * (size_t)e;
+    // rows are 160 bytes and 16-byte aligned: ten 16-byte loads instead of twenty 8-byte ones
+    const double2* row2 = reinterpret_cast<const double2*>(camrow + 20 * (size_t)e);
+    double rw[20];
+#pragma unroll
+    for (int k = 0; k < 10; k++) { const double2 t = row2[k]; rw[2 * k] = t.x; rw[2 * k + 1] = t.y; }
     double jc[12], jm[6];
 #pragma unroll
-    for (int k = 0; k < 12; k++) jc[k] = row[k];
+    for (int k = 0; k < 12; k++) jc[k] = rw[k];
 #pragma unroll
-    for (int k = 0; k < 6; k++) jm[k] = row[12 + k];
-    const double r0 = row[18], r1 = row[19];
+    for (int k = 0; k < 6; k++) jm[k] = rw[12 + k];
+    const double r0 = rw[18], r1 = rw[19];
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -390,8 +395,9 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
       acc[F_JMR + a] += jm[a] * r0 + jm[3 + a] * r1;
     }
     if (cpos_pb[e] >= 0) {
+      const double2* tu2 = reinterpret_cast<const double2*>(Tu + 6 * (size_t)e);
 #pragma unroll
-      for (int a = 0; a < 6; a++) acc[F_TU + a] += Tu[6 * (size_t)e + a];
+      for (int a = 0; a < 3; a++) { const double2 t = tu2[a]; acc[F_TU + 2 * a] += t.x; acc[F_TU + 2 * a + 1] += t.y; }
     }
   }
   wave_reduce_store<78>(acc, partial + (size_t)chunk * PSTRIDE, lane);
