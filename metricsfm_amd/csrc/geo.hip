@@ -203,15 +203,20 @@ __device__ static inline bool geo_inlier(const double* F, double x1, double y1, 
   return err <= th2;  // false for NaN
 }
 
-// grid (ceil(H / 64), n_pairs): thread = sample h of pair blockIdx.y.  counts[pair][h][3].
-__global__ __launch_bounds__(GEO_WAVE) void k_fransac_score(int H, int pair0, const int* __restrict__ off, const float2* __restrict__ pt1,
-                                                             const float2* __restrict__ pt2, uint64_t seed, double th2,
-                                                             int min_points, int* __restrict__ counts) {
+// grid (ceil((h1 - h0) / 64), n_pairs): thread = sample h in [h0, h1) of pair blockIdx.y.  counts[pair][h][3].
+// need != nullptr: only pairs flagged by the first selection pass are scored.
+__global__ __launch_bounds__(GEO_WAVE) void k_fransac_score(int H, int h0, int h1, int pair0, const int* __restrict__ off,
+                                                             const float2* __restrict__ pt1, const float2* __restrict__ pt2, uint64_t seed,
+                                                             double th2, int min_points, const uint8_t* __restrict__ need,
+                                                             int* __restrict__ counts) {
   __shared__ double A[63 * GEO_WAVE];
   __shared__ float4 pts[1024];
-  const int pair = pair0 + blockIdx.y, h = blockIdx.x * GEO_WAVE + threadIdx.x;
+  const int pair = pair0 + blockIdx.y, h = h0 + blockIdx.x * GEO_WAVE + threadIdx.x;
   const int o = off[pair], N = off[pair + 1] - o;
   if (N < min_points || N < 8) return;  // GeoVerificationFundamental: pt1.size() < 30 -> false (uniform per block)
+  if (need && !need[pair]) return;
+  const int Hstride = H;
+  H = h1;  // samples of this launch end here
   GeoModels m;
   m.n = 0;
   if (h < H) geo_solve7(seed, pair, h, N, pt1 + o, pt2 + o, A + threadIdx.x, GEO_WAVE, m);
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(GEO_WAVE) void k_fransac_score(int H, int pair0, co
     }
   }
   if (h < H) {
-    int* c = counts + ((size_t)pair * H + h) * 3;
+    int* c = counts + ((size_t)pair * Hstride + h) * 3;
     c[0] = m.n > 0 ? cnt[0] : -1;
     c[1] = m.n > 1 ? cnt[1] : -1;
     c[2] = m.n > 2 ? cnt[2] : -1;
@@ -241,7 +246,10 @@ __global__ __launch_bounds__(GEO_WAVE) void k_fransac_score(int H, int pair0, co
 // One wave per pair: replay OpenCV's sequential loop over the counts (niters shrinks whenever a
 // better model appears: cvRANSACUpdateNumIters, tabulated on the host as R[g] per pair), recompute
 // the winning model, write F, the inlier mask and the verdict of GeoVerificationFundamental.
-__global__ __launch_bounds__(GEO_WAVE) void k_fransac_select(int H, const int* __restrict__ off, const float2* __restrict__ pt1,
+// Two passes: pass 1 replays the first Hscan samples only; pairs whose budget is still larger than
+// Hscan are flagged in `need` (and finished by pass 2 over all H samples), the others are final.
+__global__ __launch_bounds__(GEO_WAVE) void k_fransac_select(int H, int Hscan, int pass, uint8_t* __restrict__ need,
+                                                              const int* __restrict__ off, const float2* __restrict__ pt1,
                                                               const float2* __restrict__ pt2, uint64_t seed, double th2,
                                                               int min_points, int min_inliers, const int* __restrict__ counts,
                                                               const int* __restrict__ niters_tab, double* __restrict__ Fout,
@@ -253,14 +261,15 @@ __global__ __launch_bounds__(GEO_WAVE) void k_fransac_select(int H, const int* _
   __shared__ int cl[3 * 1024];
   const int pair = blockIdx.x, lane = threadIdx.x;
   const int o = off[pair], N = off[pair + 1] - o;
+  if (pass == 2 && !need[pair]) return;
   if (lane == 0) { win[0] = -1; win[1] = 0; win[2] = H; }
   if (N >= min_points && N >= 8) {
     const int* R = niters_tab + o + pair;  // N + 1 entries
     int best = 6;                          // a model must beat modelPoints - 1
-    for (int h0 = 0; h0 < H; h0 += 1024) {
+    for (int h0 = 0; h0 < Hscan; h0 += 1024) {
       __syncthreads();
       if (h0 >= win[2]) break;  // uniform: win[2] is shared
-      const int nh = min(1024, H - h0);
+      const int nh = min(1024, Hscan - h0);
       for (int e = lane; e < 3 * nh; e += GEO_WAVE) cl[e] = counts[((size_t)pair * H + h0) * 3 + e];
       __syncthreads();
       if (lane == 0) {
@@ -279,6 +288,11 @@ __global__ __launch_bounds__(GEO_WAVE) void k_fransac_select(int H, const int* _
     }
   }
   __syncthreads();
+  if (pass == 1) {
+    const bool more = N >= min_points && N >= 8 && win[2] > Hscan && Hscan < H;  // the sequential loop would have gone on past Hscan
+    if (lane == 0) need[pair] = more ? 1 : 0;
+    if (more) return;
+  }
   const int wh = win[0];
   if (wh < 0) {
     for (int e = lane; e < N; e += GEO_WAVE) inlier[o + e] = 0;
@@ -391,22 +405,31 @@ MSFM_API int msfm_fundamental_ransac_batch(msfm_ctx* ctx, int n_pairs, const int
   HIP_TRY(ctx, d_nin.alloc(n_pairs));
   HIP_TRY(ctx, d_ok.alloc(n_pairs));
   const double th2 = opt->threshold * opt->threshold;
-  {
+  // Most pairs stop after a few dozen samples (cvRANSACUpdateNumIters): score the first H1 samples of every pair,
+  // replay them, and run the remaining H - H1 samples only for the pairs whose budget is still open.
+  const int H1 = std::min(H, 128);
+  DevBuf<uint8_t> d_need;
+  HIP_TRY(ctx, d_need.alloc(n_pairs));
+  auto score = [&](int h0, int h1, const uint8_t* need) {
     KTimer t(ctx, "geo_fransac_score");
-    // pairs go in slices of 32768 (grid.y limit 65535)
-    for (int p0 = 0; p0 < n_pairs; p0 += 32768) {
+    for (int p0 = 0; p0 < n_pairs; p0 += 32768) {  // grid.y limit
       const int np = std::min(32768, n_pairs - p0);
-      hipLaunchKernelGGL(k_fransac_score, dim3(cdiv(H, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, H, p0, d_off.p,
+      hipLaunchKernelGGL(k_fransac_score, dim3(cdiv(h1 - h0, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, H, h0, h1, p0, d_off.p,
                          reinterpret_cast<const float2*>(d1.p), reinterpret_cast<const float2*>(d2.p), opt->seed, th2,
-                         opt->min_points, d_counts.p);
+                         opt->min_points, need, d_counts.p);
     }
-  }
-  HIP_TRY(ctx, hipGetLastError());
-  {
+  };
+  auto select = [&](int hscan, int pass) {
     KTimer t(ctx, "geo_fransac_select");
-    hipLaunchKernelGGL(k_fransac_select, dim3(n_pairs), dim3(GEO_WAVE), 0, s, H, d_off.p, reinterpret_cast<const float2*>(d1.p),
-                       reinterpret_cast<const float2*>(d2.p), opt->seed, th2, opt->min_points, opt->min_inliers, d_counts.p, d_tab.p,
-                       dF.p, d_in.p, d_nin.p, d_ok.p);
+    hipLaunchKernelGGL(k_fransac_select, dim3(n_pairs), dim3(GEO_WAVE), 0, s, H, hscan, pass, d_need.p, d_off.p,
+                       reinterpret_cast<const float2*>(d1.p), reinterpret_cast<const float2*>(d2.p), opt->seed, th2, opt->min_points,
+                       opt->min_inliers, d_counts.p, d_tab.p, dF.p, d_in.p, d_nin.p, d_ok.p);
+  };
+  score(0, H1, nullptr);
+  select(H1, 1);
+  if (H1 < H) {
+    score(H1, H, d_need.p);
+    select(H, 2);
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(F, dF.p, sizeof(double) * 9 * (size_t)n_pairs, hipMemcpyDeviceToHost, s));
