@@ -23,7 +23,6 @@
 #include "ba_device.h"
 #include "common.h"
 
-int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* Linv, double* w, double* z, int* fail);
 
 #define PSTRIDE 80   // doubles per FTF partial
 #define CHUNK 1024   // entries per reduction chunk (16 per lane)
@@ -537,7 +536,7 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
 __global__ __launch_bounds__(64) void k_asm_cc(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                                 const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
                                                 const double* __restrict__ camftf, const double* __restrict__ diag_c,
-                                                double radius, double* __restrict__ M, int ld, int lead) {
+                                                double radius, const int* __restrict__ cb_off, double* __restrict__ M, int ld, int lead) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (t >= 36) return;
   const int rb = blk_row[b], cbk = blk_col[b];
@@ -549,14 +548,14 @@ __global__ __launch_bounds__(64) void k_asm_cc(const int* __restrict__ blk_row, 
     v += camftf[(size_t)rb * PSTRIDE + F_JCJC + t];
     if (a == c) { const double q = sqrt(diag_c[6 * rb + a] / radius); v += q * q; }
   }
-  M[(size_t)(6 * rb + a) * ld + 6 * cbk + c] = v;
+  M[(size_t)(cb_off[rb] + a) * ld + cb_off[cbk] + c] = v;
 }
 
 // intrinsics-camera blocks (rows 6*ncb + 3*mb.., cols 6*cb..): 18 used threads.
 __global__ __launch_bounds__(64) void k_asm_mc(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                                 const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
-                                                const double* __restrict__ camftf, const int* __restrict__ cb_mb, int ncb,
-                                                double* __restrict__ M, int ld, int lead) {
+                                                const double* __restrict__ camftf, const int* __restrict__ cb_mb,
+                                                const int* __restrict__ cb_off, int mo, double* __restrict__ M, int ld, int lead) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (t >= 18) return;
   const int mb = blk_row[b], cb = blk_col[b];
@@ -565,7 +564,7 @@ __global__ __launch_bounds__(64) void k_asm_mc(const int* __restrict__ blk_row, 
   double v = -s;
   if (lead && cb_mb[cb] == mb) v += camftf[(size_t)cb * PSTRIDE + F_JMJC + t];
   const int a = t / 6, c = t % 6;
-  M[(size_t)(6 * ncb + 3 * mb + a) * ld + 6 * cb + c] = v;
+  M[(size_t)(mo + 3 * mb + a) * ld + cb_off[cb] + c] = v;
 }
 
 // intrinsics-intrinsics blocks: one wave per block, lanes strided over chunks.
@@ -573,7 +572,7 @@ __global__ __launch_bounds__(64) void k_asm_mc(const int* __restrict__ blk_row, 
 __global__ __launch_bounds__(64) void k_asm_mm(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                                 const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
                                                 const double* __restrict__ modelsum, const double* __restrict__ diag_m, double radius,
-                                                int ncb, int n, double* __restrict__ M, int ld, int lead) {
+                                                int mo, int n, double* __restrict__ M, int ld, int lead) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int rb = blk_row[b], cbk = blk_col[b];
   double acc[12];
@@ -593,24 +592,38 @@ __global__ __launch_bounds__(64) void k_asm_mm(const int* __restrict__ blk_row, 
       v += modelsum[12 * (size_t)rb + lane];
       if (a == c) { const double q = sqrt(diag_m[3 * rb + a] / radius); v += q * q; }
     }
-    M[(size_t)(6 * ncb + 3 * rb + a) * ld + 6 * ncb + 3 * cbk + c] = v;
+    M[(size_t)(mo + 3 * rb + a) * ld + mo + 3 * cbk + c] = v;
   } else if (lane < 12 && rb == cbk) {
     const int a = lane - 9;
     double u = 0.0;
 #pragma unroll
     for (int k = 9; k < 12; k++) if (k == lane) u = acc[k];
-    M[(size_t)n * ld + 6 * ncb + 3 * rb + a] = (lead ? modelsum[12 * (size_t)rb + 9 + a] : 0.0) - u;  // rhs row
+    M[(size_t)n * ld + mo + 3 * rb + a] = (lead ? modelsum[12 * (size_t)rb + 9 + a] : 0.0) - u;  // rhs row
   }
 }
 
 // rhs of the camera columns + intrinsics blocks that have no (point, intrinsics) entries.
 // camftf is already global (summed over ranks), so only the lead rank contributes it.
-__global__ void k_asm_rhs_cam(int ncb, const double* __restrict__ camftf, double* __restrict__ M, int ld, int n, int lead) {
+__global__ void k_asm_rhs_cam(int ncb, const double* __restrict__ camftf, const int* __restrict__ cb_off, double* __restrict__ M, int ld,
+                              int n, int lead) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 6 * ncb) return;
   const int cb = i / 6, a = i % 6;
   const double* f = camftf + (size_t)cb * PSTRIDE;
-  M[(size_t)n * ld + i] = lead ? f[F_JCR + a] - f[F_TU + a] : 0.0;
+  M[(size_t)n * ld + cb_off[cb] + a] = lead ? f[F_JCR + a] - f[F_TU + a] : 0.0;
+}
+
+// identity on the padding columns that align the camera domains to 64 (their solution component is 0)
+__global__ void k_pad_diag(int npadcol, const int* __restrict__ padcol, double* __restrict__ M, int ld) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npadcol) M[(size_t)padcol[i] * ld + padcol[i]] = 1.0;
+}
+
+// solver order (domains, padding, separator, intrinsics) -> block order of the BA kernels
+__global__ void k_gather_z(int ncb, int nmb, const int* __restrict__ cb_off, int mo, const double* __restrict__ zsys, double* __restrict__ z) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * ncb) z[i] = zsys[cb_off[i / 6] + i % 6];
+  else if (i < 6 * ncb + 3 * nmb) z[i] = zsys[mo + (i - 6 * ncb)];
 }
 
 __global__ void k_fail_to_scal(const int* __restrict__ fail, double* __restrict__ scal, int slot) { scal[slot] = (double)*fail; }
@@ -769,11 +782,12 @@ __global__ void k_zero_int(int* p) { *p = 0; }
 // exist on some rank travel (C3: 9335 blocks = 2.7 MB instead of the 72 MB dense square).
 template <bool PACK>
 __global__ __launch_bounds__(256) void k_pack_blocks(int nblk, const int* __restrict__ u_row, const int* __restrict__ u_col,
-                                                      double* __restrict__ M, int ld, double* __restrict__ pack) {
+                                                      const int* __restrict__ cb_off, double* __restrict__ M, int ld,
+                                                      double* __restrict__ pack) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= nblk * 36) return;
   const int b = e / 36, t = e - 36 * b;
-  const size_t at = (size_t)(6 * u_row[b] + t / 6) * ld + 6 * u_col[b] + t % 6;
+  const size_t at = (size_t)(cb_off[u_row[b]] + t / 6) * ld + cb_off[u_col[b]] + t % 6;
   if (PACK) pack[e] = M[at];
   else M[at] = pack[e];
 }
@@ -792,6 +806,11 @@ struct msfm_ba {
   msfm_ctx* ctx = nullptr;
   int Nc = 0, Nm = 0, Np = 0;
   int ncb = 0, nmb = 0, npb = 0, nred = 0, npad = 0;
+  // solver layout of the reduced system: camera block cb at column cb_off[cb], intrinsics at mo + 3 mb, order nsys
+  int nsys = 0, mo = 0, n_padcol = 0;
+  msfm_chol_plan plan;
+  DevBuf<int> cb_off, padcol;
+  DevBuf<double> zsys, corners;
   int A = 0, AE = 0, NCR = 0, NPM = 0;
   bool has_gps = false;
   double gps_weight = 0;
@@ -827,6 +846,143 @@ struct msfm_ba {
   DevBuf<int> u_row, u_col;
   DevBuf<double> pack;
 };
+
+// --------------------------------------------------------------------------------------
+// Elimination order of the camera blocks.  Two cameras are coupled in S when they observe a common
+// eliminated point.  If the camera graph falls apart into K domains once a separator is removed, the
+// K domains can be factored concurrently (chol.hip, PanelJobs) and only the separator remains a
+// single chain.  Nested bisection by BFS level sets from a pseudo-peripheral node (George-Liu):
+// deterministic, O(edges) per cut.  Output: label per graph node, 0..K-1 = domain, -1 = separator.
+// --------------------------------------------------------------------------------------
+struct CamGraph {
+  int n = 0;
+  std::vector<std::vector<int>> adj;
+};
+
+static void graph_levels(const CamGraph& G, const std::vector<char>& in, int start, std::vector<int>& lev) {
+  std::fill(lev.begin(), lev.end(), -1);
+  std::vector<int> q{start}, nq;
+  lev[start] = 0;
+  while (!q.empty()) {
+    nq.clear();
+    for (int u : q)
+      for (int v : G.adj[u])
+        if (in[v] && lev[v] < 0) { lev[v] = lev[u] + 1; nq.push_back(v); }
+    q.swap(nq);
+  }
+}
+
+// Splits the node set `in` into a, b, sep (no edge between a and b).  Nodes are ordered by the
+// difference of their hop distances to two far-apart nodes s and t; a prefix of that order is side a,
+// the rest side b, and the separator is the smaller of the two one-hop boundaries.  (Level sets of the
+// distance to ONE node give L-shaped cuts on grid-like camera graphs; the difference gives the
+// straight bisector.)  Among a few cut positions around the median the one with the smallest
+// max(|a|, |b|) + |sep| wins.  false when the set cannot be split.
+static bool graph_bisect(const CamGraph& G, const std::vector<char>& in, std::vector<char>& a, std::vector<char>& b, std::vector<char>& sep) {
+  const int n = G.n;
+  int start = -1, total = 0;
+  for (int i = 0; i < n; i++) if (in[i]) { if (start < 0) start = i; total++; }
+  if (total < 3) return false;
+  std::vector<int> ls(n), lt(n);
+  for (int it = 0; it < 4; it++) {  // pseudo-peripheral node: walk to the farthest node a few times
+    graph_levels(G, in, start, ls);
+    int far = start;
+    for (int i = 0; i < n; i++) if (in[i] && ls[i] > ls[far]) far = i;
+    if (far == start) break;
+    start = far;
+  }
+  graph_levels(G, in, start, ls);
+  int t = start, unreached = 0;
+  for (int i = 0; i < n; i++) if (in[i]) { if (ls[i] < 0) unreached++; else if (ls[i] > ls[t]) t = i; }
+  if (unreached) {
+    // disconnected: the reached component and the rest need no separator at all
+    a.assign(n, 0); b.assign(n, 0); sep.assign(n, 0);
+    for (int i = 0; i < n; i++) if (in[i]) (ls[i] >= 0 ? a : b)[i] = 1;
+    return true;
+  }
+  if (t == start) return false;
+  graph_levels(G, in, t, lt);
+  std::vector<int> order;
+  for (int i = 0; i < n; i++) if (in[i]) order.push_back(i);
+  std::sort(order.begin(), order.end(), [&](int x, int y) {
+    const int kx = ls[x] - lt[x], ky = ls[y] - lt[y];
+    if (kx != ky) return kx < ky;
+    if (ls[x] != ls[y]) return ls[x] < ls[y];
+    return x < y;
+  });
+  long best = -1;
+  std::vector<char> ca, cb, cs;
+  for (int pct = 40; pct <= 60; pct += 5) {
+    const int m = std::max(1, std::min(total - 1, (int)((long)total * pct / 100)));
+    ca.assign(n, 0); cb.assign(n, 0); cs.assign(n, 0);
+    for (int k = 0; k < total; k++) (k < m ? ca : cb)[order[k]] = 1;
+    int ba_ = 0, bb_ = 0;  // one-hop boundaries
+    for (int i : order) {
+      bool touch = false;
+      for (int v : G.adj[i]) touch = touch || (ca[i] ? cb[v] : ca[v]);
+      if (touch) (ca[i] ? ba_ : bb_)++;
+    }
+    const bool from_a = ba_ <= bb_;
+    for (int i : order) {
+      if ((ca[i] != 0) != from_a) continue;
+      bool touch = false;
+      for (int v : G.adj[i]) touch = touch || (from_a ? cb[v] : ca[v]);
+      if (touch) cs[i] = 1;
+    }
+    for (int i : order) if (cs[i]) { ca[i] = 0; cb[i] = 0; }
+    // thin the separator: a separator node without a neighbour on one side belongs to the other side
+    for (int i : order) {
+      if (!cs[i]) continue;
+      bool ta = false, tb = false;
+      for (int v : G.adj[i]) { ta = ta || ca[v]; tb = tb || cb[v]; }
+      if (!tb) { cs[i] = 0; ca[i] = 1; }
+      else if (!ta) { cs[i] = 0; cb[i] = 1; }
+    }
+    int na = 0, nb = 0, nsep = 0;
+    for (int i : order) { na += ca[i]; nb += cb[i]; nsep += cs[i]; }
+    if (na == 0 || nb == 0) continue;
+    const long cost = (long)std::max(na, nb) + nsep;
+    if (best < 0 || cost < best) { best = cost; a = ca; b = cb; sep = cs; }
+  }
+  return best >= 0;
+}
+
+static void graph_split(const CamGraph& G, const std::vector<char>& in, int depth, std::vector<std::vector<char>>& doms, std::vector<char>& sep) {
+  std::vector<char> a, b, s;
+  if (depth == 0 || !graph_bisect(G, in, a, b, s)) { doms.push_back(in); return; }
+  for (int i = 0; i < G.n; i++) if (s[i]) sep[i] = 1;
+  graph_split(G, a, depth - 1, doms, sep);
+  graph_split(G, b, depth - 1, doms, sep);
+}
+
+// label[i]: domain 0..K-1 or -1 (separator).  Chooses the depth (0..3) with the shortest estimated chain of
+// 64-column panels, max_k ceil(6 |D_k| / 64) + ceil((6 |S| + tail) / 64); K = 1 means "keep the dense order".
+static int partition_cameras(const CamGraph& G, int tail_cols, int force_depth, std::vector<int>& label) {
+  const int n = G.n;
+  label.assign(n, 0);
+  int bestK = 1;
+  long best = cdiv(6L * n + tail_cols, 64);
+  const long dense = best;
+  for (int depth = 1; depth <= 3; depth++) {
+    if (force_depth >= 0 && depth != force_depth) continue;
+    std::vector<std::vector<char>> doms;
+    std::vector<char> sep(n, 0), all(n, 1);
+    graph_split(G, all, depth, doms, sep);
+    if (doms.size() < 2 || doms.size() > 8) continue;
+    long maxp = 0, nsep = 0;
+    for (auto& d : doms) { long c = 0; for (int i = 0; i < n; i++) c += d[i]; maxp = std::max<long>(maxp, cdiv(6 * c, 64)); }
+    for (int i = 0; i < n; i++) nsep += sep[i];
+    const long chain = maxp + 1 + cdiv(6 * nsep + tail_cols, 64);
+    if (force_depth >= 0 || (chain < best && chain * 10 <= dense * 8)) {  // worth it only if clearly shorter
+      best = chain;
+      bestK = (int)doms.size();
+      for (int i = 0; i < n; i++) label[i] = -1;
+      for (int k = 0; k < bestK; k++)
+        for (int i = 0; i < n; i++) if (doms[k][i]) label[i] = k;
+    }
+  }
+  return bestK;
+}
 
 static bool is_mut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
 
@@ -931,13 +1087,88 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
       // rank's shard observes it
       for (int c = 0; c < Nc; c++) if (is_mut(P->cam_mutable, c)) { cu[c] = 1; if (is_mut(P->model_mutable, P->cam_model_of_cam[c])) mu[P->cam_model_of_cam[c]] = 1; }
     }
-    for (int c = 0; c < Nc; c++) if (cu[c]) { cam_slot[c] = ba->ncb++; ba->h_cb_cam.push_back(c); }
     for (int m = 0; m < Nm; m++) if (mu[m]) { model_slot[m] = ba->nmb++; ba->h_mb_model.push_back(m); }
     for (int p = 0; p < Np; p++) if (pu[p]) { pt_slot[p] = ba->npb++; ba->h_pb_pt.push_back(p); }
+    // ---- elimination order of the camera blocks (see partition_cameras) ----
+    std::vector<int> gnode(Nc, -1), gcam;
+    for (int c = 0; c < Nc; c++) if (cu[c]) { gnode[c] = (int)gcam.size(); gcam.push_back(c); }
+    const int ng = (int)gcam.size();
+    std::vector<int> label(ng, 0);
+    int K = 1;
+    const char* env = getenv("MSFM_CHOL_DOMAINS");  // "0": dense order, "1".."3": force that bisection depth
+    const int force = env ? atoi(env) : -1;
+    if (ng >= 128 && ng <= 4096 && force != 0) {
+      // adjacency as a 0/1 matrix: cameras sharing an eliminated point; max-reduced over the ranks' shards
+      std::vector<double> adjm((size_t)ng * ng, 0.0);
+      std::vector<int> run;
+      for (int o = 0; o < No;) {
+        const int p = P->obs_pt[o];
+        run.clear();
+        int e = o;
+        for (; e < No && P->obs_pt[e] == p; e++)
+          if (gnode[P->obs_cam[e]] >= 0) run.push_back(gnode[P->obs_cam[e]]);
+        if (is_mut(P->pt_mutable, p))
+          for (int a : run) for (int b : run) if (a != b) adjm[(size_t)a * ng + b] = 1.0;
+        o = e;
+      }
+      if (ctx->world > 1) {
+        DevBuf<double> dadj;
+        HIP_TRY(ctx, dadj.from(adjm, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        const int rc = ctx->allreduce(ctx->allreduce_user, dadj.p, adjm.size(), MSFM_REDUCE_MAX, (void*)s);
+        if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce hook failed: %d", rc);
+        HIP_TRY(ctx, hipMemcpyAsync(adjm.data(), dadj.p, sizeof(double) * adjm.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+      }
+      CamGraph G;
+      G.n = ng;
+      G.adj.resize(ng);
+      for (int a = 0; a < ng; a++)
+        for (int b = 0; b < ng; b++) if (adjm[(size_t)a * ng + b] != 0.0) G.adj[a].push_back(b);
+      K = partition_cameras(G, 3 * ba->nmb + 1, force, label);
+      if (getenv("MSFM_VERBOSE") && ctx->rank == 0) {
+        std::vector<int> cnt(K + 1, 0);
+        for (int g = 0; g < ng; g++) cnt[label[g] < 0 ? K : label[g]]++;
+        fprintf(stderr, "msfm: camera graph %d nodes -> %d domain(s):", ng, K);
+        for (int k = 0; k < K; k++) fprintf(stderr, " %d", cnt[k]);
+        fprintf(stderr, "  separator %d\n", K > 1 ? cnt[K] : 0);
+      }
+    }
+    // slots: domain 0, domain 1, ..., separator; inside each group ascending camera index
+    std::vector<int> cb_off_h;
+    int col = 0;
+    std::vector<int> padcol_h;
+    for (int k = 0; k < (K > 1 ? K : 1); k++) {
+      const int begin = col;
+      for (int g = 0; g < ng; g++)
+        if (K <= 1 || label[g] == k) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
+      if (K > 1) {
+        while (col % 64) padcol_h.push_back(col++);  // identity padding up to the next panel boundary
+        ba->plan.dom_begin[k] = begin;
+        ba->plan.dom_end[k] = col;
+      }
+    }
+    if (K > 1) {
+      ba->plan.K = K;
+      ba->plan.sep_begin = col;
+      for (int g = 0; g < ng; g++)
+        if (label[g] < 0) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
+    }
+    ba->mo = col;
+    ba->nsys = col + 3 * ba->nmb;
+    ba->n_padcol = (int)padcol_h.size();
+    HIP_TRY(ctx, ba->cb_off.from(cb_off_h.empty() ? std::vector<int>(1, 0) : cb_off_h, s));
+    HIP_TRY(ctx, ba->padcol.from(padcol_h.empty() ? std::vector<int>(1, 0) : padcol_h, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
   }
   const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
   ba->nred = 6 * ncb + 3 * nmb;
-  ba->npad = 64 * cdiv(ba->nred + 1, 64);
+  ba->npad = 64 * cdiv(ba->nsys + 1, 64);
+  if (ba->plan.K > 1) {
+    ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.sep_begin, 64);
+    HIP_TRY(ctx, ba->corners.alloc((size_t)ba->plan.K * ba->plan.ldc * ba->plan.ldc));
+    ba->plan.corners = ba->corners.p;
+  }
   ba->has_gps = P->gps_xyz != nullptr;
   ba->gps_weight = P->gps_weight;
   // ---- active observations: eliminated-point rows first (point-major), then the rest ----
@@ -1125,7 +1356,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
   AL(ptL, 6 * (size_t)npb); AL(ptg, 3 * (size_t)npb);
   AL(f_partial, (size_t)ba->n_fchunks * PSTRIDE); AL(camftf, (size_t)ncb * PSTRIDE); AL(modelsum, 12 * (size_t)nmb);
-  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad + 8);
+  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad + 8); AL(zsys, ba->npad + 8);
   AL(g_r, 3 * (size_t)ncb); AL(g_J, 3 * (size_t)ncb);
   ba->nblk_obs = cdiv(As, 256);
   ba->nblk_pt = cdiv(std::max(1, npb), 32);  // 8 lanes per point
@@ -1292,14 +1523,14 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     HIP_TRY(ctx, hipMemsetAsync(ba->M.p, 0, sizeof(double) * (size_t)ba->npad * ba->npad, s));
     if (ba->cc.n_blocks)
       hipLaunchKernelGGL(k_asm_cc, dim3(ba->cc.n_blocks), dim3(64), 0, s, ba->cc.blk_row.p, ba->cc.blk_col.p, ba->cc.blk_chunk_first.p,
-                         ba->cc.partial.p, ba->camftf.p, ba->diag_c.p, radius, ba->M.p, ba->npad, lead);
+                         ba->cc.partial.p, ba->camftf.p, ba->diag_c.p, radius, ba->cb_off.p, ba->M.p, ba->npad, lead);
     if (ba->mc.n_blocks)
       hipLaunchKernelGGL(k_asm_mc, dim3(ba->mc.n_blocks), dim3(64), 0, s, ba->mc.blk_row.p, ba->mc.blk_col.p, ba->mc.blk_chunk_first.p,
-                         ba->mc.partial.p, ba->camftf.p, ba->cb_mb.p, ncb, ba->M.p, ba->npad, lead);
+                         ba->mc.partial.p, ba->camftf.p, ba->cb_mb.p, ba->cb_off.p, ba->mo, ba->M.p, ba->npad, lead);
     if (ba->mm.n_blocks)
       hipLaunchKernelGGL(k_asm_mm, dim3(ba->mm.n_blocks), dim3(64), 0, s, ba->mm.blk_row.p, ba->mm.blk_col.p, ba->mm.blk_chunk_first.p,
-                         ba->mm.partial.p, ba->modelsum.p, ba->diag_m.p, radius, ncb, ba->nred, ba->M.p, ba->npad, lead);
-    if (ncb) hipLaunchKernelGGL(k_asm_rhs_cam, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, ncb, ba->camftf.p, ba->M.p, ba->npad, ba->nred, lead);
+                         ba->mm.partial.p, ba->modelsum.p, ba->diag_m.p, radius, ba->mo, ba->nsys, ba->M.p, ba->npad, lead);
+    if (ncb) hipLaunchKernelGGL(k_asm_rhs_cam, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, ncb, ba->camftf.p, ba->cb_off.p, ba->M.p, ba->npad, ba->nsys, lead);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "assemble launch: %s", hipGetErrorString(e));
@@ -1307,15 +1538,17 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     if (ba->n_ublk > 0) {
       // camera-camera blocks packed (union structure), intrinsics rows + rhs row as one dense slab
       const int nb = cdiv(ba->n_ublk * 36, 256);
-      hipLaunchKernelGGL(k_pack_blocks<true>, dim3(nb), dim3(256), 0, s, ba->n_ublk, ba->u_row.p, ba->u_col.p, ba->M.p, ba->npad, ba->pack.p);
+      hipLaunchKernelGGL(k_pack_blocks<true>, dim3(nb), dim3(256), 0, s, ba->n_ublk, ba->u_row.p, ba->u_col.p, ba->cb_off.p, ba->M.p, ba->npad, ba->pack.p);
       MSFM_TRY(allreduce(ba, ba->pack.p, (size_t)ba->n_ublk * 36, MSFM_REDUCE_SUM));
-      MSFM_TRY(allreduce(ba, ba->M.p + (size_t)6 * ncb * ba->npad, (size_t)(ba->nred - 6 * ncb + 1) * ba->npad, MSFM_REDUCE_SUM));
-      hipLaunchKernelGGL(k_pack_blocks<false>, dim3(nb), dim3(256), 0, s, ba->n_ublk, ba->u_row.p, ba->u_col.p, ba->M.p, ba->npad, ba->pack.p);
+      MSFM_TRY(allreduce(ba, ba->M.p + (size_t)ba->mo * ba->npad, (size_t)(ba->nsys - ba->mo + 1) * ba->npad, MSFM_REDUCE_SUM));
+      hipLaunchKernelGGL(k_pack_blocks<false>, dim3(nb), dim3(256), 0, s, ba->n_ublk, ba->u_row.p, ba->u_col.p, ba->cb_off.p, ba->M.p, ba->npad, ba->pack.p);
     } else {
       // rows [0, nred] of M (S and the rhs row) are contiguous: one sum over ranks
-      MSFM_TRY(allreduce(ba, ba->M.p, (size_t)(ba->nred + 1) * ba->npad, MSFM_REDUCE_SUM));
+      MSFM_TRY(allreduce(ba, ba->M.p, (size_t)(ba->nsys + 1) * ba->npad, MSFM_REDUCE_SUM));
     }
   }
+  // identity on the padding columns (after the exchange: they are not part of it)
+  if (ba->n_padcol) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(ba->n_padcol, 256)), dim3(256), 0, s, ba->n_padcol, ba->padcol.p, ba->M.p, ba->npad);
   MSFM_TRY(allreduce(ba, ba->scal.p + S_GMAX, 2, MSFM_REDUCE_MAX));
   return MSFM_OK;
 }
@@ -1337,7 +1570,9 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
   const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
   const bool lead = ctx->rank == 0;
   if (ba->nred > 0) {
-    MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nred, ba->Linv.p, ba->w.p, ba->z.p, ba->fail.p));
+    MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, ba->zsys.p, ba->fail.p,
+                                    ba->plan.K > 1 ? &ba->plan : nullptr));
+    hipLaunchKernelGGL(k_gather_z, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ncb, nmb, ba->cb_off.p, ba->mo, ba->zsys.p, ba->z.p);
     hipLaunchKernelGGL(k_check_finite, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ba->nred, ba->z.p, ba->fail.p);
   }
   {

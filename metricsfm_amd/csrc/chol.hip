@@ -253,6 +253,30 @@ __device__ __forceinline__ void tile_st(double* Ls, int a, int b, int lr, int lk
   for (int i = 0; i < 4; i++) Ls[(16 * a + lk + 4 * i) * LDT + 16 * b + lr] = v[i];
 }
 
+// One launch can carry several independent panel steps ("jobs"): with an elimination order that puts
+// K mutually uncoupled camera domains first and their separator last, the K domain chains advance in
+// the same launch.  A job's rows are two ranges: A = [a0, a0 + 16 na16) (rest of its own domain,
+// starting with the 64 x 64 block to factor) and B = [b0, b0 + 16 nb16) (separator + rhs row); the
+// B x B tiles of its trailing update go to a private corner buffer (summed into M afterwards), so
+// concurrent jobs never write the same tile.  The plain dense factorisation is one job with B empty.
+struct PanelJob {
+  int j0;          // panel to apply, < 0: none (first block of a chain)
+  int t0;          // block to factor, < 0: update only
+  int a0, na16;    // range A, na16 a multiple of 4
+  int b0, nb16;    // range B (nb16 counts the 16-row tiles that carry data)
+  int nrt;         // 16-row tiles that carry data, over A then B
+  int ncw;         // column-0 workgroups
+  int wg0, nwg;    // workgroups [wg0, wg0 + nwg) of the launch
+  int ldc;         // leading dimension of corner
+  double* corner;  // destination of B x B tiles, nullptr: M itself
+};
+struct PanelJobs {
+  int count;
+  PanelJob job[8];
+};
+__device__ __forceinline__ int job_row16(const PanelJob& jb, int rt) { return rt < jb.na16 ? jb.a0 + 16 * rt : jb.b0 + 16 * (rt - jb.na16); }
+__device__ __forceinline__ int job_row64(const PanelJob& jb, int ti) { return 4 * ti < jb.na16 ? jb.a0 + 64 * ti : jb.b0 + 64 * (ti - jb.na16 / 4); }
+
 __device__ __forceinline__ void p0_load(const double* __restrict__ M, int ld, int t0, int j0, int tid, d2 (&pv)[8]) {
 #pragma unroll
   for (int it = 0; it < 8; it++) {
@@ -273,14 +297,13 @@ __device__ __forceinline__ void p0_store(double* Bs, int tid, const d2 (&pv)[8])
 // of barriers (the branch is wave-uniform), so that the register file of a wave holds either the
 // pivot chain's state or a helper's tiles, never both.
 template <bool FULL>
-__device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, int j0, int n, int nrt, double* __restrict__ Dinv,
+__device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const PanelJob& jb, int b, int n, double* __restrict__ Dinv,
                                            double* __restrict__ Ldiag, int* fail, double* Bs, double* Ls, double* dinv, double* dvec) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
+  const int j0 = jb.j0, t0 = jb.t0, nrt = jb.nrt;
   const bool upd = j0 >= 0;
-  const int t0 = j0 + NB;
   const int ncol = min(NB, n - t0);
-  const int b = blockIdx.x;
   if (wave == 0) {
     // ================= pivot-chain wave =================
     d2 pv[8];
@@ -319,7 +342,7 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, int j
     if (upd) p0_load(M, ld, t0, j0, tid, pv);
     const int rt = 4 + 3 * b + wave - 1;
     const bool own = rt < nrt;
-    const size_t r0 = (size_t)t0 + 16 * (own ? rt : 0);
+    const size_t r0 = (size_t)job_row16(jb, own ? rt : 0);
     double preg[16];
     d4 T[4];
     if (own) {
@@ -449,33 +472,51 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, int j
   MSFM_PROBE(10);
 }
 
-// grid: ncw column-0 workgroups, then (for j0 >= 0) the 64x64 tiles (I, J), 1 <= J <= I < nt, of the
-// trailing update  C_IJ -= P_I P_J^T.
+// grid: for every job its column-0 workgroups, then the 64x64 tiles (I, J), jmin <= J <= I < nt, of the
+// trailing update  C_IJ -= P_I P_J^T  (jmin = 1 when the job also factors: the column-0 workgroups own J = 0).
 template <bool FULL>
-__global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld, int j0, int n, int nrt, int ncw, int nt,
-                                                      double* __restrict__ Dinv, double* __restrict__ Ldiag, int* fail) {
+__global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld, int n, double* __restrict__ Dinv,
+                                                      double* __restrict__ Ldiag, int* fail, PanelJobs jobs) {
   // small arrays and the diagonal block first: their uniform-address reads then fit the 16-bit DS offset
   __shared__ double sm[80 + 64 * DV + 2 * 64 * LDT];
   double* As = sm + 80 + 64 * DV;
   double* Bs = As + 64 * LDT;
   const int tid = threadIdx.x;
-  MSFM_PROBE_ARM(j0);
+  int ji = 0;
+  for (int k = 1; k < jobs.count; k++)
+    if ((int)blockIdx.x >= jobs.job[k].wg0) ji = k;
+  const PanelJob& jb = jobs.job[ji];
+  const int bl = blockIdx.x - jb.wg0;
+  MSFM_PROBE_ARM(jb.j0);
   MSFM_PROBE(0);
-  if ((int)blockIdx.x < ncw) {
-    panel_col0<FULL>(M, ld, j0, n, nrt, Dinv, Ldiag, fail, /*Bs=*/Bs, /*Ls=*/As, /*dinv=*/sm + 80, /*dvec=*/sm);
+  if (bl < jb.ncw) {
+    panel_col0<FULL>(M, ld, jb, bl, n, Dinv, Ldiag, fail, /*Bs=*/Bs, /*Ls=*/As, /*dinv=*/sm + 80, /*dvec=*/sm);
     return;
   }
   const int wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
-  const int t0 = j0 + NB;
-  // pairs (I, J) with 1 <= J <= I < nt, enumerated row by row: index q = I(I-1)/2 + (J-1)
-  const int q = blockIdx.x - ncw;
+  const int j0 = jb.j0;
+  // pairs (I, J) with jmin <= J <= I < nt, enumerated row by row (shifted by one when jmin == 0)
+  const int jmin = jb.t0 >= 0 ? 1 : 0;
+  const int q = bl - jb.ncw;
   int I = (int)((sqrt(8.0 * q + 1.0) + 1.0) * 0.5);
   while (I * (I - 1) / 2 > q) I--;
   while ((I + 1) * I / 2 <= q) I++;
-  const int J = q - I * (I - 1) / 2 + 1;
-  const int ri = t0 + I * 64, rj = t0 + J * 64;
+  int J = q - I * (I - 1) / 2 + 1;
+  if (!jmin) { I--; J--; }
+  const int ri = job_row64(jb, I), rj = job_row64(jb, J);
+  // destination of the tile: M, or the job's private corner when both tiles lie in range B
+  const int nA64 = jb.na16 / 4;
+  double* C;
+  int ldC;
+  if (jb.corner && I >= nA64 && J >= nA64) {
+    ldC = jb.ldc;
+    C = jb.corner + (size_t)(64 * (I - nA64)) * ldC + 64 * (J - nA64);
+  } else {
+    ldC = ld;
+    C = M + (size_t)ri * ld + rj;
+  }
   // all loads first: the two panel tiles and this wave's quadrant of C (the accumulators start from it)
   d2 va[8], vb[8];
 #pragma unroll
@@ -488,8 +529,8 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
   d4 acc00, acc01, acc10, acc11;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const double* c0 = &M[(size_t)(ri + qrow + 4 * i) * ld + rj + qcol];
-    const double* c1 = &M[(size_t)(ri + qrow + 16 + 4 * i) * ld + rj + qcol];
+    const double* c0 = &C[(size_t)(qrow + 4 * i) * ldC + qcol];
+    const double* c1 = &C[(size_t)(qrow + 16 + 4 * i) * ldC + qcol];
     acc00[i] = c0[0]; acc01[i] = c0[16]; acc10[i] = c1[0]; acc11[i] = c1[16];
   }
 #pragma unroll
@@ -504,9 +545,25 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
   quad_abt(As, Bs, wr, wc, lr, lk, acc00, acc01, acc10, acc11);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    double* c0 = &M[(size_t)(ri + qrow + 4 * i) * ld + rj + qcol];
-    double* c1 = &M[(size_t)(ri + qrow + 16 + 4 * i) * ld + rj + qcol];
+    double* c0 = &C[(size_t)(qrow + 4 * i) * ldC + qcol];
+    double* c1 = &C[(size_t)(qrow + 16 + 4 * i) * ldC + qcol];
     c0[0] = acc00[i]; c0[16] = acc01[i]; c1[0] = acc10[i]; c1[16] = acc11[i];
+  }
+}
+
+// M[b0.., b0..] += sum_k corner_k (lower 64x64 tiles of the separator square), after the domain chains
+__global__ __launch_bounds__(256) void k_merge_corners(double* __restrict__ M, int ld, int b0, int nB64, const double* __restrict__ corners,
+                                                        int ldc, int ncorner) {
+  int I = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > (int)blockIdx.x) I--;
+  while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) I++;
+  const int J = blockIdx.x - I * (I + 1) / 2;
+  (void)nB64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = 64 * I + (e >> 6), c = 64 * J + (e & 63);
+    double s = 0.0;
+    for (int k = 0; k < ncorner; k++) s += corners[(size_t)k * ldc * ldc + (size_t)r * ldc + c];
+    M[(size_t)(b0 + r) * ld + b0 + c] += s;
   }
 }
 
@@ -554,28 +611,36 @@ __global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // Back substitution step for block jb (from the last block down):
-//   z_j = Linv_j^T w_j ;  w_i -= L_ji^T z_j for every block i < j.
-// Grid = max(jb, 1) workgroups of 256 threads; every workgroup recomputes z_j itself (64x64
-// mat-vec against the explicit inverse) so there is no in-launch dependency; workgroup 0 stores
-// z_j; workgroup i < jb updates w_i.  Nobody writes w_j in this launch.
+//   z_j = Linv_j^T w_j ;  w_i -= L_ji^T z_j for the blocks i in [ib, ib + ni) (all blocks before j in
+//   the dense order; with camera domains only the blocks of j's own domain couple to it, and the
+//   steps of different domains share a launch).
+// Per job max(ni, 1) workgroups of 256 threads; every workgroup recomputes z_j itself (64x64
+// mat-vec against the explicit inverse) so there is no in-launch dependency; the job's first
+// workgroup stores z_j.  Nobody writes w_j in this launch.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict__ M, int ld, int n, int jb,
+struct BackJob { int jb, ib, ni, wg0; };
+struct BackJobs { int count; BackJob job[8]; };
+__global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict__ M, int ld, int n, BackJobs jobs,
                                                          const double* __restrict__ Linv, double* __restrict__ w,
                                                          double* __restrict__ z) {
   __shared__ double part[4][NB];
   __shared__ double zj[NB];
+  int ji = 0;
+  for (int k = 1; k < jobs.count; k++)
+    if ((int)blockIdx.x >= jobs.job[k].wg0) ji = k;
+  const int jb = jobs.job[ji].jb, bl = blockIdx.x - jobs.job[ji].wg0, ni = jobs.job[ji].ni;
   const int tid = threadIdx.x, j0 = jb * NB;
   const int col = tid & 63, kq = tid >> 6;
   const double* Li = Linv + (size_t)jb * NB * NB;
   // issue the loads of both phases up front: they do not depend on each other
   double lv[16], mv[16];
-  const int i0 = blockIdx.x * NB;
+  const int i0 = (jobs.job[ji].ib + bl) * NB;
 #pragma unroll
   for (int k = 0; k < 16; k++) lv[k] = Li[(16 * kq + k) * NB + col];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int r = j0 + 16 * kq + k;
-    mv[k] = (jb > 0 && r < n) ? M[(size_t)r * ld + i0 + col] : 0.0;
+    mv[k] = (ni > 0 && r < n) ? M[(size_t)r * ld + i0 + col] : 0.0;
   }
   double s = 0.0;
 #pragma unroll
@@ -585,10 +650,10 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict
   if (tid < NB) {
     const double zz = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     zj[tid] = zz;
-    if (blockIdx.x == 0) z[j0 + tid] = zz;
+    if (bl == 0) z[j0 + tid] = zz;
   }
   __syncthreads();
-  if (jb == 0) return;
+  if (ni == 0) return;
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < 16; k++) acc += mv[k] * zj[16 * kq + k];
@@ -606,8 +671,25 @@ __global__ void k_copy_row(const double* __restrict__ M, int ld, int row, int n,
 // Host driver.  M: npad x npad, row n = rhs.  On return z[0..n) solves S z = rhs.
 // `fail` (device int) is OR-ed with 1 when S is not positive definite.
 // work: npad*16 doubles (16x16 inverses) + npad*64 (full block inverses) + npad*64 (diagonal blocks of L).
-int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z,
-                           int* fail) {
+// plan (optional): K uncoupled domains whose panel chains advance together, one job each per launch.
+static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /*data rows in B*/, double* corner, int ldc) {
+  PanelJob jb;
+  jb.j0 = j0; jb.t0 = t0; jb.a0 = a0; jb.na16 = 4 * nA64; jb.b0 = b0; jb.nb16 = cdiv(std::max(0, nrows_b), 16);
+  jb.nrt = jb.na16 + jb.nb16;
+  const int nt = nA64 + cdiv(jb.nb16, 4);
+  if (t0 >= 0) {
+    jb.ncw = std::max(1, cdiv(jb.nrt - 4, 3));  // column-0 workgroups: three 16-row tiles each
+    jb.nwg = jb.ncw + (j0 >= 0 ? nt * (nt - 1) / 2 : 0);
+  } else {
+    jb.ncw = 0;
+    jb.nwg = nt * (nt + 1) / 2;
+  }
+  jb.wg0 = 0; jb.corner = corner; jb.ldc = ldc;
+  return jb;
+}
+
+int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z, int* fail,
+                           const msfm_chol_plan* plan) {
   if (!M || !work || !w || !z || !fail || npad % NB != 0 || n < 1 || n + 1 > npad)
     return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad workspace (null buffer or size)");
   hipStream_t s = ctx->stream;
@@ -615,22 +697,83 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   double* Dinv = work;
   double* Linv = work + (size_t)npad * 16;
   double* Ldiag = work + (size_t)npad * 80;
-  for (int t0 = 0; t0 < n; t0 += NB) {
-    const int j0 = t0 - NB;
-    const int nrt = cdiv(nrows - t0, 16);            // 16-row tiles from t0 down that carry data
-    const int ncw = std::max(1, cdiv(nrt - 4, 3));   // column-0 workgroups: three row tiles each
+  int t_first = 0;
+  if (plan && plan->K > 1) {
+    // ---- the K domain chains, step by step: step l of domain k factors its block l (after applying its panel l-1);
+    //      the step after a domain's last block only applies that last panel to the separator rows ----
+    const int K = plan->K, sb = plan->sep_begin, ldc = plan->ldc;
+    if (K > 8 || sb % NB || !plan->corners || ldc < 64 * cdiv(nrows - sb, 64))
+      return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan");
+    HIP_TRY(ctx, hipMemsetAsync(plan->corners, 0, sizeof(double) * (size_t)K * ldc * ldc, s));
+    int maxp = 0;
+    for (int k = 0; k < K; k++) maxp = std::max(maxp, (plan->dom_end[k] - plan->dom_begin[k]) / NB);
+    for (int l = 0; l <= maxp; l++) {
+      PanelJobs jobs;
+      jobs.count = 0;
+      int wg = 0;
+      for (int k = 0; k < K; k++) {
+        const int P = (plan->dom_end[k] - plan->dom_begin[k]) / NB;
+        if (l > P) continue;
+        const int t0 = l < P ? plan->dom_begin[k] + NB * l : -1;
+        const int j0 = l > 0 ? plan->dom_begin[k] + NB * (l - 1) : -1;
+        PanelJob jb = make_job(j0, t0, t0 >= 0 ? t0 : 0, t0 >= 0 ? P - l : 0, sb, nrows - sb, plan->corners + (size_t)k * ldc * ldc, ldc);
+        jb.wg0 = wg;
+        wg += jb.nwg;
+        jobs.job[jobs.count++] = jb;
+      }
+      if (!jobs.count) break;
+      KTimer t(ctx, "chol_panel_mfma");
+      hipLaunchKernelGGL(k_panel_v2<true>, dim3(wg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
+    }
+    {
+      KTimer t(ctx, "chol_panel_mfma");
+      const int nB64 = cdiv(nrows - sb, 64);
+      hipLaunchKernelGGL(k_merge_corners, dim3(nB64 * (nB64 + 1) / 2), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, K);
+    }
+    t_first = sb;
+  }
+  for (int t0 = t_first; t0 < n; t0 += NB) {
+    // the separator (or the whole matrix): one job per launch, its first block has nothing left to apply
+    const int j0 = t0 > t_first ? t0 - NB : -1;
+    PanelJobs jobs;
+    jobs.count = 1;
+    jobs.job[0] = make_job(j0, t0, t0, cdiv(nrows - t0, 64), 0, 0, nullptr, 0);
+    jobs.job[0].nrt = cdiv(nrows - t0, 16);  // 16-row tiles from t0 down that carry data
+    jobs.job[0].ncw = std::max(1, cdiv(jobs.job[0].nrt - 4, 3));
     const int nt = cdiv(nrows - t0, 64);
-    const int nbulk = j0 >= 0 ? nt * (nt - 1) / 2 : 0;
+    jobs.job[0].nwg = jobs.job[0].ncw + (j0 >= 0 ? nt * (nt - 1) / 2 : 0);
     KTimer t(ctx, "chol_panel_mfma");  // trailing update with panel j0 + potrf / trsm of the panel at t0
-    if (n - t0 >= NB) hipLaunchKernelGGL(k_panel_v2<true>, dim3(ncw + nbulk), dim3(256), 0, s, M, npad, j0, n, nrt, ncw, nt, Dinv, Ldiag, fail);
-    else hipLaunchKernelGGL(k_panel_v2<false>, dim3(ncw + nbulk), dim3(256), 0, s, M, npad, j0, n, nrt, ncw, nt, Dinv, Ldiag, fail);
+    if (n - t0 >= NB) hipLaunchKernelGGL(k_panel_v2<true>, dim3(jobs.job[0].nwg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
+    else hipLaunchKernelGGL(k_panel_v2<false>, dim3(jobs.job[0].nwg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
   }
   {
     KTimer t(ctx, "chol_backsolve");
     hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB)), dim3(256), 0, s, Ldiag, n, Dinv, Linv);
     hipLaunchKernelGGL(k_copy_row, dim3(cdiv(npad, 256)), dim3(256), 0, s, M, npad, n, n, w, npad);
-    for (int jb = cdiv(n, NB) - 1; jb >= 0; jb--)
-      hipLaunchKernelGGL(k_backsolve_step, dim3(jb > 0 ? jb : 1), dim3(256), 0, s, M, npad, n, jb, Linv, w, z);
+    const int first_dense = (plan && plan->K > 1) ? plan->sep_begin / NB : 0;
+    for (int jb = cdiv(n, NB) - 1; jb >= first_dense; jb--) {  // separator (or everything): couples to every block before it
+      BackJobs bj;
+      bj.count = 1;
+      bj.job[0] = BackJob{jb, 0, jb, 0};
+      hipLaunchKernelGGL(k_backsolve_step, dim3(jb > 0 ? jb : 1), dim3(256), 0, s, M, npad, n, bj, Linv, w, z);
+    }
+    if (first_dense) {
+      int maxp = 0;
+      for (int k = 0; k < plan->K; k++) maxp = std::max(maxp, (plan->dom_end[k] - plan->dom_begin[k]) / NB);
+      for (int l = 0; l < maxp; l++) {  // block P_k - 1 - l of every domain in one launch
+        BackJobs bj;
+        bj.count = 0;
+        int wg = 0;
+        for (int k = 0; k < plan->K; k++) {
+          const int ib = plan->dom_begin[k] / NB, P = (plan->dom_end[k] - plan->dom_begin[k]) / NB;
+          if (l >= P) continue;
+          const int jb = ib + P - 1 - l;
+          bj.job[bj.count++] = BackJob{jb, ib, jb - ib, wg};
+          wg += std::max(1, jb - ib);
+        }
+        hipLaunchKernelGGL(k_backsolve_step, dim3(wg), dim3(256), 0, s, M, npad, n, bj, Linv, w, z);
+      }
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "cholesky launch: %s", hipGetErrorString(e));

@@ -88,3 +88,16 @@ struct DevBuf {
 };
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Elimination structure of the reduced system (chol.hip): columns [dom_begin[k], dom_end[k]) are K
+// mutually uncoupled camera domains (64-aligned, identity padding inside), [sep_begin, n) is their
+// separator + intrinsics.  K <= 1: plain dense order.  corners: K buffers of ldc x ldc doubles.
+struct msfm_chol_plan {
+  int K = 0;
+  int dom_begin[8] = {0}, dom_end[8] = {0};
+  int sep_begin = 0;
+  double* corners = nullptr;
+  int ldc = 0;
+};
+int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z, int* fail,
+                           const msfm_chol_plan* plan);

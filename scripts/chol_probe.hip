@@ -19,14 +19,29 @@ int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 3003;
   const int pj0 = argc > 2 ? atoi(argv[2]) : 640;
   const int pwg = argc > 3 ? atoi(argv[3]) : 0;
+  const int K = argc > 4 ? atoi(argv[4]) : 1;
   const int npad = (n + 1 + 63) / 64 * 64;
   msfm_ctx* ctx = nullptr;
   if (msfm_ctx_create(0, &ctx) != 0) { printf("no ctx\n"); return 1; }
   std::vector<double> h((size_t)npad * npad, 0.0);
   std::mt19937_64 g(7);
   std::uniform_real_distribution<double> U(-1, 1);
+  msfm_chol_plan plan;
+  const int dsz = K > 1 ? (int)(0.7 * n / K) / 64 * 64 : 0;
+  if (K > 1) {
+    plan.K = K;
+    int at = 0;
+    for (int k = 0; k < K; k++) { plan.dom_begin[k] = at; at += dsz - (k == 1 ? 64 : 0); plan.dom_end[k] = at; }  // unequal chains
+    plan.sep_begin = at;
+    plan.ldc = 64 * ((n + 1 - plan.sep_begin + 63) / 64);
+    hipMalloc(&plan.corners, sizeof(double) * (size_t)K * plan.ldc * plan.ldc);
+  }
+  auto dom = [&](int i) { for (int k = 0; k < plan.K; k++) if (i >= plan.dom_begin[k] && i < plan.dom_end[k]) return k; return -1; };
   for (int r = 0; r < n; r++) {
-    for (int c = 0; c < r; c++) h[(size_t)r * npad + c] = U(g);
+    for (int c = 0; c < r; c++) {
+      const int dr = dom(r), dc = dom(c);
+      h[(size_t)r * npad + c] = (dr >= 0 && dc >= 0 && dr != dc) ? 0.0 : U(g);   // no coupling between domains
+    }
     h[(size_t)r * npad + r] = n + 1.0;
   }
   for (int c = 0; c < n; c++) h[(size_t)n * npad + c] = U(g);
@@ -42,7 +57,7 @@ int main(int argc, char** argv) {
     hipMemcpy(M, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
     hipDeviceSynchronize();
     hipEventRecord(e0, ctx->stream);
-    int rc = msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail);
+    int rc = msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, K > 1 ? &plan : nullptr);
     hipEventRecord(e1, ctx->stream);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -18,6 +18,10 @@ def main():
     if which == "gps":
         sc = scene.make_aerial_scene(20, 2500, seed=21, gps_sigma=0.5, rot_sigma=0.02, trans_sigma=0.3, point_sigma=0.2)
         kw = dict(gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams))
+    elif which == "domains":
+        # >= 128 cameras: the union camera graph is bisected identically on every rank (MSFM_CHOL_DOMAINS forced by the test)
+        sc = scene.make_aerial_scene(150, 5000, seed=8)
+        kw = {}
     else:
         sc = scene.config_scene(2)
         kw = {}

@@ -140,3 +140,36 @@ def test_ba_degenerate_structures(ctx, oracle):
     assert r_gpu["num_residuals"] == r_ref["num_residuals"] == 0
     assert r_gpu["termination"] == r_ref["termination"] and r_gpu["num_iterations"] == r_ref["num_iterations"] == 0
     assert (a_gpu.point == sc.point).all() and (a_gpu.cam_pose == sc.cam_pose).all()
+
+
+def _panel_launches(ctx, arrays, opts):
+    ctx.profile(True)
+    ctx.profile_reset()
+    r = ctx.ba_solve(arrays, opts)
+    st = ctx.profile_get()
+    ctx.profile(False)
+    return r, st["chol_panel_mfma"]["launches"]
+
+
+@pytest.mark.parametrize("depth", ["1", "2"])
+def test_ba_domain_parallel_factorisation(ctx, oracle, monkeypatch, depth):
+    """>= 128 cameras: the camera graph is bisected (depth 1 / 2) and the domains' panel chains share launches.
+    Same answers as the dense elimination order and as the oracle, with fewer panel launches."""
+    from metricsfm_amd import capi
+    sc = scene.make_aerial_scene(168, 6000, seed=5, gps_sigma=0.5)
+    kw = dict(gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams))
+    okw = dict(max_num_iterations=12)
+    monkeypatch.setenv("MSFM_CHOL_DOMAINS", "0")
+    a_dense = A.BaArrays.from_scene(sc, **kw)
+    r_dense, n_dense = _panel_launches(ctx, a_dense, capi.default_options(**okw))
+    monkeypatch.setenv("MSFM_CHOL_DOMAINS", depth)
+    a_dom = A.BaArrays.from_scene(sc, **kw)
+    r_dom, n_dom = _panel_launches(ctx, a_dom, capi.default_options(**okw))
+    assert n_dom < n_dense, (n_dom, n_dense)           # the chains really ran side by side
+    assert r_dom["num_iterations"] == r_dense["num_iterations"]
+    np.testing.assert_array_equal(r_dom["iterations"]["step_is_successful"], r_dense["iterations"]["step_is_successful"])
+    np.testing.assert_allclose(r_dom["iterations"]["cost"], r_dense["iterations"]["cost"], rtol=1e-10)
+    for name in ("cam_pose", "cam_model", "point"):
+        assert _rel(getattr(a_dom, name), getattr(a_dense, name)) < 1e-8, name
+    # and against the CPU oracle (dense Schur complement, camera order as given)
+    check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc, **kw), okw)

@@ -12,10 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,which,port", [(2, "c2", 29741), (3, "gps", 29742)])
+@pytest.mark.parametrize("world,which,port", [(2, "c2", 29741), (3, "gps", 29742), (2, "domains", 29743)])
 def test_sharded_ba_matches_single_rank(tmp_path, world, which, port):
     out = tmp_path / "mr.npz"
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if which == "domains":
+        env["MSFM_CHOL_DOMAINS"] = "2"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "multirank_worker.py"), str(out), which]
     subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=600)
