@@ -266,7 +266,8 @@ struct PanelJob {
   int b0, nb16;    // range B (nb16 counts the 16-row tiles that carry data)
   int nrt;         // 16-row tiles that carry data, over A then B
   int ncw;         // column-0 workgroups
-  int wg0, nwg;    // workgroups [wg0, wg0 + nwg) of the launch
+  int wg0, nwg;    // workgroups [wg0, wg0 + nwg) of the launch: ncw column-0 ones, then the bulk ones
+  int ntile;       // 64x64 tiles of the trailing update, dealt round-robin to the nwg - ncw bulk workgroups
   int ldc;         // leading dimension of corner
   double* corner;  // destination of B x B tiles, nullptr: M itself
 };
@@ -497,72 +498,108 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lk = lane >> 4;
   const int j0 = jb.j0;
-  // pairs (I, J) with jmin <= J <= I < nt, enumerated row by row (shifted by one when jmin == 0)
-  const int jmin = jb.t0 >= 0 ? 1 : 0;
-  const int q = bl - jb.ncw;
-  int I = (int)((sqrt(8.0 * q + 1.0) + 1.0) * 0.5);
-  while (I * (I - 1) / 2 > q) I--;
-  while ((I + 1) * I / 2 <= q) I++;
-  int J = q - I * (I - 1) / 2 + 1;
-  if (!jmin) { I--; J--; }
-  const int ri = job_row64(jb, I), rj = job_row64(jb, J);
-  // destination of the tile: M, or the job's private corner when both tiles lie in range B
-  const int nA64 = jb.na16 / 4;
-  double* C;
-  int ldC;
-  if (jb.corner && I >= nA64 && J >= nA64) {
-    ldC = jb.ldc;
-    C = jb.corner + (size_t)(64 * (I - nA64)) * ldC + 64 * (J - nA64);
-  } else {
-    ldC = ld;
-    C = M + (size_t)ri * ld + rj;
-  }
-  // all loads first: the two panel tiles and this wave's quadrant of C (the accumulators start from it)
-  d2 va[8], vb[8];
-#pragma unroll
-  for (int it = 0; it < 8; it++) {
-    const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
-    va[it] = *reinterpret_cast<const d2*>(&M[(size_t)(ri + r) * ld + j0 + c2]);
-    vb[it] = *reinterpret_cast<const d2*>(&M[(size_t)(rj + r) * ld + j0 + c2]);
-  }
+  const int jmin = jb.t0 >= 0 ? 1 : 0, nA64 = jb.na16 / 4;
+  const int nbw = jb.nwg - jb.ncw;
   const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;
-  d4 acc00, acc01, acc10, acc11;
+  // A bulk workgroup walks tiles q, q + nbw, ...: the panel tiles and the C quadrant of the NEXT tile are
+  // fetched into registers while the MFMAs of the current one run (the kernel runs one workgroup per CU,
+  // so nothing else hides that latency).
+  auto locate = [&](int q, int& ri, int& rj, double*& C, int& ldC) {
+    // pairs (I, J) with jmin <= J <= I < nt, enumerated row by row (shifted by one when jmin == 0)
+    int I = (int)((sqrt(8.0 * q + 1.0) + 1.0) * 0.5);
+    while (I * (I - 1) / 2 > q) I--;
+    while ((I + 1) * I / 2 <= q) I++;
+    int J = q - I * (I - 1) / 2 + 1;
+    if (!jmin) { I--; J--; }
+    ri = job_row64(jb, I);
+    rj = job_row64(jb, J);
+    // destination of the tile: M, or the job's private corner when both tiles lie in range B
+    if (jb.corner && I >= nA64 && J >= nA64) {
+      ldC = jb.ldc;
+      C = jb.corner + (size_t)(64 * (I - nA64)) * ldC + 64 * (J - nA64);
+    } else {
+      ldC = ld;
+      C = M + (size_t)ri * ld + rj;
+    }
+  };
+  d2 va[8], vb[8];
+  d4 c00, c01, c10, c11;
+  auto fetch = [&](int ri, int rj, const double* C, int ldC) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const double* c0 = &C[(size_t)(qrow + 4 * i) * ldC + qcol];
-    const double* c1 = &C[(size_t)(qrow + 16 + 4 * i) * ldC + qcol];
-    acc00[i] = c0[0]; acc01[i] = c0[16]; acc10[i] = c1[0]; acc11[i] = c1[16];
-  }
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+      va[it] = *reinterpret_cast<const d2*>(&M[(size_t)(ri + r) * ld + j0 + c2]);
+      vb[it] = *reinterpret_cast<const d2*>(&M[(size_t)(rj + r) * ld + j0 + c2]);
+    }
 #pragma unroll
-  for (int it = 0; it < 8; it++) {
-    const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
-    As[r * LDT + c2] = -va[it].x;  // negated once here: the MFMAs then accumulate C - P_I P_J^T directly
-    As[r * LDT + c2 + 1] = -va[it].y;
-    Bs[r * LDT + c2] = vb[it].x;
-    Bs[r * LDT + c2 + 1] = vb[it].y;
-  }
-  __syncthreads();
-  quad_abt(As, Bs, wr, wc, lr, lk, acc00, acc01, acc10, acc11);
+    for (int i = 0; i < 4; i++) {
+      const double* p0 = &C[(size_t)(qrow + 4 * i) * ldC + qcol];
+      const double* p1 = &C[(size_t)(qrow + 16 + 4 * i) * ldC + qcol];
+      c00[i] = p0[0]; c01[i] = p0[16]; c10[i] = p1[0]; c11[i] = p1[16];
+    }
+  };
+  int q = bl - jb.ncw;
+  int ri, rj, ldC;
+  double* C;
+  locate(q, ri, rj, C, ldC);
+  fetch(ri, rj, C, ldC);
+  for (;;) {
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double* c0 = &C[(size_t)(qrow + 4 * i) * ldC + qcol];
-    double* c1 = &C[(size_t)(qrow + 16 + 4 * i) * ldC + qcol];
-    c0[0] = acc00[i]; c0[16] = acc01[i]; c1[0] = acc10[i]; c1[16] = acc11[i];
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+      As[r * LDT + c2] = -va[it].x;  // negated once here: the MFMAs then accumulate C - P_I P_J^T directly
+      As[r * LDT + c2 + 1] = -va[it].y;
+      Bs[r * LDT + c2] = vb[it].x;
+      Bs[r * LDT + c2 + 1] = vb[it].y;
+    }
+    d4 acc00 = c00, acc01 = c01, acc10 = c10, acc11 = c11;
+    double* Cw = C;
+    const int ldw = ldC;
+    __syncthreads();
+    const int qn = q + nbw;
+    const bool more = qn < jb.ntile;
+    if (more) {
+      locate(qn, ri, rj, C, ldC);
+      fetch(ri, rj, C, ldC);
+    }
+    quad_abt(As, Bs, wr, wc, lr, lk, acc00, acc01, acc10, acc11);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      double* p0 = &Cw[(size_t)(qrow + 4 * i) * ldw + qcol];
+      double* p1 = &Cw[(size_t)(qrow + 16 + 4 * i) * ldw + qcol];
+      p0[0] = acc00[i]; p0[16] = acc01[i]; p1[0] = acc10[i]; p1[16] = acc11[i];
+    }
+    if (!more) break;
+    q = qn;
+    __syncthreads();  // every wave is done with As / Bs
   }
 }
 
 // M[b0.., b0..] += sum_k corner_k (lower 64x64 tiles of the separator square), after the domain chains
 __global__ __launch_bounds__(256) void k_merge_corners(double* __restrict__ M, int ld, int b0, int nB64, const double* __restrict__ corners,
                                                         int ldc, int ncorner) {
-  int I = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-  while (I * (I + 1) / 2 > (int)blockIdx.x) I--;
-  while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) I++;
-  const int J = blockIdx.x - I * (I + 1) / 2;
+  // 4 workgroups per lower 64x64 tile, 4 elements per thread, all loads issued before the sums
+  const int tile = blockIdx.x >> 2, part = blockIdx.x & 3;
+  int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > tile) I--;
+  while ((I + 1) * (I + 2) / 2 <= tile) I++;
+  const int J = tile - I * (I + 1) / 2;
   (void)nB64;
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+  double v[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int e = part * 1024 + u * 256 + threadIdx.x;
+    const int r = 64 * I + (e >> 6), c = 64 * J + (e & 63);
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[u][k] = k < ncorner ? corners[(size_t)k * ldc * ldc + (size_t)r * ldc + c] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int e = part * 1024 + u * 256 + threadIdx.x;
     const int r = 64 * I + (e >> 6), c = 64 * J + (e & 63);
     double s = 0.0;
-    for (int k = 0; k < ncorner; k++) s += corners[(size_t)k * ldc * ldc + (size_t)r * ldc + c];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += v[u][k];
     M[(size_t)(b0 + r) * ld + b0 + c] += s;
   }
 }
@@ -672,6 +709,10 @@ __global__ void k_copy_row(const double* __restrict__ M, int ld, int row, int n,
 // `fail` (device int) is OR-ed with 1 when S is not positive definite.
 // work: npad*16 doubles (16x16 inverses) + npad*64 (full block inverses) + npad*64 (diagonal blocks of L).
 // plan (optional): K uncoupled domains whose panel chains advance together, one job each per launch.
+// One tile per bulk workgroup: the hardware dispatcher balances them over the CUs the column-0 workgroups leave free
+// (4 tiles per workgroup with register prefetch of the next tile measured slower: coarser quantisation, same time per tile).
+static int bulk_workgroups(int ntile) { return ntile; }
+
 static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /*data rows in B*/, double* corner, int ldc) {
   PanelJob jb;
   jb.j0 = j0; jb.t0 = t0; jb.a0 = a0; jb.na16 = 4 * nA64; jb.b0 = b0; jb.nb16 = cdiv(std::max(0, nrows_b), 16);
@@ -679,11 +720,12 @@ static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /
   const int nt = nA64 + cdiv(jb.nb16, 4);
   if (t0 >= 0) {
     jb.ncw = std::max(1, cdiv(jb.nrt - 4, 3));  // column-0 workgroups: three 16-row tiles each
-    jb.nwg = jb.ncw + (j0 >= 0 ? nt * (nt - 1) / 2 : 0);
+    jb.ntile = j0 >= 0 ? nt * (nt - 1) / 2 : 0;
   } else {
     jb.ncw = 0;
-    jb.nwg = nt * (nt + 1) / 2;
+    jb.ntile = nt * (nt + 1) / 2;
   }
+  jb.nwg = jb.ncw + bulk_workgroups(jb.ntile);
   jb.wg0 = 0; jb.corner = corner; jb.ldc = ldc;
   return jb;
 }
@@ -728,7 +770,7 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     {
       KTimer t(ctx, "chol_panel_mfma");
       const int nB64 = cdiv(nrows - sb, 64);
-      hipLaunchKernelGGL(k_merge_corners, dim3(nB64 * (nB64 + 1) / 2), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, K);
+      hipLaunchKernelGGL(k_merge_corners, dim3(4 * (nB64 * (nB64 + 1) / 2)), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, K);
     }
     t_first = sb;
   }
@@ -740,8 +782,7 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     jobs.job[0] = make_job(j0, t0, t0, cdiv(nrows - t0, 64), 0, 0, nullptr, 0);
     jobs.job[0].nrt = cdiv(nrows - t0, 16);  // 16-row tiles from t0 down that carry data
     jobs.job[0].ncw = std::max(1, cdiv(jobs.job[0].nrt - 4, 3));
-    const int nt = cdiv(nrows - t0, 64);
-    jobs.job[0].nwg = jobs.job[0].ncw + (j0 >= 0 ? nt * (nt - 1) / 2 : 0);
+    jobs.job[0].nwg = jobs.job[0].ncw + bulk_workgroups(jobs.job[0].ntile);
     KTimer t(ctx, "chol_panel_mfma");  // trailing update with panel j0 + potrf / trsm of the panel at t0
     if (n - t0 >= NB) hipLaunchKernelGGL(k_panel_v2<true>, dim3(jobs.job[0].nwg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
     else hipLaunchKernelGGL(k_panel_v2<false>, dim3(jobs.job[0].nwg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
