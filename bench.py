@@ -68,6 +68,8 @@ def main():
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
 
     import torch
+    # one rank per GPU on the real node; a rehearsal with more ranks than GPUs (gloo, one test GPU) shares devices
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     dist = None
     if world > 1:
         import torch.distributed as dist
