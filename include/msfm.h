@@ -229,6 +229,17 @@ int msfm_ba_upload_params(msfm_ba* ba, const double* cam_pose, const double* cam
                           const double* point);
 int msfm_ba_download_params(msfm_ba* ba, double* cam_pose, double* cam_model, double* point);
 void msfm_ba_destroy(msfm_ba* ba);
+/* How the reduced camera system of a resident problem is laid out and eliminated (no reference counterpart:
+ * Ceres' DENSE_SCHUR factors S in the given camera order).  n_domains <= 1: dense order. */
+typedef struct msfm_ba_layout {
+  int reduced_order;      /* 6 * camera blocks + 3 * intrinsics blocks */
+  int system_order;       /* order of the factored matrix: reduced_order + identity padding of the domains */
+  int n_domains;          /* mutually uncoupled camera domains whose panel chains share launches */
+  int domain_cols[8];     /* columns of each domain (multiples of 64) */
+  int separator_cols;     /* separator cameras + intrinsics */
+  int panel_launches;     /* panel launches per factorisation */
+} msfm_ba_layout;
+int msfm_ba_get_layout(const msfm_ba* ba, msfm_ba_layout* out);
 
 /* Multi-GPU: points (with all their observations) are sharded over ranks, cameras and
  * intrinsics are replicated; a few times per LM iteration `count` doubles at `buf_dev` (the per-camera J^T J sums, the

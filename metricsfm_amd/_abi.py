@@ -25,6 +25,12 @@ class BaProblem(C.Structure):
                 ("pt_mutable", c_u8_p), ("gps_xyz", c_double_p), ("gps_weight", C.c_double)]
 
 
+class BaLayout(C.Structure):
+    """msfm_ba_layout (include/msfm.h)."""
+    _fields_ = [("reduced_order", C.c_int), ("system_order", C.c_int), ("n_domains", C.c_int), ("domain_cols", C.c_int * 8),
+                ("separator_cols", C.c_int), ("panel_launches", C.c_int)]
+
+
 class FransacOptions(C.Structure):
     """msfm_fransac_options (include/msfm.h)."""
     _fields_ = [("threshold", C.c_double), ("confidence", C.c_double), ("max_iterations", C.c_int),

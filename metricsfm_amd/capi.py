@@ -20,7 +20,7 @@ SYMBOLS = [
     "msfm_knn2_f32", "msfm_descset_create", "msfm_descset_upload", "msfm_descset_count", "msfm_descset_destroy",
     "msfm_match_pairs", "msfm_match_result_counts", "msfm_match_result_fetch", "msfm_match_result_stats", "msfm_match_result_destroy",
     "msfm_match_pairs_rerun", "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
-    "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ctx_set_allreduce",
+    "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ba_get_layout", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
     "msfm_epipolar_filter_batch",
@@ -81,6 +81,7 @@ def lib():
         fn.argtypes = [vp, C.POINTER(A.Tracks), d, d, A.c_double_p, A.c_double_p, A.c_u8_p]
     L.msfm_reproject_mse_batch.argtypes = [vp, C.POINTER(A.Tracks), A.c_double_p, A.c_double_p]
     L.msfm_epipolar_filter.argtypes = [vp, A.c_float_p, A.c_float_p, i, A.c_double_p, d, A.c_u8_p]
+    L.msfm_ba_get_layout.argtypes = [vp, C.POINTER(A.BaLayout)]
     L.msfm_fransac_default_options.argtypes = [C.POINTER(A.FransacOptions)]
     L.msfm_fransac_default_options.restype = None
     L.msfm_fundamental_ransac_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, C.POINTER(A.FransacOptions),
@@ -348,6 +349,13 @@ class BaResident:
         buf = A.SummaryBuf(capacity)
         self.ctx.check(lib().msfm_ba_run(self._h, C.byref(options), C.byref(buf.struct)))
         return buf.result()
+
+    def layout(self):
+        lay = A.BaLayout()
+        self.ctx.check(lib().msfm_ba_get_layout(self._h, C.byref(lay)))
+        return dict(reduced_order=lay.reduced_order, system_order=lay.system_order, n_domains=lay.n_domains,
+                    domain_cols=list(lay.domain_cols)[:max(0, lay.n_domains if lay.n_domains > 1 else 0)],
+                    separator_cols=lay.separator_cols, panel_launches=lay.panel_launches)
 
     def upload(self, cam_pose=None, cam_model=None, point=None):
         cp, cm, pt = A.as_c(cam_pose, np.float64), A.as_c(cam_model, np.float64), A.as_c(point, np.float64)

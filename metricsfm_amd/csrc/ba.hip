@@ -1393,6 +1393,24 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   return MSFM_OK;
 }
 
+MSFM_API int msfm_ba_get_layout(const msfm_ba* ba, msfm_ba_layout* out) {
+  if (!ba || !out) return MSFM_E_INVAL;
+  memset(out, 0, sizeof *out);
+  out->reduced_order = ba->nred;
+  out->system_order = ba->nsys;
+  const int K = ba->plan.K > 1 ? ba->plan.K : 0;
+  out->n_domains = K ? K : 1;
+  int maxp = 0;
+  for (int k = 0; k < K; k++) {
+    out->domain_cols[k] = ba->plan.dom_end[k] - ba->plan.dom_begin[k];
+    maxp = std::max(maxp, out->domain_cols[k] / 64);
+  }
+  out->separator_cols = K ? ba->nsys - ba->plan.sep_begin : ba->nsys;
+  out->panel_launches = K ? maxp + 1 + cdiv(out->separator_cols, 64) : cdiv(ba->nsys, 64);
+  if (!K) out->domain_cols[0] = 0;
+  return MSFM_OK;
+}
+
 MSFM_API int msfm_ba_upload_params(msfm_ba* ba, const double* cam_pose, const double* cam_model, const double* point) {
   if (!ba) return MSFM_E_INVAL;
   msfm_ctx* ctx = ba->ctx;

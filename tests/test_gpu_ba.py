@@ -164,6 +164,9 @@ def test_ba_domain_parallel_factorisation(ctx, oracle, monkeypatch, depth):
     r_dense, n_dense = _panel_launches(ctx, a_dense, capi.default_options(**okw))
     monkeypatch.setenv("MSFM_CHOL_DOMAINS", depth)
     a_dom = A.BaArrays.from_scene(sc, **kw)
+    lay = ctx.ba(A.BaArrays.from_scene(sc, **kw)).layout()
+    assert lay["n_domains"] == 2 ** int(depth) and all(c % 64 == 0 for c in lay["domain_cols"])
+    assert sum(lay["domain_cols"]) + lay["separator_cols"] == lay["system_order"] >= lay["reduced_order"] == 6 * 168 + 3
     r_dom, n_dom = _panel_launches(ctx, a_dom, capi.default_options(**okw))
     assert n_dom < n_dense, (n_dom, n_dense)           # the chains really ran side by side
     assert r_dom["num_iterations"] == r_dense["num_iterations"]
