@@ -16,6 +16,7 @@
 // The LM control flow (step acceptance, radius update, stopping rules) follows Ceres 1.13's
 // TrustRegionMinimizer and runs on the host; one small scalar read-back per phase.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -1088,7 +1089,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
       for (int c = 0; c < Nc; c++) if (is_mut(P->cam_mutable, c)) { cu[c] = 1; if (is_mut(P->model_mutable, P->cam_model_of_cam[c])) mu[P->cam_model_of_cam[c]] = 1; }
     }
     for (int m = 0; m < Nm; m++) if (mu[m]) { model_slot[m] = ba->nmb++; ba->h_mb_model.push_back(m); }
-    for (int p = 0; p < Np; p++) if (pu[p]) { pt_slot[p] = ba->npb++; ba->h_pb_pt.push_back(p); }
+    for (int p = 0; p < Np; p++) if (pu[p]) ba->h_pb_pt.push_back(p);  // slots are assigned below, once the camera order is known
     // ---- elimination order of the camera blocks (see partition_cameras) ----
     std::vector<int> gnode(Nc, -1), gcam;
     for (int c = 0; c < Nc; c++) if (cu[c]) { gnode[c] = (int)gcam.size(); gcam.push_back(c); }
@@ -1154,6 +1155,36 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
       for (int g = 0; g < ng; g++)
         if (label[g] < 0) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
     }
+    // ---- order of the eliminated points: by the (sorted) list of camera blocks that see them ----
+    // Points seen by the same cameras become neighbours, so the records of a camera pair's common points are
+    // runs in both cameras' segments (the pair kernel's gathers and k_point's scattered stores turn near-sequential).
+    // Internal only: h_pb_pt maps block -> caller's point index.
+    if (!getenv("MSFM_POINT_ORDER") || atoi(getenv("MSFM_POINT_ORDER")) != 0) {
+      // key: the four smallest camera blocks, 16 bits each (21 bits x 3 when there are more than 65535 blocks)
+      const bool wide = ba->ncb >= 0xFFFF;
+      std::vector<std::pair<uint64_t, int>> keyed;
+      keyed.reserve(ba->h_pb_pt.size());
+      std::vector<int> cams;
+      for (int o = 0; o < No;) {
+        const int p = P->obs_pt[o];
+        cams.clear();
+        int e = o;
+        for (; e < No && P->obs_pt[e] == p; e++)
+          if (cam_slot[P->obs_cam[e]] >= 0) cams.push_back(cam_slot[P->obs_cam[e]]);
+        if (pu[p]) {
+          std::sort(cams.begin(), cams.end());
+          uint64_t k = 0;
+          const int nk = wide ? 3 : 4, bits = wide ? 21 : 16;
+          for (int i = 0; i < nk; i++) k = (k << bits) | (uint64_t)(i < (int)cams.size() ? cams[i] : ((1 << bits) - 1));
+          keyed.push_back({k, p});
+        }
+        o = e;
+      }
+      std::sort(keyed.begin(), keyed.end());  // ties fall back to the caller's point index
+      if (keyed.size() == ba->h_pb_pt.size())
+        for (size_t i = 0; i < keyed.size(); i++) ba->h_pb_pt[i] = keyed[i].second;
+    }
+    for (size_t i = 0; i < ba->h_pb_pt.size(); i++) pt_slot[ba->h_pb_pt[i]] = ba->npb++;
     ba->mo = col;
     ba->nsys = col + 3 * ba->nmb;
     ba->n_padcol = (int)padcol_h.size();
@@ -1175,8 +1206,18 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   std::vector<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
   std::vector<double> o_x, o_y, o_w;
   std::vector<int> pt_first(npb + 1, 0);
+  // input runs per point (obs_pt is non-decreasing): pass 0 walks the eliminated points in block order
+  std::vector<int> run_first(Np + 1, 0);
+  for (int o = 0; o < No; o++) run_first[P->obs_pt[o] + 1]++;
+  for (int p = 0; p < Np; p++) run_first[p + 1] += run_first[p];
+  std::vector<int> walk;
+  walk.reserve(No);
+  for (int pb = 0; pb < ba->npb; pb++)
+    for (int o = run_first[ba->h_pb_pt[pb]]; o < run_first[ba->h_pb_pt[pb] + 1]; o++) walk.push_back(o);
   for (int pass = 0; pass < 2; pass++) {
-    for (int o = 0; o < No; o++) {
+    const int nwalk = pass == 0 ? (int)walk.size() : No;
+    for (int wi = 0; wi < nwalk; wi++) {
+      const int o = pass == 0 ? walk[wi] : wi;
       const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
       const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
       if (!cm && !pm) continue;
