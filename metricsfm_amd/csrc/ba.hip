@@ -36,9 +36,11 @@
 #define F_TU 72      // 6
 
 // scalar slots (device `scal` array)
-// [0,5) are sums, [5,7) are maxima.  S_XCOST is the cost at x (kept across the speculative solve),
-// S_COST the cost at the candidate.
-enum { S_COST = 0, S_MCC, S_DX2, S_X2, S_XCOST, S_GMAX, S_FAIL, S_N };
+// Scalars of one LM iteration.  [0, S_GMAX) are sums over ranks (S_FAIL: non-zero on any rank = failure), S_GMAX a
+// maximum.  S_XCOST is the cost at x (kept across the speculative solve), S_COST the cost at the candidate.  With more
+// than one rank the kernels write the rank's partials to `sloc` and ONE sum per iteration brings them into `scal`:
+// the maximum travels as one slot per rank (S_RANK0 + r), of which only rank r's is non-zero.
+enum { S_COST = 0, S_MCC, S_DX2, S_X2, S_FAIL, S_XCOST, S_GMAX, S_RANK0 = 8, S_N = 64 };
 
 struct BaPtrs {
   int A, AE, ncb, nmb, npb, NCR;
@@ -834,7 +836,8 @@ struct msfm_ba {
   PairJobs cc, mc, mm;
   DevBuf<double> M, Linv, w, z;
   DevBuf<double> gps, g_r, g_J;
-  DevBuf<double> partial, partial2, partial3, gmax_buf, scal;
+  DevBuf<double> partial, partial2, partial3, gmax_buf, scal, sloc;
+  double* swrite = nullptr;  // where the kernels put scalars: scal (one rank) or sloc (partials, summed by reduce_scalars)
   DevBuf<int> fail;
   double* h_scal = nullptr;  // pinned
   hipEvent_t ev_scal = nullptr;
@@ -1383,7 +1386,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     ba->n_ublk = (int)ur.size();
     HIP_TRY(ctx, ba->u_row.from(ur, s));
     HIP_TRY(ctx, ba->u_col.from(uc, s));
-    HIP_TRY(ctx, ba->pack.alloc((size_t)std::max(1, ba->n_ublk) * 36));
+    HIP_TRY(ctx, ba->pack.alloc((size_t)std::max(1, ba->n_ublk) * 36 + (size_t)(ba->nsys - ba->mo + 1) * ba->npad));
     HIP_TRY(ctx, hipStreamSynchronize(s));
   }
   const size_t As = std::max(1, A);
@@ -1404,7 +1407,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   const size_t npart = (size_t)ba->nblk_obs + ba->nblk_pt + cdiv(std::max(1, ncb), 256) + 64;
   AL(partial, npart); AL(partial2, npart); AL(partial3, npart);
   AL(gmax_buf, (size_t)ba->nblk_pt + 6 * (size_t)ncb + 3 * (size_t)nmb + 8);
-  AL(scal, 16);
+  AL(scal, S_N); AL(sloc, S_N);
   HIP_TRY(ctx, ba->fail.alloc(4));
 #undef AL
   {
@@ -1417,6 +1420,9 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     for (const void* q : must)
       if (!q) return msfm_set_error(ctx, MSFM_E_NOMEM, "msfm_ba_create: a device buffer was not allocated");
   }
+  ba->swrite = ctx->world > 1 ? ba->sloc.p : ba->scal.p;
+  HIP_TRY(ctx, hipMemsetAsync(ba->scal.p, 0, sizeof(double) * S_N, s));
+  HIP_TRY(ctx, hipMemsetAsync(ba->sloc.p, 0, sizeof(double) * S_N, s));
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_scal, 16 * sizeof(double)));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ba->ev_scal, hipEventDisableTiming));
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_fail, 4 * sizeof(int)));
@@ -1517,7 +1523,7 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int
       if (jac) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
       else hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->scal.p, slot, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->swrite, slot, 0);
   }
   return MSFM_OK;
 }
@@ -1562,9 +1568,9 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
                          ba->diag_m.p, ba->scale_m.p, reuse_diag ? 1 : 0, mode, opt->min_lm_diagonal, opt->max_lm_diagonal, gmax_m);
   }
   if (mode == 1) return MSFM_OK;
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, ba->scal.p,
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, ba->swrite,
                      S_GMAX, 1);
-  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->scal.p, S_FAIL);
+  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->swrite, S_FAIL);
   {
     KTimer t(ctx, "ba_schur_pairs");
     if (ba->cc.n_chunks)
@@ -1597,10 +1603,14 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     if (ba->n_ublk > 0) {
       // camera-camera blocks packed (union structure), intrinsics rows + rhs row as one dense slab
       const int nb = cdiv(ba->n_ublk * 36, 256);
+      // ... and the intrinsics rows + rhs row (contiguous in M) behind them: one sum for the whole system
+      const size_t nblk = (size_t)ba->n_ublk * 36, nslab = (size_t)(ba->nsys - ba->mo + 1) * ba->npad;
+      double* slab = ba->M.p + (size_t)ba->mo * ba->npad;
       hipLaunchKernelGGL(k_pack_blocks<true>, dim3(nb), dim3(256), 0, s, ba->n_ublk, ba->u_row.p, ba->u_col.p, ba->cb_off.p, ba->M.p, ba->npad, ba->pack.p);
-      MSFM_TRY(allreduce(ba, ba->pack.p, (size_t)ba->n_ublk * 36, MSFM_REDUCE_SUM));
-      MSFM_TRY(allreduce(ba, ba->M.p + (size_t)ba->mo * ba->npad, (size_t)(ba->nsys - ba->mo + 1) * ba->npad, MSFM_REDUCE_SUM));
+      HIP_TRY(ctx, hipMemcpyAsync(ba->pack.p + nblk, slab, sizeof(double) * nslab, hipMemcpyDeviceToDevice, s));
+      MSFM_TRY(allreduce(ba, ba->pack.p, nblk + nslab, MSFM_REDUCE_SUM));
       hipLaunchKernelGGL(k_pack_blocks<false>, dim3(nb), dim3(256), 0, s, ba->n_ublk, ba->u_row.p, ba->u_col.p, ba->cb_off.p, ba->M.p, ba->npad, ba->pack.p);
+      HIP_TRY(ctx, hipMemcpyAsync(slab, ba->pack.p + nblk, sizeof(double) * nslab, hipMemcpyDeviceToDevice, s));
     } else {
       // rows [0, nred] of M (S and the rhs row) are contiguous: one sum over ranks
       MSFM_TRY(allreduce(ba, ba->M.p, (size_t)(ba->nsys + 1) * ba->npad, MSFM_REDUCE_SUM));
@@ -1608,7 +1618,28 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   }
   // identity on the padding columns (after the exchange: they are not part of it)
   if (ba->n_padcol) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(ba->n_padcol, 256)), dim3(256), 0, s, ba->n_padcol, ba->padcol.p, ba->M.p, ba->npad);
-  MSFM_TRY(allreduce(ba, ba->scal.p + S_GMAX, 2, MSFM_REDUCE_MAX));
+  return MSFM_OK;
+}
+
+__global__ void k_scal_pack(const double* __restrict__ sloc, double* __restrict__ scal, int rank, int world) {
+  const int i = threadIdx.x;
+  if (i < S_GMAX) scal[i] = sloc[i];
+  if (i < world) scal[S_RANK0 + i] = i == rank ? sloc[S_GMAX] : 0.0;
+}
+__global__ void k_scal_unpack(double* __restrict__ scal, int world) {
+  double g = 0.0;  // gradient norms are non-negative
+  for (int r = 0; r < world; r++) g = fmax(g, scal[S_RANK0 + r]);
+  scal[S_GMAX] = g;
+}
+
+// all scalars of the iteration over the ranks, in one sum (see the enum)
+static int reduce_scalars(msfm_ba* ba) {
+  msfm_ctx* ctx = ba->ctx;
+  if (ctx->world <= 1) return MSFM_OK;
+  if (S_RANK0 + ctx->world > S_N) return msfm_set_error(ctx, MSFM_E_INVAL, "too many ranks for the scalar block");
+  hipLaunchKernelGGL(k_scal_pack, dim3(1), dim3(64), 0, ctx->stream, ba->sloc.p, ba->scal.p, ctx->rank, ctx->world);
+  MSFM_TRY(allreduce(ba, ba->scal.p, (size_t)S_RANK0 + ctx->world, MSFM_REDUCE_SUM));
+  hipLaunchKernelGGL(k_scal_unpack, dim3(1), dim3(1), 0, ctx->stream, ba->scal.p, ctx->world);
   return MSFM_OK;
 }
 
@@ -1662,16 +1693,14 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
                          ba->lin_Jc.p, ba->lin_Jm.p, ba->z.p, ngps ? 1 : 0, ba->g_r.p, ba->g_J.p, ba->partial.p + moff);
       moff += cdiv(nrest, 256);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, moff, ba->scal.p, S_MCC, 0);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial2.p, off, ba->scal.p, S_DX2, 0);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial3.p, off, ba->scal.p, S_X2, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, moff, ba->swrite, S_MCC, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial2.p, off, ba->swrite, S_DX2, 0);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial3.p, off, ba->swrite, S_X2, 0);
   }
   MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/false, opt->huber_delta, S_COST));
-  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->scal.p, S_FAIL);
+  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->swrite, S_FAIL);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "solve launch: %s", hipGetErrorString(e));
-  MSFM_TRY(allreduce(ba, ba->scal.p + S_COST, 4, MSFM_REDUCE_SUM));
-  MSFM_TRY(allreduce(ba, ba->scal.p + S_FAIL, 1, MSFM_REDUCE_MAX));
   return MSFM_OK;
 }
 
@@ -1718,7 +1747,6 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     if (npb) hipLaunchKernelGGL(k_make_scale, dim3(cdiv(3 * npb, 256)), dim3(256), 0, s, 3 * npb, ba->diag_p.p, ba->scale_p.p);
     MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
   }
-  MSFM_TRY(allreduce(ba, ba->scal.p + S_XCOST, 1, MSFM_REDUCE_SUM));
   int iteration = 0, num_invalid = 0, termination = 0;
   // The reduced system and the trust-region step computed from it are enqueued back to back and
   // their scalars read with ONE host synchronisation per LM iteration: the step is speculative
@@ -1726,6 +1754,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   auto assemble_and_step = [&]() -> int {
     MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0));
     if (iteration < opt->max_num_iterations && radius > opt->min_trust_region_radius) MSFM_TRY(run_solve(ba, opt));
+    MSFM_TRY(reduce_scalars(ba));
     MSFM_TRY(read_scalars(ba));
     return MSFM_OK;
   };
@@ -1786,7 +1815,6 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
     if (relinearise) {
       MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
-      MSFM_TRY(allreduce(ba, ba->scal.p + S_XCOST, 1, MSFM_REDUCE_SUM));
     }
     MSFM_TRY(assemble_and_step());
     if (relinearise) {

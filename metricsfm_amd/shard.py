@@ -76,15 +76,24 @@ class TorchAllReduce:
         self.backend = dist.get_backend(group)
         self.calls = 0
         self.bytes = 0
+        self._streams, self._views = {}, {}
 
     def __call__(self, buf_ptr, count, op, stream_ptr):
         torch, dist = self.torch, self.dist
         rop = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
         self.calls += 1
         self.bytes += 8 * count
-        ext = torch.cuda.ExternalStream(stream_ptr, device=self.device)
+        # the library reduces the same few device buffers every LM iteration: wrap each (pointer, count) and the
+        # stream once, the hook then costs one dictionary lookup plus the collective's own dispatch
+        ext = self._streams.get(stream_ptr)
+        if ext is None:
+            ext = self._streams[stream_ptr] = torch.cuda.ExternalStream(stream_ptr, device=self.device)
         with torch.cuda.stream(ext):
-            t = torch.as_tensor(_DevPtr(buf_ptr, count), device=self.device)
+            t = self._views.get((buf_ptr, count))
+            if t is None:
+                t = self._views[(buf_ptr, count)] = torch.as_tensor(_DevPtr(buf_ptr, count), device=self.device)
+                if len(self._views) > 64:   # buffers of destroyed problems
+                    self._views = {(buf_ptr, count): t}
             if self.backend == "nccl":
                 dist.all_reduce(t, op=rop, group=self.group)  # ordered after / before work on `ext`
             else:

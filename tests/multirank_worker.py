@@ -18,6 +18,9 @@ def main():
     if which == "gps":
         sc = scene.make_aerial_scene(20, 2500, seed=21, gps_sigma=0.5, rot_sigma=0.02, trans_sigma=0.3, point_sigma=0.2)
         kw = dict(gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams))
+    elif which == "c3":   # manual check at full size (not part of the suite)
+        sc = scene.config_scene(3)
+        kw = {}
     elif which == "domains":
         # >= 128 cameras: the union camera graph is bisected identically on every rank (MSFM_CHOL_DOMAINS forced by the test)
         sc = scene.make_aerial_scene(150, 5000, seed=8)
@@ -30,7 +33,7 @@ def main():
     ctx = capi.Context(0)
     hook = shard.TorchAllReduce(dist, 0)
     ctx.set_allreduce(hook, rank, world)
-    opts = capi.default_options(max_num_iterations=40)
+    opts = capi.default_options(max_num_iterations=12 if which == "c3" else 40)
     res = ctx.ba_solve(mine, opts)
     # gather the points back (host concatenation; cameras are replicated and must agree bitwise)
     pts = [None] * world

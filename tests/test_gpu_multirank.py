@@ -27,4 +27,4 @@ def test_sharded_ba_matches_single_rank(tmp_path, world, which, port):
     np.testing.assert_allclose(r["cost"], r["cost1"], rtol=1e-9)
     for a, b in (("point", "point1"), ("cam", "cam1"), ("model", "model1")):
         assert np.abs(r[a] - r[b]).max() <= 1e-8 * np.abs(r[b]).max(), a
-    assert r["calls"] > 4 * r["it"]  # the hook really carried the reduction
+    assert r["calls"] >= 3 * r["it"]  # the hook really carried the reduction (3 sums per LM iteration)
