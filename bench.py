@@ -161,19 +161,18 @@ def main():
     lay = ba.layout()
     if st:
         dense_flops = n_red ** 3 / 3.0
+        # `achieved` follows the contract: ALGORITHMIC flops of the path (the dense factorisation, n^3/3) per launch
+        # / launch time.  With camera domains the kernel executes fewer flops for the same result; that figure is given beside it.
+        exe_flops = dense_flops
+        note = ("n^3/3 = %.2f GFLOP per factorisation (SURVEY 8d) spread over %d panel launches (trailing update + next potrf + trsm fused)"
+                % (dense_flops / 1e9, st["launches"] // max(1, n_solves)))
         if lay["n_domains"] > 1:
             sep = lay["separator_cols"] + 1
             exe_flops = sep ** 3 / 3.0 + sum(nk ** 3 / 3.0 + nk * nk * sep + nk * sep * sep for nk in lay["domain_cols"])
-            note = ("%.2f GFLOP executed per factorisation (%d camera domains of %s columns factored side by side, then the %d-column "
-                    "separator; the dense order of the reference would be n^3/3 = %.2f GFLOP) over %d panel launches"
-                    % (exe_flops / 1e9, lay["n_domains"], lay["domain_cols"], lay["separator_cols"], dense_flops / 1e9,
-                       st["launches"] // max(1, n_solves)))
-        else:
-            exe_flops = dense_flops
-            note = ("n^3/3 = %.2f GFLOP per factorisation spread over %d panel launches (trailing update + next potrf + trsm fused)"
-                    % (dense_flops / 1e9, st["launches"] // max(1, n_solves)))
-        add("chol_panel_mfma", "mfma", exe_flops * n_solves / max(1, st["launches"]), note)
-        rooflines["chol_panel_mfma"]["dense_equivalent_tflops"] = dense_flops * n_solves / (st["total_ms"] * 1e-3) / 1e12
+            note += ("; %d camera domains of %s columns are factored side by side, then the %d-column separator: %.2f GFLOP actually executed"
+                     % (lay["n_domains"], lay["domain_cols"], lay["separator_cols"], exe_flops / 1e9))
+        add("chol_panel_mfma", "mfma", dense_flops * n_solves / max(1, st["launches"]), note)
+        rooflines["chol_panel_mfma"]["executed_tflops"] = exe_flops * n_solves / (st["total_ms"] * 1e-3) / 1e12
         rooflines["chol_panel_mfma"]["layout"] = lay
     add("ba_linearize", "hbm", sc.n_obs * (24 + 16 + 46 * 8), "bytes read + written per linearisation")
     add("ba_point", "hbm", sc.n_obs * 44 * 8 + sc.n_points * 12 * 8, "SoA Jacobians in, T / T.u records out")
