@@ -401,6 +401,41 @@ std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<Pair
   return out;
 }
 
+// ---- track building -------------------------------------------------------------------------------
+std::vector<Point3D> BuildTracks(const std::string& fold, const std::vector<std::vector<int>>& match_graph, std::vector<Camera>& cams,
+                                 const std::vector<std::vector<Vec2>>& keypoints) {
+  const int n_img = (int)match_graph.size();
+  std::vector<int> n_feat(n_img), pair_img, off{0}, flat;
+  for (int i = 0; i < n_img; i++) n_feat[i] = (int)keypoints[i].size();
+  for (int i = 0; i < n_img; i++) {
+    std::vector<int> ids;
+    std::vector<std::vector<std::pair<int, int>>> recs;
+    QueryMatch(fold, i, ids, recs);  // the file of image i holds one record per matched image
+    for (int j = 0; j < n_img; j++) {
+      if (match_graph[i][j] <= 0) continue;  // slam_gps.cc:571-575
+      for (size_t r = 0; r < ids.size(); r++) {
+        if (ids[r] != j) continue;
+        pair_img.push_back(i); pair_img.push_back(j);
+        for (auto& m : recs[r]) { flat.push_back(m.first); flat.push_back(m.second); }
+        off.push_back((int)flat.size() / 2);
+        break;
+      }
+    }
+  }
+  msfm_track_set* set = nullptr;
+  check(msfm_tracks_build(n_img, n_feat.data(), (int)pair_img.size() / 2, pair_img.data(), off.data(), flat.data(), &set), "tracks_build");
+  int nt = 0, no = 0;
+  msfm_track_set_size(set, &nt, &no);
+  std::vector<int> toff(nt + 1), oi(std::max(1, no)), of(std::max(1, no));
+  msfm_track_set_fetch(set, toff.data(), oi.data(), of.data());
+  msfm_track_set_destroy(set);
+  std::vector<Point3D> pts(nt);
+  for (int t = 0; t < nt; t++)
+    for (int e = toff[t]; e < toff[t + 1]; e++)
+      pts[t].AddObservation(&cams[oi[e]], keypoints[oi[e]][of[e]].x, keypoints[oi[e]][of[e]].y, oi[e]);
+  return pts;
+}
+
 // ---- match files ---------------------------------------------------------------------------------
 void WriteOutMatches(const std::string& fold, int idx1, int idx2, const std::vector<std::pair<int, int>>& matches) {
   const int num_match = (int)matches.size();

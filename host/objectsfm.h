@@ -159,6 +159,13 @@ class GeoVerification {
 std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<PairMatches>& matches,
                                                           const std::vector<std::vector<Point2f>>& keypoints);
 
+// Track building, the data association of SLAMGPS::Triangulation (slam_gps.cc:565-635): walk the match graph in the
+// reference's order (idx1 ascending, idx2 ascending over match_graph[idx1][idx2] > 0, matches read back with
+// QueryMatch) and grow points greedily - msfm_tracks_build keeps the std::map::insert semantics.  Returns the new
+// points with their observations attached (AddObservation(cam, x, y, image id), as :600-603 keys them).
+std::vector<Point3D> BuildTracks(const std::string& output_fold, const std::vector<std::vector<int>>& match_graph,
+                                 std::vector<Camera>& cams, const std::vector<std::vector<Vec2>>& keypoints);
+
 // The reference's stage boundary is a set of files: per image `<idx1>_match` (binary records
 // int idx2, int n, int[2n]) and `graph_matching.txt`.  Same bytes as FineMatchingGraph::WriteOutMatches /
 // WriteOutMatchGraph (fine_matching_graph.cc:247-292) and Graph::QueryMatch (graph.cc:92-137).

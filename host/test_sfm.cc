@@ -118,19 +118,23 @@ int main() {
   std::vector<std::vector<std::pair<int, int>>> m0;
   QueryMatch(fold, 0, ids0, m0);  // Graph::QueryMatch, graph.cc:92-121
   if ((int)ids0.size() != n_cams - 1) { std::printf("FAIL: match files\n"); return 1; }
-  // --- stage 2: tracks from the matches against image 0 (union over pairs (0, j)), Trianglate2 ---
-  std::vector<Point3D> pts(n_pts);
-  std::vector<char> has0(n_pts, 0);
-  for (size_t rec = 0; rec < ids0.size(); rec++) {
-    PairMatches pm; pm.idx1 = 0; pm.idx2 = ids0[rec]; pm.matches_good = m0[rec];
-    for (auto& m : pm.matches_good) {
-      const int id = m.first;  // feature id in image 0 names the track
-      if (!has0[id]) { pts[id].AddObservation(&cams[0], kp[0][id].x, kp[0][id].y, id); has0[id] = 1; }
-      pts[id].AddObservation(&cams[pm.idx2], kp[pm.idx2][m.second].x, kp[pm.idx2][m.second].y, m.second + pm.idx2 * 1000000);
+  // --- stage 2: tracks from the whole match graph (SLAMGPS::Triangulation's data association, slam_gps.cc:565-635), Trianglate2 ---
+  std::vector<Point3D> pts = BuildTracks(fold, match_graph, cams, kp);
+  size_t pure = 0;
+  for (auto& p : pts) {   // with verified matches a track never mixes two scene points
+    int first = -1; bool same = true;
+    for (auto& o : p.pts2d_) {
+      int f = -1;
+      for (size_t m = 0; m < kp[o.first].size(); m++) if (kp[o.first][m].x == o.second.x && kp[o.first][m].y == o.second.y) { f = (int)m; break; }
+      const int sp = f >= 0 ? feat_pt[o.first][f] : -2;
+      if (first < 0) first = sp; else same = same && sp == first;
     }
+    pure += same;
   }
+  std::printf("tracks: %zu points from the match graph, %zu pure\n", pts.size(), pure);
+  if (pts.size() < (size_t)n_pts || pure < 0.99 * pts.size()) { std::printf("FAIL: track building\n"); return 1; }
   std::vector<Point3D*> pp;
-  for (auto& p : pts) if (p.cams_.size() >= 2) pp.push_back(&p);
+  for (auto& p : pts) if (p.cams_.size() >= 3) pp.push_back(&p);  // fewer than 3 views -> bad (slam_gps.cc:642)
   std::vector<char> ok;
   TrianglateBatch(pp, 7.0, 3.0 / 180.0 * M_PI, /*dlt=*/false, &ok);  // thresholds of sfm_incremental.cc:780-784
   size_t n_ok = 0;

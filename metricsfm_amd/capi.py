@@ -23,7 +23,7 @@ SYMBOLS = [
     "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ba_get_layout", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
-    "msfm_epipolar_filter_batch",
+    "msfm_epipolar_filter_batch", "msfm_tracks_build", "msfm_track_set_size", "msfm_track_set_fetch", "msfm_track_set_destroy",
 ]
 
 
@@ -87,6 +87,11 @@ def lib():
     L.msfm_fundamental_ransac_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, C.POINTER(A.FransacOptions),
                                                 A.c_double_p, A.c_u8_p, A.c_int_p, A.c_u8_p]
     L.msfm_epipolar_filter_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, A.c_double_p, A.c_u8_p, d, A.c_u8_p]
+    L.msfm_tracks_build.argtypes = [i, A.c_int_p, i, A.c_int_p, A.c_int_p, A.c_int_p, C.POINTER(vp)]
+    L.msfm_track_set_size.argtypes = [vp, A.c_int_p, A.c_int_p]
+    L.msfm_track_set_fetch.argtypes = [vp, A.c_int_p, A.c_int_p, A.c_int_p]
+    L.msfm_track_set_destroy.argtypes = [vp]
+    L.msfm_track_set_destroy.restype = None
     _lib = L
     return L
 
@@ -99,6 +104,36 @@ def default_options(**kw):
             raise AttributeError(k)
         setattr(o, k, v)
     return o
+
+
+def build_tracks(n_features, pairs, matches_per_pair):
+    """SLAMGPS::Triangulation's data association (slam_gps.cc:565-635).  n_features[image]; pairs [(idx1, idx2)] in visiting
+    order; matches_per_pair[p] = int array [m][2] (feature in idx1, feature in idx2).
+    Returns CSR tracks: track_off, obs_image, obs_feature (observations in ascending image order)."""
+    nf = A.as_c(np.asarray(n_features, dtype=np.int32), np.int32)
+    pr = A.as_c(np.asarray(pairs, dtype=np.int32).reshape(-1, 2), np.int32)
+    off = np.zeros(len(pr) + 1, dtype=np.int32)
+    for p, m in enumerate(matches_per_pair):
+        off[p + 1] = off[p] + len(m)
+    flat = np.zeros((max(1, off[-1]), 2), dtype=np.int32)
+    for p, m in enumerate(matches_per_pair):
+        if len(m):
+            flat[off[p]:off[p + 1]] = np.asarray(m, dtype=np.int32).reshape(-1, 2)
+    flat = A.as_c(flat, np.int32)
+    h = C.c_void_p()
+    rc = lib().msfm_tracks_build(len(nf), A.ptr(nf, A.c_int_p), len(pr), A.ptr(pr, A.c_int_p), A.ptr(off, A.c_int_p),
+                                 A.ptr(flat, A.c_int_p), C.byref(h))
+    if rc != 0:
+        raise MsfmError(rc, "msfm_tracks_build: invalid input")
+    try:
+        nt, no = C.c_int32(), C.c_int32()
+        lib().msfm_track_set_size(h, C.byref(nt), C.byref(no))
+        toff = np.zeros(nt.value + 1, dtype=np.int32)
+        oi, of = np.zeros(max(1, no.value), dtype=np.int32), np.zeros(max(1, no.value), dtype=np.int32)
+        lib().msfm_track_set_fetch(h, A.ptr(toff, A.c_int_p), A.ptr(oi, A.c_int_p), A.ptr(of, A.c_int_p))
+    finally:
+        lib().msfm_track_set_destroy(h)
+    return toff, oi[:no.value], of[:no.value]
 
 
 def fransac_options(**kw):

@@ -180,6 +180,41 @@ def fundamental_ransac(offsets, pt1, pt2, threshold=3.0, confidence=0.99, max_it
     return F, inl[:len(pt1)], nin[:n], ok[:n]
 
 
+def build_tracks(pairs, matches_per_pair, idx_max_per_image=1000000):
+    """SLAMGPS::Triangulation's data association, slam_gps.cc:565-635, restated literally: one map from the global
+    feature id (local + image * idx_max_per_image) to a point, points hold {image: feature} maps filled with
+    insert-if-absent (std::map::insert).  Pure Python: for small cases only.
+    Returns CSR tracks (track_off, obs_image, obs_feature), observations in ascending image (= map key) order."""
+    pts_points_map = {}
+    pts = []   # each: dict image -> feature (Point3D::cams_ / pts2d_ are keyed by the image id here, slam_gps.cc:600-603)
+    for (id_img1, id_img2), matches in zip(pairs, matches_per_pair):
+        for id_pt1_local, id_pt2_local in matches:
+            g1 = int(id_pt1_local) + int(id_img1) * idx_max_per_image
+            g2 = int(id_pt2_local) + int(id_img2) * idx_max_per_image
+            if g1 in pts_points_map:
+                id_pt = pts_points_map[g1]
+                pts[id_pt].setdefault(int(id_img2), int(id_pt2_local))
+                pts_points_map.setdefault(g2, id_pt)
+            elif g2 in pts_points_map:
+                id_pt = pts_points_map[g2]
+                pts[id_pt].setdefault(int(id_img1), int(id_pt1_local))
+                pts_points_map.setdefault(g1, id_pt)
+            else:
+                pt = {}
+                pt.setdefault(int(id_img1), int(id_pt1_local))
+                pt.setdefault(int(id_img2), int(id_pt2_local))
+                pts.append(pt)
+                pts_points_map.setdefault(g1, len(pts) - 1)
+                pts_points_map.setdefault(g2, len(pts) - 1)
+    off, img, feat = [0], [], []
+    for pt in pts:
+        for k in sorted(pt):
+            img.append(k)
+            feat.append(pt[k])
+        off.append(len(img))
+    return np.array(off, np.int32), np.array(img, np.int32), np.array(feat, np.int32)
+
+
 def knn2(train, query, fast=False):
     train, query = np.ascontiguousarray(train, dtype=np.float32), np.ascontiguousarray(query, dtype=np.float32)
     ids = np.zeros((len(query), 2), dtype=np.int32)

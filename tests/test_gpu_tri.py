@@ -64,3 +64,27 @@ def test_epipolar_filter(ctx, oracle):
     p2 = (rng.standard_normal((5000, 2)) * 800).astype(np.float32)
     np.testing.assert_array_equal(ctx.epipolar_filter(p1, p2, F, 3.0), oracle.epipolar_filter(p1, p2, F, 3.0))
     assert ctx.epipolar_filter(p1[:0], p2[:0], F).shape == (0,)
+
+
+def test_tracks_to_triangulated_points(ctx, oracle):
+    """Match graph -> tracks (slam_gps.cc:565-635) -> one batched Trianglate2 call with the 3-view rule (:637-648)."""
+    from metricsfm_amd import capi, tracks
+    sc = scene.make_aerial_scene(14, 600, seed=9)
+    n_feat, keyp, pairs, matches = tracks.matches_from_scene(sc)
+    off, img, feat = capi.build_tracks(n_feat, pairs, matches)
+    o_off, o_img, o_feat = oracle.build_tracks(pairs, matches)
+    np.testing.assert_array_equal(off, o_off); np.testing.assert_array_equal(img, o_img); np.testing.assert_array_equal(feat, o_feat)
+    assert len(off) - 1 == sc.n_points                      # consistent matches: one track per scene point
+    R, t, c, fk = scene.cameras_for_tracks(sc)
+    X, mse, bad = tracks.triangulate_tracks(ctx, off, img, feat, keyp, R, t, c, fk, th_outlier=7.0)
+    xy = np.concatenate([keyp[i][f][None] for i, f in zip(img, feat)])
+    Xo, mo, oko = oracle.triangulate_midpoint(A.TrackArrays(off, img, xy, R, t, c, fk), 7.0, np.deg2rad(3.0))
+    np.testing.assert_array_equal(bad, (oko == 0) | (np.diff(off) < 3))
+    np.testing.assert_allclose(X, Xo, rtol=1e-9, atol=1e-9)
+    # every track is one scene point: its first observation names it
+    first_obs = {}
+    for o in range(sc.n_obs):
+        first_obs.setdefault((int(sc.obs_cam[o]), tuple(sc.obs_xy[o])), int(sc.obs_pt[o]))
+    pid = np.array([first_obs[(int(img[off[k]]), tuple(keyp[img[off[k]]][feat[off[k]]]))] for k in range(len(off) - 1)])
+    good = ~bad
+    assert good.mean() > 0.5 and np.abs(X[good] - sc.point_gt[pid[good]]).max() < 1.0
