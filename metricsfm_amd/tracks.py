@@ -44,3 +44,49 @@ def matches_from_scene(sc, pairs=None):
         out_pairs.append((i, j))
         matches.append(np.array([[feat_of[i][p], feat_of[j][p]] for p in common], dtype=np.int32))
     return [len(k) for k in keyp], keyp, out_pairs, matches
+
+
+def generate_new_points(ctx: capi.Context, cam1, visible_cams, matches_per_cam, done1, done2_per_cam, keypoints, cam_R, cam_t, cam_c,
+                        cam_fk, th_mse_reprojection=3.0, th_angle_small=3.0 / 180.0 * 3.1415, th_angle_large=5.0 / 180.0 * 3.1415):
+    """IncrementalSfM::GenerateNew3DPoints (sfm_incremental.cc:755-915) for the newest camera `cam1`: every match with a
+    visible camera whose two features are not triangulated yet becomes a two-view candidate; Trianglate2 with
+    th_angle_small, or th_angle_large when the pair has more than 500 matches (:780-784); accepted candidates are sorted
+    by their mse TRUNCATED to an integer (the reference stores it through a pair<.., int>, :828) - stable here.
+    All candidates of all visible cameras go through at most two batched GPU calls (one per angle threshold).
+
+    matches_per_cam[k] = [m][2] (feature in cam1, feature in visible_cams[k]); done1[f] / done2_per_cam[k][f] = already
+    triangulated.  Returns X [n][3], mse [n], cam2 [n], feat1 [n], feat2 [n] in the order the reference appends them to pts_."""
+    cand = []   # (cam2, f1, f2, large?)
+    for k, cam2 in enumerate(visible_cams):
+        if cam2 == cam1:
+            continue
+        m = np.asarray(matches_per_cam[k], dtype=np.int64).reshape(-1, 2)
+        large = len(m) > 500
+        d2 = np.asarray(done2_per_cam[k], dtype=bool)
+        for f1, f2 in m:
+            if done1[f1] or d2[f2]:
+                continue
+            cand.append((cam2, int(f1), int(f2), large))
+    if not cand:
+        z = np.zeros(0, dtype=np.int64)
+        return np.zeros((0, 3)), np.zeros(0), z, z, z
+    cand = np.array(cand, dtype=np.int64)
+    n = len(cand)
+    X, mse, ok = np.zeros((n, 3)), np.zeros(n), np.zeros(n, dtype=np.uint8)
+    k1 = np.asarray(keypoints[cam1], dtype=np.float64)
+    for large, th in ((0, th_angle_small), (1, th_angle_large)):
+        sel = np.nonzero(cand[:, 3] == large)[0]
+        if len(sel) == 0:
+            continue
+        cam = np.column_stack([np.full(len(sel), cam1), cand[sel, 0]]).reshape(-1)
+        xy = np.zeros((2 * len(sel), 2))
+        xy[0::2] = k1[cand[sel, 1]]
+        for c2 in np.unique(cand[sel, 0]):
+            s2 = cand[sel, 0] == c2
+            xy[1::2][s2] = np.asarray(keypoints[c2], dtype=np.float64)[cand[sel, 2][s2]]
+        tr = A.TrackArrays(2 * np.arange(len(sel) + 1, dtype=np.int32), cam.astype(np.int32), xy, cam_R, cam_t, cam_c, cam_fk)
+        Xs, ms, oks = ctx.triangulate_midpoint(tr, th_mse_reprojection, th)
+        X[sel], mse[sel], ok[sel] = Xs, ms, oks
+    keep = np.nonzero(ok)[0]
+    order = keep[np.argsort(np.trunc(mse[keep]).astype(np.int64), kind="stable")]
+    return X[order], mse[order], cand[order, 0], cand[order, 1], cand[order, 2]

@@ -215,6 +215,31 @@ def build_tracks(pairs, matches_per_pair, idx_max_per_image=1000000):
     return np.array(off, np.int32), np.array(img, np.int32), np.array(feat, np.int32)
 
 
+def generate_new_points(cam1, visible_cams, matches_per_cam, done1, done2_per_cam, keypoints, cam_R, cam_t, cam_c, cam_fk,
+                        th_mse_reprojection=3.0, th_angle_small=3.0 / 180.0 * 3.1415, th_angle_large=5.0 / 180.0 * 3.1415):
+    """IncrementalSfM::GenerateNew3DPoints, sfm_incremental.cc:755-915, restated literally: one Trianglate2 per candidate."""
+    out = []
+    for k, cam2 in enumerate(visible_cams):
+        if cam2 == cam1:
+            continue
+        matches = np.asarray(matches_per_cam[k]).reshape(-1, 2)
+        th = th_angle_large if len(matches) > 500 else th_angle_small
+        for f1, f2 in matches:
+            if done1[f1] or done2_per_cam[k][f2]:
+                continue
+            xy = np.array([keypoints[cam1][f1], keypoints[cam2][f2]], dtype=np.float64)
+            tr = A.TrackArrays(np.array([0, 2], np.int32), np.array([cam1, cam2], np.int32), xy, cam_R, cam_t, cam_c, cam_fk)
+            X, mse, ok = triangulate_midpoint(tr, th_mse_reprojection, th)
+            if ok[0]:
+                out.append((int(mse[0]), X[0].copy(), float(mse[0]), int(cam2), int(f1), int(f2)))   # pair<Point3DNew*, int>(.., mse_)
+    out.sort(key=lambda r: r[0])   # stable
+    if not out:
+        z = np.zeros(0, dtype=np.int64)
+        return np.zeros((0, 3)), np.zeros(0), z, z, z
+    return (np.array([r[1] for r in out]), np.array([r[2] for r in out]), np.array([r[3] for r in out]), np.array([r[4] for r in out]),
+            np.array([r[5] for r in out]))
+
+
 def knn2(train, query, fast=False):
     train, query = np.ascontiguousarray(train, dtype=np.float32), np.ascontiguousarray(query, dtype=np.float32)
     ids = np.zeros((len(query), 2), dtype=np.int32)

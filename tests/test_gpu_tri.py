@@ -88,3 +88,31 @@ def test_tracks_to_triangulated_points(ctx, oracle):
     pid = np.array([first_obs[(int(img[off[k]]), tuple(keyp[img[off[k]]][feat[off[k]]]))] for k in range(len(off) - 1)])
     good = ~bad
     assert good.mean() > 0.5 and np.abs(X[good] - sc.point_gt[pid[good]]).max() < 1.0
+
+
+def test_generate_new_points_matches_literal_loop(ctx, oracle):
+    """IncrementalSfM::GenerateNew3DPoints (sfm_incremental.cc:755-915): two batched calls against one Trianglate2 per candidate."""
+    from metricsfm_amd import tracks
+    rng = np.random.default_rng(4)
+    sc = scene.make_aerial_scene(16, 6000, seed=12)
+    n_feat, keyp, pairs, matches = tracks.matches_from_scene(sc)
+    cam1 = 15
+    vis = [j for (i, j) in pairs if i == cam1] + [cam1]          # visible_cams_ contains the camera itself (:1895-1903)
+    mlist = [matches[pairs.index((cam1, j))] if j != cam1 else np.zeros((0, 2), np.int32) for j in vis]
+    # a few wrong matches, and some features already triangulated
+    for m in mlist:
+        if len(m):
+            bad = rng.random(len(m)) < 0.05
+            m[bad, 1] = rng.integers(0, 50, bad.sum())
+    done1 = rng.random(n_feat[cam1]) < 0.3
+    done2 = [rng.random(n_feat[j]) < 0.3 for j in vis]
+    assert any(len(m) > 500 for m in mlist) and any(0 < len(m) <= 500 for m in mlist)   # both angle thresholds are exercised
+    R, t, c, fk = scene.cameras_for_tracks(sc)
+    got = tracks.generate_new_points(ctx, cam1, vis, mlist, done1, done2, keyp, R, t, c, fk, th_mse_reprojection=7.0)
+    want = oracle.generate_new_points(cam1, vis, mlist, done1, done2, keyp, R, t, c, fk, th_mse_reprojection=7.0)
+    assert len(got[0]) == len(want[0]) > 100
+    for g, w in zip(got[2:], want[2:]):
+        np.testing.assert_array_equal(g, w)                      # same candidates, same order
+    np.testing.assert_allclose(got[0], want[0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(got[1], want[1], rtol=1e-7, atol=1e-9)
+    assert (np.diff(np.trunc(got[1])) >= 0).all()
