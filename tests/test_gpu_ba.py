@@ -176,3 +176,23 @@ def test_ba_domain_parallel_factorisation(ctx, oracle, monkeypatch, depth):
         assert _rel(getattr(a_dom, name), getattr(a_dense, name)) < 1e-8, name
     # and against the CPU oracle (dense Schur complement, camera order as given)
     check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc, **kw), okw)
+
+
+def test_ba_disconnected_camera_graph(ctx, oracle, monkeypatch):
+    """Two surveys that share nothing but the camera model: the camera graph has two components, the separator of the
+    bisection is empty and only the intrinsics block (+ rhs) is left for the single chain."""
+    from metricsfm_amd import capi
+    s1 = scene.make_aerial_scene(70, 2500, seed=31)
+    s2 = scene.make_aerial_scene(66, 2200, seed=32)
+
+    def arrays():
+        return A.BaArrays(np.concatenate([s1.cam_pose, s2.cam_pose]), s1.cam_model.copy(),
+                          np.concatenate([s1.cam_model_of_cam, s2.cam_model_of_cam]), np.concatenate([s1.point, s2.point]),
+                          np.concatenate([s1.obs_cam, s2.obs_cam + s1.n_cams]), np.concatenate([s1.obs_pt, s2.obs_pt + s1.n_points]),
+                          np.concatenate([s1.obs_xy, s2.obs_xy]), np.concatenate([s1.pt_weight, s2.pt_weight]))
+
+    monkeypatch.setenv("MSFM_CHOL_DOMAINS", "1")
+    lay = ctx.ba(arrays()).layout()
+    assert lay["n_domains"] == 2 and lay["separator_cols"] == 3          # nothing but f, k1, k2 couples the two surveys
+    assert sorted(lay["domain_cols"]) == [64 * -(-6 * 66 // 64), 64 * -(-6 * 70 // 64)]
+    check_parity(ctx, oracle, arrays, dict(max_num_iterations=10))
