@@ -1066,6 +1066,11 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
       return msfm_set_error(ctx, MSFM_E_INVAL, "obs_pt must be non-decreasing (gather order, optimizer.cc:62)");
   }
   const auto t0 = std::chrono::steady_clock::now();
+  const bool verbose = getenv("MSFM_VERBOSE") != nullptr;
+  auto lap = [&](const char* what) {
+    if (verbose && ctx->rank == 0)
+      fprintf(stderr, "msfm: create %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   msfm_ba* ba = new msfm_ba();
@@ -1205,39 +1210,47 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   }
   ba->has_gps = P->gps_xyz != nullptr;
   ba->gps_weight = P->gps_weight;
+  lap("blocks + orders");
   // ---- active observations: eliminated-point rows first (point-major), then the rest ----
   std::vector<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
   std::vector<double> o_x, o_y, o_w;
   std::vector<int> pt_first(npb + 1, 0);
+  for (auto* v : {&o_cam, &o_model, &o_pt, &o_cb, &o_mb, &o_pb}) v->reserve(No);
+  for (auto* v : {&o_x, &o_y, &o_w}) v->reserve(No);
   // input runs per point (obs_pt is non-decreasing): pass 0 walks the eliminated points in block order
   std::vector<int> run_first(Np + 1, 0);
   for (int o = 0; o < No; o++) run_first[P->obs_pt[o] + 1]++;
   for (int p = 0; p < Np; p++) run_first[p + 1] += run_first[p];
-  std::vector<int> walk;
-  walk.reserve(No);
-  for (int pb = 0; pb < ba->npb; pb++)
-    for (int o = run_first[ba->h_pb_pt[pb]]; o < run_first[ba->h_pb_pt[pb] + 1]; o++) walk.push_back(o);
-  for (int pass = 0; pass < 2; pass++) {
-    const int nwalk = pass == 0 ? (int)walk.size() : No;
-    for (int wi = 0; wi < nwalk; wi++) {
-      const int o = pass == 0 ? walk[wi] : wi;
-      const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
-      const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
-      if (!cm && !pm) continue;
-      if ((pass == 0) != pm) continue;
-      o_cam.push_back(c); o_model.push_back(m); o_pt.push_back(p);
-      o_cb.push_back(cm ? cam_slot[c] : -1);
-      o_mb.push_back((cm && is_mut(P->model_mutable, m)) ? model_slot[m] : -1);
-      o_pb.push_back(pm ? pt_slot[p] : -1);
-      if (pm) pt_first[pt_slot[p] + 1]++;
-      o_x.push_back(P->obs_xy[2 * (size_t)o]); o_y.push_back(P->obs_xy[2 * (size_t)o + 1]);
-      o_w.push_back(P->pt_weight ? P->pt_weight[p] : 1.0);
+  auto take = [&](int o, int pass) {
+    const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
+    const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
+    if (!cm && !pm) return;
+    if ((pass == 0) != pm) return;
+    o_cam.push_back(c); o_model.push_back(m); o_pt.push_back(p);
+    o_cb.push_back(cm ? cam_slot[c] : -1);
+    o_mb.push_back((cm && is_mut(P->model_mutable, m)) ? model_slot[m] : -1);
+    o_pb.push_back(pm ? pt_slot[p] : -1);
+    if (pm) pt_first[pt_slot[p] + 1]++;
+    o_x.push_back(P->obs_xy[2 * (size_t)o]); o_y.push_back(P->obs_xy[2 * (size_t)o + 1]);
+    o_w.push_back(P->pt_weight ? P->pt_weight[p] : 1.0);
+  };
+  // pass 0: the eliminated points in block order (their input runs are scattered: fetch a few points ahead)
+  for (int pb = 0; pb < ba->npb; pb++) {
+    if (pb + 8 < ba->npb) {
+      const int on = run_first[ba->h_pb_pt[pb + 8]];
+      __builtin_prefetch(&P->obs_cam[on]);
+      __builtin_prefetch(&P->obs_xy[2 * (size_t)on]);
+      __builtin_prefetch(&P->obs_xy[2 * (size_t)on + 8]);
     }
-    if (pass == 0) ba->AE = (int)o_cam.size();
+    for (int o = run_first[ba->h_pb_pt[pb]]; o < run_first[ba->h_pb_pt[pb] + 1]; o++) take(o, 0);
   }
+  ba->AE = (int)o_cam.size();
+  // pass 1: observations of frozen points by free cameras, in input order
+  if (P->pt_mutable) for (int o = 0; o < No; o++) take(o, 1);  // (no mask: every point is eliminated)
   for (int i = 0; i < npb; i++) pt_first[i + 1] += pt_first[i];
   const int A = ba->A = (int)o_cam.size();
   ba->n_residuals = 2 * A + (ba->has_gps ? 3 * ncb : 0);
+  lap("active observations");
   // ---- camera-major positions ----
   std::vector<int> cam_first(ncb + 1, 0);
   for (int i = 0; i < A; i++) if (o_cb[i] >= 0) cam_first[o_cb[i] + 1]++;
@@ -1280,6 +1293,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   }
   pm_first[npb] = (int)pm_mb.size();
   const int NPM = ba->NPM = (int)pm_mb.size();
+  lap("positions + pm entries");
   // ---- FTF chunks (camera-major rows) ----
   std::vector<int> f_start, f_end, cam_chunk_first(ncb + 1, 0);
   for (int c = 0; c < ncb; c++) {
@@ -1345,6 +1359,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     // key_first of forced empty blocks must still be monotone: it is (first[k] == first[k+1]).
     return finish_jobs(ba, J, pa, pbv, key_first, brow, bcol, nout);
   };
+  lap("before upload");
   // ---- upload ----
   std::vector<double> gps_cb;
   if (ba->has_gps) {
@@ -1363,7 +1378,9 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   if (ba->has_gps) UP(gps, gps_cb);
 #undef UP
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  lap("uploads");
   MSFM_TRY(build_pairs(0, ba->cc, 36));
+  lap("pairs cc");
   MSFM_TRY(build_pairs(1, ba->mc, 18));
   MSFM_TRY(build_pairs(2, ba->mm, 12));
   if (ctx->world > 1 && ncb > 0 && ncb <= 4096) {
@@ -1434,6 +1451,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   HIP_TRY(ctx, hipMemcpyAsync(ba->model.p, P->cam_model, sizeof(double) * 3 * (size_t)Nm, hipMemcpyHostToDevice, s));
   if (Np) HIP_TRY(ctx, hipMemcpyAsync(ba->pt.p, P->point, sizeof(double) * 3 * (size_t)Np, hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  lap("done");
   ba->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   guard.p = nullptr;
   *out = ba;
