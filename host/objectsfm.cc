@@ -401,6 +401,64 @@ std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<Pair
   return out;
 }
 
+// ---- feature files ---------------------------------------------------------------------------------
+bool WriteoutImageFeature(const std::string& fold, int idx, const ImageInfo& info, const std::vector<Point2f>& kp,
+                          const std::vector<float>& desc, int desc_cols) {
+  std::ofstream ofs(fold + "/" + std::to_string(idx) + "_feature", std::ios::binary);
+  if (!ofs.is_open()) return false;
+  ofs.write((const char*)&info.rows, sizeof(int));
+  ofs.write((const char*)&info.cols, sizeof(int));
+  for (const float* f : {&info.zoom_ratio, &info.f_mm, &info.f_pixel, &info.gps_latitude, &info.gps_longitude}) ofs.write((const char*)f, sizeof(float));
+  for (const std::string* t : {&info.cam_maker, &info.cam_model}) {
+    const int n = (int)t->length();
+    ofs.write((const char*)&n, sizeof(int));
+    ofs.write(t->data(), n);
+  }
+  const int num_pts = (int)kp.size();
+  ofs.write((const char*)&num_pts, sizeof(int));
+  std::vector<float> c(2 * (size_t)num_pts);
+  for (int i = 0; i < num_pts; i++) {  // points are centralized (database.cc:522-527)
+    c[2 * i] = (float)(kp[i].x - info.cols / 2.0);
+    c[2 * i + 1] = (float)(kp[i].y - info.rows / 2.0);
+  }
+  ofs.write((const char*)c.data(), c.size() * sizeof(float));
+  const int rows = desc_cols ? (int)(desc.size() / desc_cols) : 0, type = 5;  // CV_32FC1
+  ofs.write((const char*)&rows, sizeof(int));
+  ofs.write((const char*)&desc_cols, sizeof(int));
+  ofs.write((const char*)&type, sizeof(int));
+  ofs.write((const char*)desc.data(), desc.size() * sizeof(float));
+  return true;
+}
+
+bool ReadinImageFeatures(const std::string& fold, int idx, ImageInfo& info, std::vector<Point2f>& kp, std::vector<float>& desc,
+                         int& desc_cols) {
+  std::ifstream ifs(fold + "/" + std::to_string(idx) + "_feature", std::ios::binary);
+  if (!ifs.is_open()) return false;
+  ifs.read((char*)&info.rows, sizeof(int));
+  ifs.read((char*)&info.cols, sizeof(int));
+  for (float* f : {&info.zoom_ratio, &info.f_mm, &info.f_pixel, &info.gps_latitude, &info.gps_longitude}) ifs.read((char*)f, sizeof(float));
+  for (std::string* t : {&info.cam_maker, &info.cam_model}) {
+    int n = 0;
+    ifs.read((char*)&n, sizeof(int));
+    t->assign((size_t)std::max(0, n), '\0');
+    ifs.read(&(*t)[0], n);
+  }
+  int num_pts = 0;
+  ifs.read((char*)&num_pts, sizeof(int));
+  std::vector<float> c(2 * (size_t)std::max(0, num_pts));
+  ifs.read((char*)c.data(), c.size() * sizeof(float));
+  kp.resize(num_pts);
+  for (int i = 0; i < num_pts; i++) { kp[i].x = c[2 * i]; kp[i].y = c[2 * i + 1]; }
+  int rows = 0, type = 0;
+  ifs.read((char*)&rows, sizeof(int));
+  ifs.read((char*)&desc_cols, sizeof(int));
+  ifs.read((char*)&type, sizeof(int));
+  if (type != 5) return false;  // only CV_32FC1 descriptors (database.cc:412-418)
+  desc.resize((size_t)rows * desc_cols);
+  ifs.read((char*)desc.data(), desc.size() * sizeof(float));
+  return (bool)ifs;
+}
+
 // ---- track building -------------------------------------------------------------------------------
 std::vector<Point3D> BuildTracks(const std::string& fold, const std::vector<std::vector<int>>& match_graph, std::vector<Camera>& cams,
                                  const std::vector<std::vector<Vec2>>& keypoints) {

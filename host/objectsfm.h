@@ -159,6 +159,18 @@ class GeoVerification {
 std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<PairMatches>& matches,
                                                           const std::vector<std::vector<Point2f>>& keypoints);
 
+// The per-image feature file of the extraction stage (Database::WriteoutImageFeature / ReadinImageFeatures,
+// SfM/src/database.cc:490-541, :352-423): header, centred keypoints, raw descriptors.  cv::Mat -> flat float rows.
+struct ImageInfo {  // basic_structs.h ImageInfo
+  int rows = 0, cols = 0;
+  float zoom_ratio = 1.f, f_mm = 0.f, f_pixel = 0.f, gps_latitude = 0.f, gps_longitude = 0.f;
+  std::string cam_maker, cam_model;
+};
+bool WriteoutImageFeature(const std::string& output_fold, int idx, const ImageInfo& info, const std::vector<Point2f>& keypoints_px,
+                          const std::vector<float>& descriptors /*[n][cols]*/, int desc_cols = 128);
+bool ReadinImageFeatures(const std::string& output_fold, int idx, ImageInfo& info, std::vector<Point2f>& keypoints_centred,
+                         std::vector<float>& descriptors, int& desc_cols);
+
 // Track building, the data association of SLAMGPS::Triangulation (slam_gps.cc:565-635): walk the match graph in the
 // reference's order (idx1 ascending, idx2 ascending over match_graph[idx1][idx2] > 0, matches read back with
 // QueryMatch) and grow points greedily - msfm_tracks_build keeps the std::map::insert semantics.  Returns the new

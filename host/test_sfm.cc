@@ -72,6 +72,20 @@ int main() {
       for (int k = 0; k < 128; k++) desc[i][(size_t)m * 128 + k] = std::min(255.f, std::max(0.f, base[p][k] + noise(gen)));
     }
   }
+  // --- stage 0: the extraction stage hands over <idx>_feature files (database.cc:490-541): write them, read them back ---
+  char tmpl[] = "/tmp/msfm_test_sfm_XXXXXX";
+  const std::string fold = mkdtemp(tmpl) ? std::string(tmpl) : std::string("/tmp");
+  for (int i = 0; i < n_cams; i++) {
+    ImageInfo info;
+    info.rows = H; info.cols = W; info.f_pixel = (float)f; info.cam_maker = "synthetic"; info.cam_model = "pinhole";
+    std::vector<Point2f> px(kp[i].size());
+    for (size_t m = 0; m < px.size(); m++) { px[m].x = (float)(kp[i][m].x + W / 2.0); px[m].y = (float)(kp[i][m].y + H / 2.0); }
+    if (!WriteoutImageFeature(fold, i, info, px, desc[i])) { std::printf("FAIL: feature file write\n"); return 1; }
+    ImageInfo back; std::vector<Point2f> kc; std::vector<float> d; int dc = 0;
+    if (!ReadinImageFeatures(fold, i, back, kc, d, dc) || dc != 128 || d != desc[i] || back.cols != W || back.cam_model != "pinhole" ||
+        kc.size() != px.size() || std::fabs(kc[0].x - (float)kp[i][0].x) > 1e-3f) { std::printf("FAIL: feature file read\n"); return 1; }
+    desc[i] = d;  // matching runs on what came back from disk
+  }
   // --- stage 1: matching, matching_type = "all" (test_sfm.cc:50; initial_matching_graph.cc:55-63) ---
   std::vector<std::pair<int, int>> pairs;
   for (int i = 0; i < n_cams; i++) for (int j = 0; j < n_cams; j++) if (i != j) pairs.push_back({i, j});
@@ -104,8 +118,6 @@ int main() {
     if (!GeoVerification::GeoVerificationFundamental(a, b, inl, Fm)) { std::printf("FAIL: GeoVerificationFundamental\n"); return 1; }
   }
   // the reference hands matches to the SfM stage through files: write the verified ones, read image 0's back
-  char tmpl[] = "/tmp/msfm_test_sfm_XXXXXX";
-  const std::string fold = mkdtemp(tmpl) ? std::string(tmpl) : std::string("/tmp");
   std::vector<std::vector<int>> match_graph(n_cams, std::vector<int>(n_cams, 0));
   for (size_t p = 0; p < matches.size(); p++) {
     auto& pm = matches[p];

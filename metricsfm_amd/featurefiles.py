@@ -1,0 +1,108 @@
+"""The reference's per-image feature file and its Bundler export, so that datasets produced by
+the reference's extraction stage can feed libmsfm and libmsfm's results can feed the reference's downstream tools.
+
+  <output_fold>/<idx>_feature   binary (Database::WriteoutImageFeature / ReadinImageFeatures, SfM/src/database.cc:490-541, :352-423):
+      int32 rows, int32 cols, float32 zoom_ratio, float32 f_mm, float32 f_pixel, float32 gps_latitude, float32 gps_longitude,
+      int32 len + bytes cam_maker, int32 len + bytes cam_model,
+      int32 n, float32[2n] keypoints CENTRED (x - cols/2.0, y - rows/2.0; the writer centres, the reader does not undo it),
+      int32 rows, int32 cols, int32 OpenCV type, raw descriptor bytes (CV_32FC1 = 5 for SIFT, database.cc:412-418)
+  bundle.rd.out                 text, "# Bundle file v0.3" (IncrementalSfM::SaveForCMVS, sfm_incremental.cc:1302-1353): fixed, 8 decimals;
+      per camera f k1 k2 / R (row-major, 9 values) / t; per point X Y Z / 255 255 255 / view list, where the reference
+      truncates the image coordinates to int before printing them as float (:1342-1345).
+Native little-endian, as the reference writes them with ofstream::write."""
+import os
+import struct
+
+import numpy as np
+
+CV_8U, CV_32F = 0, 5
+_ELEM = {0: (np.uint8, 1), 1: (np.int8, 1), 2: (np.uint16, 2), 3: (np.int16, 2), 4: (np.int32, 4), 5: (np.float32, 4), 6: (np.float64, 8)}
+
+
+def feature_file(fold, idx):
+    return os.path.join(fold, "%d_feature" % idx)
+
+
+def write_image_feature(fold, idx, info, keypoints_px, descriptors):
+    """info: dict(rows, cols, zoom_ratio, f_mm, f_pixel, gps_latitude, gps_longitude, cam_maker, cam_model);
+    keypoints_px [n][2] in image pixels (centred on write, database.cc:522-527); descriptors [n][d] float32 or uint8."""
+    kp = np.asarray(keypoints_px, dtype=np.float64).reshape(-1, 2)
+    d = np.ascontiguousarray(descriptors)
+    if d.dtype not in (np.float32, np.uint8):
+        d = d.astype(np.float32)
+    cv_type = CV_32F if d.dtype == np.float32 else CV_8U
+    centred = np.empty((len(kp), 2), dtype=np.float32)
+    centred[:, 0] = kp[:, 0] - info["cols"] / 2.0
+    centred[:, 1] = kp[:, 1] - info["rows"] / 2.0
+    maker, model = info.get("cam_maker", "").encode(), info.get("cam_model", "").encode()
+    with open(feature_file(fold, idx), "wb") as f:
+        f.write(struct.pack("<ii5f", int(info["rows"]), int(info["cols"]), info.get("zoom_ratio", 1.0), info.get("f_mm", 0.0),
+                            info.get("f_pixel", 0.0), info.get("gps_latitude", 0.0), info.get("gps_longitude", 0.0)))
+        f.write(struct.pack("<i", len(maker)) + maker)
+        f.write(struct.pack("<i", len(model)) + model)
+        f.write(struct.pack("<i", len(centred)))
+        centred.tofile(f)
+        f.write(struct.pack("<iii", d.shape[0], d.shape[1] if d.ndim > 1 else 1, cv_type))
+        d.tofile(f)
+
+
+def read_image_feature(fold, idx):
+    """-> info dict, keypoints [n][2] float32 (centred pixels, as stored), descriptors [rows][cols]."""
+    with open(feature_file(fold, idx), "rb") as f:
+        rows, cols, zoom, f_mm, f_px, lat, lon = struct.unpack("<ii5f", f.read(28))
+        n = struct.unpack("<i", f.read(4))[0]
+        maker = f.read(n).decode()
+        n = struct.unpack("<i", f.read(4))[0]
+        model = f.read(n).decode()
+        npts = struct.unpack("<i", f.read(4))[0]
+        kp = np.fromfile(f, dtype=np.float32, count=2 * npts).reshape(-1, 2)
+        drows, dcols, cv_type = struct.unpack("<iii", f.read(12))
+        depth, channels = cv_type & 7, (cv_type >> 3) + 1
+        dt, _ = _ELEM[depth]
+        desc = np.fromfile(f, dtype=dt, count=drows * dcols * channels).reshape(drows, dcols * channels)
+    info = dict(rows=rows, cols=cols, zoom_ratio=zoom, f_mm=f_mm, f_pixel=f_px, gps_latitude=lat, gps_longitude=lon, cam_maker=maker,
+                cam_model=model)
+    return info, kp, desc
+
+
+def write_bundle_out(path, cam_fk, cam_R, cam_t, points, views):
+    """cam_fk [nc][3], cam_R [nc][9] row-major, cam_t [nc][3]; points [np][3]; views[p] = list of (camera, key, x, y)."""
+    with open(path, "w") as ff:
+        ff.write("# Bundle file v0.3\n")
+        ff.write("%d %d\n" % (len(cam_t), len(points)))
+        for i in range(len(cam_t)):
+            ff.write("%.8f %.8f %.8f\n" % tuple(cam_fk[i]))
+            ff.write(" ".join("%.8f" % v for v in np.asarray(cam_R[i]).reshape(9)) + "\n")
+            ff.write("%.8f %.8f %.8f\n" % tuple(cam_t[i]))
+        for p in range(len(points)):
+            ff.write("%.8f %.8f %.8f " % tuple(points[p]))
+            ff.write("255 255 255 ")
+            ff.write("%d\n" % len(views[p]))
+            for cam, key, x, y in views[p]:
+                ff.write("%d %d %.8f %.8f\n" % (cam, key, float(int(x)), float(int(y))))   # int x = it1->second(0): truncation
+
+
+def read_bundle_out(path):
+    tok = open(path).read().split("\n")
+    assert tok[0].startswith("# Bundle file")
+    nc, npt = (int(v) for v in tok[1].split())
+    fk, R, t = np.zeros((nc, 3)), np.zeros((nc, 9)), np.zeros((nc, 3))
+    line = 2
+    for i in range(nc):
+        fk[i] = [float(v) for v in tok[line].split()]
+        R[i] = [float(v) for v in tok[line + 1].split()]
+        t[i] = [float(v) for v in tok[line + 2].split()]
+        line += 3
+    pts, views = np.zeros((npt, 3)), []
+    for p in range(npt):
+        v = tok[line].split()
+        pts[p] = [float(x) for x in v[:3]]
+        nv = int(v[6])
+        line += 1
+        vs = []
+        for _ in range(nv):
+            w = tok[line].split()
+            vs.append((int(w[0]), int(w[1]), float(w[2]), float(w[3])))
+            line += 1
+        views.append(vs)
+    return fk, R, t, pts, views

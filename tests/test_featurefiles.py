@@ -1,0 +1,50 @@
+"""The reference's <idx>_feature file and bundle.rd.out export: byte layout and round trips."""
+import struct
+
+import numpy as np
+
+from metricsfm_amd import featurefiles as F
+
+
+def test_feature_file_layout_and_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    info = dict(rows=3000, cols=4000, zoom_ratio=0.5, f_mm=24.0, f_pixel=4800.0, gps_latitude=31.5, gps_longitude=118.75,
+                cam_maker="DJI", cam_model="FC6310")
+    kp = rng.uniform(0, 3000, (7, 2))
+    desc = rng.integers(0, 255, (7, 128)).astype(np.float32)
+    F.write_image_feature(str(tmp_path), 3, info, kp, desc)
+    raw = open(F.feature_file(str(tmp_path), 3), "rb").read()
+    # database.cc:499-539, field by field
+    assert struct.unpack_from("<ii5f", raw, 0) == (3000, 4000, 0.5, 24.0, 4800.0, 31.5, 118.75)
+    assert struct.unpack_from("<i", raw, 28)[0] == 3 and raw[32:35] == b"DJI"
+    assert struct.unpack_from("<i", raw, 35)[0] == 6 and raw[39:45] == b"FC6310"
+    assert struct.unpack_from("<i", raw, 45)[0] == 7
+    first = struct.unpack_from("<2f", raw, 49)
+    assert first == (np.float32(kp[0, 0] - 2000.0), np.float32(kp[0, 1] - 1500.0))          # centred on write
+    assert struct.unpack_from("<iii", raw, 49 + 56) == (7, 128, 5)                           # CV_32FC1
+    assert len(raw) == 49 + 56 + 12 + 7 * 128 * 4
+    info2, kp2, desc2 = F.read_image_feature(str(tmp_path), 3)
+    assert info2 == info
+    np.testing.assert_array_equal(kp2, (kp - [2000.0, 1500.0]).astype(np.float32))
+    np.testing.assert_array_equal(desc2, desc)
+    F.write_image_feature(str(tmp_path), 4, info, kp, desc.astype(np.uint8))
+    assert F.read_image_feature(str(tmp_path), 4)[2].dtype == np.uint8
+
+
+def test_bundle_out_round_trip(tmp_path):
+    rng = np.random.default_rng(1)
+    fk = np.array([[4800.0, 1e-3, -2e-3], [4790.5, 0.0, 0.0]])
+    R = np.stack([np.eye(3).reshape(9), np.eye(3)[::-1].reshape(9)])
+    t = rng.normal(size=(2, 3))
+    pts = rng.normal(size=(3, 3))
+    views = [[(0, 5, 10.7, -3.9), (1, 1000007, 99.2, 4.0)], [(1, 1000009, -0.5, 0.5)], []]
+    path = str(tmp_path / "bundle.rd.out")
+    F.write_bundle_out(path, fk, R, t, pts, views)
+    lines = open(path).read().split("\n")
+    assert lines[0] == "# Bundle file v0.3" and lines[1] == "2 3"
+    assert lines[2] == "4800.00000000 0.00100000 -0.00200000"
+    fk2, R2, t2, pts2, views2 = F.read_bundle_out(path)
+    np.testing.assert_allclose(fk2, fk, atol=1e-8); np.testing.assert_allclose(R2, R, atol=1e-8)
+    np.testing.assert_allclose(t2, t, atol=1e-8); np.testing.assert_allclose(pts2, pts, atol=1e-8)
+    assert views2[0] == [(0, 5, 10.0, -3.0), (1, 1000007, 99.0, 4.0)]      # image coordinates truncated to int (:1342-1345)
+    assert views2[1] == [(1, 1000009, 0.0, 0.0)] and views2[2] == []
