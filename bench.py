@@ -188,7 +188,7 @@ def main():
     roofline = dict(rooflines[dom["kernel"]], kernel=dom["kernel"]) if dom["kernel"] in rooflines else whole
     # HBM traffic of the dominant kernel from the rocprofv3 PMC passes (profiles/), per launch, if recorded
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and args.config == 3 and world == 1:  # the counters were collected on the headline configuration
         try:
             pmc = json.load(open(pmc_path))
             if roofline.get("kernel") in pmc:
