@@ -28,3 +28,30 @@ def test_sharded_ba_matches_single_rank(tmp_path, world, which, port):
     for a, b in (("point", "point1"), ("cam", "cam1"), ("model", "model1")):
         assert np.abs(r[a] - r[b]).max() <= 1e-8 * np.abs(r[b]).max(), a
     assert r["calls"] >= 3 * r["it"]  # the hook really carried the reduction (3 sums per LM iteration)
+
+
+def test_hook_runs_on_the_rccl_backend(tmp_path):
+    """backend "nccl" (= RCCL) with a single rank: the hook wraps the library's stream and a raw device pointer and hands
+    them to torch.distributed.all_reduce - the call sequence of the N-GPU bench, minus the peers."""
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from metricsfm_amd import capi, shard
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29744")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+ctx = capi.Context(0)
+hook = shard.TorchAllReduce(dist, 0)
+assert hook.backend == "nccl"
+buf = torch.arange(1000, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+for op in (0, 1, 0):
+    assert hook(buf.data_ptr(), buf.numel(), op, ctx.stream) == 0
+ctx.synchronize(); torch.cuda.synchronize()
+assert (buf.cpu().numpy() == np.arange(1000)).all() and hook.calls == 3 and len(hook._views) == 1
+ctx.close(); dist.destroy_process_group()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
