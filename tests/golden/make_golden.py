@@ -44,6 +44,19 @@ def main():
     Xd, _, okd = O.triangulate_dlt(tra, 3.0, th)
     np.savez_compressed(os.path.join(HERE, "tri_small.npz"), off=tra.track_off, cam=tra.track_cam, xy=tra.track_xy, R=R, t=t,
                         c=c, fk=fk, th_angle=th, X_mid=Xm, ok_mid=okm, X_dlt=Xd, ok_dlt=okd)
+    # geometric verification: three pairs (one below the 30-point gate), oracle output of the FM_RANSAC restatement
+    sys.path.insert(0, os.path.dirname(HERE))
+    from twoview import make_batch  # noqa: E402
+    off, p1, p2, _ = make_batch(2024, [150, 25, 60], outlier_frac=0.3)
+    F, inl, nin, ok = O.fundamental_ransac(off, p1, p2)
+    np.savez_compressed(os.path.join(HERE, "fransac_small.npz"), off=off, pt1=p1, pt2=p2, F=F, inlier=inl, n_inliers=nin, ok=ok)
+    # tracks: a small match graph with conflicting matches
+    pairs = [(0, 1), (0, 2), (1, 2), (2, 3), (1, 3), (0, 3)]
+    rng = np.random.default_rng(5)
+    matches = [np.column_stack([rng.permutation(40)[:18], rng.permutation(40)[:18]]).astype(np.int32) for _ in pairs]
+    toff, timg, tfeat = O.build_tracks(pairs, matches)
+    np.savez_compressed(os.path.join(HERE, "tracks_small.npz"), pairs=np.array(pairs, np.int32), match_off=np.cumsum([0] + [len(m) for m in matches]),
+                        matches=np.concatenate(matches), track_off=toff, obs_image=timg, obs_feature=tfeat)
 
 
 if __name__ == "__main__":

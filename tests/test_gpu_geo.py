@@ -65,3 +65,12 @@ def test_epipolar_filter_batch_matches_oracle(ctx, O):
         s = slice(off[p], off[p + 1])
         want = O.epipolar_filter(p1[s], p2[s], F[p], 3.0) if ok[p] else np.zeros(off[p + 1] - off[p], np.uint8)
         np.testing.assert_array_equal(got[s], want)
+
+
+def test_fransac_golden_fixture(ctx):
+    """The committed oracle output (tests/golden/fransac_small.npz) without running the oracle."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "fransac_small.npz"))
+    F, inl, nin, ok = ctx.fundamental_ransac(f["off"], f["pt1"], f["pt2"])
+    np.testing.assert_array_equal(F, f["F"]); np.testing.assert_array_equal(inl, f["inlier"])
+    np.testing.assert_array_equal(nin, f["n_inliers"]); np.testing.assert_array_equal(ok, f["ok"])

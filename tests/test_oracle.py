@@ -190,6 +190,15 @@ def test_golden_vectors(oracle):
     np.testing.assert_array_equal(ok, t["ok_mid"])
     X, mse, ok = oracle.triangulate_dlt(tr, 3.0, float(t["th_angle"]))
     np.testing.assert_allclose(X, t["X_dlt"], rtol=1e-10, atol=1e-10)
+    f = np.load(os.path.join(GOLD, "fransac_small.npz"))
+    F, inl, nin, ok = oracle.fundamental_ransac(f["off"], f["pt1"], f["pt2"])
+    np.testing.assert_array_equal(F, f["F"]); np.testing.assert_array_equal(inl, f["inlier"])
+    np.testing.assert_array_equal(nin, f["n_inliers"]); np.testing.assert_array_equal(ok, f["ok"])
+    k = np.load(os.path.join(GOLD, "tracks_small.npz"))
+    mo = k["match_off"]
+    got = oracle.build_tracks([tuple(p) for p in k["pairs"]], [k["matches"][mo[i]:mo[i + 1]] for i in range(len(k["pairs"]))])
+    for g_, name in zip(got, ("track_off", "obs_image", "obs_feature")):
+        np.testing.assert_array_equal(g_, k[name])
 
 
 # ---- geometric verification: FM_RANSAC restatement ----

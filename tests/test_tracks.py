@@ -58,3 +58,12 @@ def test_tracks_quirks_and_errors(oracle):
     with pytest.raises(capi.MsfmError):
         capi.build_tracks([10, 10], [(0, 1)], [np.array([[3, 12]])])   # feature index out of range
     assert len(capi.build_tracks([4, 4], [], [])[0]) == 1
+
+
+def test_tracks_golden_fixture():
+    import os
+    k = np.load(os.path.join(os.path.dirname(__file__), "golden", "tracks_small.npz"))
+    mo = k["match_off"]
+    got = capi.build_tracks([40, 40, 40, 40], [tuple(p) for p in k["pairs"]], [k["matches"][mo[i]:mo[i + 1]] for i in range(len(k["pairs"]))])
+    for g, name in zip(got, ("track_off", "obs_image", "obs_feature")):
+        np.testing.assert_array_equal(g, k[name])
