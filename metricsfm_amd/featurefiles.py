@@ -106,3 +106,47 @@ def read_bundle_out(path):
             line += 1
         views.append(vs)
     return fk, R, t, pts, views
+
+
+def write_openmvs(path, cams, points):
+    """IncrementalSfM::SaveforOpenMVS (sfm_incremental.cc:1147-1245), sfm_openmvs.txt.
+    cams: list of dict(image_path, f, R [9], t [3], id, px, py, w, h); points: list of dict(X [3], bad, views = [(cam index, x, y)]
+    in std::map key order, x / y centred pixels).  Quirks kept: the image name is path[last '\\\\' : -1] (leading separator kept,
+    last character dropped, :1171-1172); pixel coordinates are x + px truncated to int; the view COUNT is taken against the
+    first view's camera size for every view (the counting loop never advances its camera iterator, :1203-1213) while the views
+    actually written are tested against their own camera (:1234-1242)."""
+    def pix(v, off):
+        return int(v + off)   # int x = it1->second(0) + px_: double sum truncated toward zero
+
+    with open(path, "w") as ff:
+        ff.write("%d\n" % len(cams))
+        for c in cams:
+            p = c["image_path"]
+            t = p.rfind("\\")
+            ff.write(p[t:len(p) - 1] + "\n" if t >= 0 else p[-1:len(p) - 1] + "\n")   # npos: substr(npos, ..) would throw; empty here
+            ff.write("%.8f\n" % c["f"])
+            ff.write(" ".join("%.8f" % v for v in np.asarray(c["R"]).reshape(9)) + "\n")
+            ff.write("%.8f %.8f %.8f\n" % tuple(c["t"]))
+        goods = []
+        for pt in points:
+            if pt.get("bad"):
+                goods.append(0)
+                continue
+            n = len(pt["views"])
+            if n:
+                c0 = cams[pt["views"][0][0]]
+                for (_, x, y) in pt["views"]:
+                    xi, yi = pix(x, c0["px"]), pix(y, c0["py"])
+                    if xi < 0 or xi >= c0["w"] or yi < 0 or yi >= c0["h"]:
+                        n -= 1
+            goods.append(n)
+        ff.write("%d\n" % sum(1 for pt, g in zip(points, goods) if not pt.get("bad") and g >= 2))
+        for pt, g in zip(points, goods):
+            if g < 2 or pt.get("bad"):
+                continue
+            ff.write("%.8f %.8f %.8f 255 255 255 %d\n" % (pt["X"][0], pt["X"][1], pt["X"][2], g))
+            for (ci, x, y) in pt["views"]:
+                c = cams[ci]
+                xi, yi = pix(x, c["px"]), pix(y, c["py"])
+                if not (xi < 0 or xi >= c["w"] or yi < 0 or yi >= c["h"]):
+                    ff.write("%d %d %d\n" % (c["id"], xi, yi))

@@ -48,3 +48,21 @@ def test_bundle_out_round_trip(tmp_path):
     np.testing.assert_allclose(t2, t, atol=1e-8); np.testing.assert_allclose(pts2, pts, atol=1e-8)
     assert views2[0] == [(0, 5, 10.0, -3.0), (1, 1000007, 99.0, 4.0)]      # image coordinates truncated to int (:1342-1345)
     assert views2[1] == [(1, 1000009, 0.0, 0.0)] and views2[2] == []
+
+
+def test_openmvs_export_with_reference_quirks(tmp_path):
+    cams = [dict(image_path="D:\\data\\img_0001.jpg", f=4800.0, R=np.eye(3).reshape(9), t=[0.0, 0.0, 0.0], id=7, px=2000.0, py=1500.0, w=4000, h=3000),
+            dict(image_path="D:\\data\\img_0002.jpg", f=4801.5, R=np.eye(3).reshape(9), t=[1.0, 2.0, 3.0], id=9, px=100.0, py=100.0, w=200, h=200)]
+    points = [dict(X=[1.0, 2.0, 3.0], views=[(0, -10.4, 20.9), (1, 50.0, -50.0)]),          # both inside their own image
+              dict(X=[4.0, 5.0, 6.0], views=[(1, 150.0, 0.0), (0, 0.0, 0.0)]),               # first view outside camera 1 -> counted 1 -> dropped ... 
+              dict(X=[7.0, 8.0, 9.0], bad=True, views=[(0, 0.0, 0.0), (1, 0.0, 0.0)]),
+              dict(X=[0.5, 0.5, 0.5], views=[(0, 1500.0, 0.0), (1, 1500.0, 0.0)])]          # counted against camera 0 (both fine), written: only the first
+    path = str(tmp_path / "sfm_openmvs.txt")
+    F.write_openmvs(path, cams, points)
+    lines = open(path).read().split("\n")
+    assert lines[0] == "2" and lines[1] == "\\img_0001.jp" and lines[2] == "4800.00000000"     # substr(t, size - 1 - t)
+    assert lines[9] == "2"                                                                     # good points
+    assert lines[10] == "1.00000000 2.00000000 3.00000000 255 255 255 2"
+    assert lines[11] == "7 1989 1520" and lines[12] == "9 150 50"                              # int(-10.4 + 2000), int(20.9 + 1500)
+    assert lines[13] == "0.50000000 0.50000000 0.50000000 255 255 255 2"                       # the count says 2 ...
+    assert lines[14] == "7 3500 1500" and lines[15] == ""                                      # ... one view is written (camera 1 is 200 px wide)
