@@ -222,3 +222,22 @@ def test_ba_full_size_properties(ctx, monkeypatch):
     assert r0["num_iterations"] == r["num_iterations"]
     np.testing.assert_allclose(r0["iterations"]["cost"], it["cost"], rtol=1e-9)
     assert _rel(a0.cam_pose, a.cam_pose) < 1e-7 and _rel(a0.point, a.point) < 1e-7
+
+
+def test_ba_domains_with_window_masks(ctx, oracle, monkeypatch):
+    """Frozen cameras and frozen points (PartialBundleAdjustment masks, sfm_incremental.cc:917-1014) on a problem large enough
+    for the camera-domain order: frozen cameras have no block, observations of frozen points only touch camera diagonals."""
+    monkeypatch.setenv("MSFM_CHOL_DOMAINS", "2")
+    sc = scene.make_aerial_scene(150, 4000, seed=17)
+    cam_mut = np.ones(sc.n_cams, np.uint8); cam_mut[::13] = 0
+    pt_mut = (np.arange(sc.n_points) % 11 != 0).astype(np.uint8)
+
+    def arrays():
+        return A.BaArrays.from_scene(sc, cam_mutable=cam_mut, pt_mutable=pt_mut)
+
+    lay = ctx.ba(arrays()).layout()
+    assert lay["n_domains"] == 4 and lay["reduced_order"] == 6 * int(cam_mut.sum()) + 3
+    # the trajectory has rejected trial steps with costs 300x the accepted ones: their cost is compared a little looser
+    _, _, a = check_parity(ctx, oracle, arrays, dict(max_num_iterations=10), tol_cost=1e-8)
+    np.testing.assert_array_equal(a.cam_pose[cam_mut == 0], sc.cam_pose[cam_mut == 0])     # frozen blocks untouched
+    np.testing.assert_array_equal(a.point[pt_mut == 0], sc.point[pt_mut == 0])
