@@ -9,6 +9,7 @@ the reference's extraction stage can feed libmsfm and libmsfm's results can feed
   bundle.rd.out                 text, "# Bundle file v0.3" (IncrementalSfM::SaveForCMVS, sfm_incremental.cc:1302-1353): fixed, 8 decimals;
       per camera f k1 k2 / R (row-major, 9 values) / t; per point X Y Z / 255 255 255 / view list, where the reference
       truncates the image coordinates to int before printing them as float (:1342-1345).
+  sfm_openmvs.txt, temp_result  text: the OpenMVS hand-over (:1147-1245) and the reconstruction checkpoint (:1465-1749), below.
 Native little-endian, as the reference writes them with ofstream::write."""
 import os
 import struct
@@ -150,3 +151,97 @@ def write_openmvs(path, cams, points):
                 xi, yi = pix(x, c["px"]), pix(y, c["py"])
                 if not (xi < 0 or xi >= c["w"] or yi < 0 or yi >= c["h"]):
                     ff.write("%d %d %d\n" % (c["id"], xi, yi))
+
+
+def _g(x):
+    return format(float(x), ".20g")   # ofs.precision(20), default float field (sfm_incremental.cc:1472)
+
+
+def write_temp_result(path, state):
+    """IncrementalSfM::WriteTempResultOut (sfm_incremental.cc:1465-1573): the text checkpoint of a reconstruction.
+    state = dict(cam_models=[dict(id, cam_maker, cam_model, w, h, f_mm, f, f_hyp, px, py, k1, k2, data[3], num_cams)],
+                 cams=[dict(id_img, model_id, is_mutable, data[6], pts=[(key, point id)], visible_cams=[...])],
+                 pts=[dict(id, is_mutable, is_bad_estimated, is_new_added, data[3], cams=[(key, id_img)], pts2d=[(key, x, y)],
+                           key_new_obs, mse)], localize_fail_times=[...]); map-typed lists in ascending key order."""
+    with open(path, "w") as f:
+        f.write("%d\n" % len(state["cam_models"]))
+        for m in state["cam_models"]:
+            f.write("%d\n%s\n%s\n" % (m["id"], m["cam_maker"], m["cam_model"]))
+            f.write("%d %d\n" % (m["w"], m["h"]))
+            f.write(" ".join(_g(v) for v in (m["f_mm"], m["f"], m["f_hyp"], m["px"], m["py"], m["k1"], m["k2"], *m["data"][:3])) + "\n")
+            f.write("%d\n" % m["num_cams"])
+        f.write("%d\n" % len(state["cams"]))
+        for c in state["cams"]:
+            f.write("%d\n%d\n%d\n" % (c["id_img"], c["model_id"], int(bool(c["is_mutable"]))))
+            f.write("".join(" " + _g(v) for v in c["data"][:6]) + "\n")
+            f.write("%d\n" % len(c["pts"]))
+            f.write("".join("%d %d " % (k, i) for k, i in c["pts"]) + "\n")
+            f.write("%d\n" % len(c["visible_cams"]))
+            f.write("".join("%d " % v for v in c["visible_cams"]) + "\n")
+        f.write("%d\n" % len(state["pts"]))
+        for p in state["pts"]:
+            f.write("%d\n" % p["id"])
+            f.write("%d %d %d\n" % (int(bool(p["is_mutable"])), int(bool(p["is_bad_estimated"])), int(bool(p["is_new_added"]))))
+            f.write(" ".join(_g(v) for v in p["data"][:3]) + "\n")
+            f.write("%d\n" % len(p["cams"]))
+            f.write("".join("%d %d " % (k, i) for k, i in p["cams"]) + "\n")
+            f.write("%d\n" % len(p["pts2d"]))
+            f.write("".join("%d %s %s " % (k, _g(x), _g(y)) for k, x, y in p["pts2d"]) + "\n")
+            f.write("%d\n" % p["key_new_obs"])
+            f.write(_g(p["mse"]) + "\n")
+        f.write("".join("%d " % v for v in state["localize_fail_times"]))
+
+
+def read_temp_result(path, n_localize=None):
+    """IncrementalSfM::ReadTempResultIn (sfm_incremental.cc:1575-1749), token by token like the `ifs >>` chain (the two
+    camera strings are read with getline).  n_localize: how many trailing localisation counters to read (default: all)."""
+    text = open(path).read()
+    pos = 0
+
+    def tok():
+        nonlocal pos
+        while pos < len(text) and text[pos].isspace():
+            pos += 1
+        start = pos
+        while pos < len(text) and not text[pos].isspace():
+            pos += 1
+        return text[start:pos]
+
+    def line():
+        nonlocal pos
+        end = text.find("\n", pos)
+        end = len(text) if end < 0 else end
+        s = text[pos:end]
+        pos = min(len(text), end + 1)
+        return s
+
+    st = dict(cam_models=[], cams=[], pts=[], localize_fail_times=[])
+    for _ in range(int(tok())):
+        m = dict(id=int(tok()))
+        line()                                  # rest of the id line (std::getline(ifs, temp))
+        m["cam_maker"], m["cam_model"] = line(), line()
+        m["w"], m["h"] = int(tok()), int(tok())
+        vals = [float(tok()) for _ in range(10)]
+        m.update(f_mm=vals[0], f=vals[1], f_hyp=vals[2], px=vals[3], py=vals[4], k1=vals[5], k2=vals[6], data=vals[7:10])
+        m["num_cams"] = int(tok())
+        st["cam_models"].append(m)
+    for _ in range(int(tok())):
+        c = dict(id_img=int(tok()), model_id=int(tok()), is_mutable=bool(int(tok())))
+        c["data"] = [float(tok()) for _ in range(6)]
+        c["pts"] = [(int(tok()), int(tok())) for _ in range(int(tok()))]
+        c["visible_cams"] = [int(tok()) for _ in range(int(tok()))]
+        st["cams"].append(c)
+    for _ in range(int(tok())):
+        p = dict(id=int(tok()), is_mutable=bool(int(tok())), is_bad_estimated=bool(int(tok())), is_new_added=bool(int(tok())))
+        p["data"] = [float(tok()) for _ in range(3)]
+        p["cams"] = [(int(tok()), int(tok())) for _ in range(int(tok()))]
+        p["pts2d"] = [(int(tok()), float(tok()), float(tok())) for _ in range(int(tok()))]
+        p["key_new_obs"] = int(tok())
+        p["mse"] = float(tok())
+        st["pts"].append(p)
+    while n_localize is None or len(st["localize_fail_times"]) < n_localize:
+        t = tok()
+        if not t:
+            break
+        st["localize_fail_times"].append(int(t))
+    return st

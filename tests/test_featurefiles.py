@@ -66,3 +66,24 @@ def test_openmvs_export_with_reference_quirks(tmp_path):
     assert lines[11] == "7 1989 1520" and lines[12] == "9 150 50"                              # int(-10.4 + 2000), int(20.9 + 1500)
     assert lines[13] == "0.50000000 0.50000000 0.50000000 255 255 255 2"                       # the count says 2 ...
     assert lines[14] == "7 3500 1500" and lines[15] == ""                                      # ... one view is written (camera 1 is 200 px wide)
+
+
+def test_temp_result_checkpoint_round_trip(tmp_path):
+    st = dict(cam_models=[dict(id=0, cam_maker="DJI", cam_model="FC 6310", w=4000, h=3000, f_mm=8.8, f=4799.643, f_hyp=4800.0, px=2000.0,
+                               py=1500.0, k1=1.048e-3, k2=3.789e-3, data=[4799.643, 1.048e-3, 3.789e-3], num_cams=2)],
+              cams=[dict(id_img=0, model_id=0, is_mutable=True, data=[0.1, -0.2, 0.3, 1.0, 2.0, 3.0], pts=[(5, 0), (9, 1)], visible_cams=[0, 1]),
+                    dict(id_img=1, model_id=0, is_mutable=False, data=[0.0] * 6, pts=[(1000007, 0)], visible_cams=[1, 0])],
+              pts=[dict(id=0, is_mutable=True, is_bad_estimated=False, is_new_added=True, data=[1.0 / 3.0, 2.0, -3.5],
+                        cams=[(5, 0), (1000007, 1)], pts2d=[(5, 10.25, -3.5), (1000007, 99.0, 4.125)], key_new_obs=1000007, mse=0.4196),
+                   dict(id=1, is_mutable=False, is_bad_estimated=True, is_new_added=False, data=[0.0, 0.0, 1.0], cams=[(9, 0)],
+                        pts2d=[(9, 1.0, 2.0)], key_new_obs=9, mse=1e5)],
+              localize_fail_times=[0, 2])
+    path = str(tmp_path / "temp_result")
+    F.write_temp_result(path, st)
+    lines = open(path).read().split("\n")
+    assert lines[0] == "1" and lines[2] == "DJI" and lines[3] == "FC 6310" and lines[4] == "4000 3000"
+    assert lines[5].split()[0] == "8.8000000000000007105"                 # precision(20): the binary value, not the literal
+    assert lines[11] == " 0.10000000000000000555 -0.2000000000000000111 0.2999999999999999889 1 2 3"   # leading blank kept
+    assert lines[13] == "5 0 9 1 " and lines[15] == "0 1 "
+    back = F.read_temp_result(path)
+    assert back == st                                                     # %.20g round-trips every double
