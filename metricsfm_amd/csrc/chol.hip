@@ -270,6 +270,7 @@ struct PanelJob {
   int ntile;       // 64x64 tiles of the trailing update, dealt round-robin to the nwg - ncw bulk workgroups
   int ldc;         // leading dimension of corner
   double* corner;  // destination of B x B tiles, nullptr: M itself
+  int defer_corner;  // the B x B tiles are left out here: one SYRK over all panels forms them after the domain chains
 };
 struct PanelJobs {
   int count;
@@ -506,11 +507,20 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
   // so nothing else hides that latency).
   auto locate = [&](int q, int& ri, int& rj, double*& C, int& ldC) {
     // pairs (I, J) with jmin <= J <= I < nt, enumerated row by row (shifted by one when jmin == 0)
-    int I = (int)((sqrt(8.0 * q + 1.0) + 1.0) * 0.5);
-    while (I * (I - 1) / 2 > q) I--;
-    while ((I + 1) * I / 2 <= q) I++;
-    int J = q - I * (I - 1) / 2 + 1;
-    if (!jmin) { I--; J--; }
+    int I, J;
+    const int ntri = nA64 * (nA64 - 1) / 2;  // pairs 1 <= J <= I < nA64
+    if (jb.defer_corner && q >= ntri) {
+      // rows of range B against the columns of range A only (defer_corner jobs always factor: jmin == 1)
+      const int w = nA64 - 1, e = q - ntri;
+      I = nA64 + e / w;
+      J = 1 + e % w;
+    } else {
+      I = (int)((sqrt(8.0 * q + 1.0) + 1.0) * 0.5);
+      while (I * (I - 1) / 2 > q) I--;
+      while ((I + 1) * I / 2 <= q) I++;
+      J = q - I * (I - 1) / 2 + 1;
+      if (!jmin) { I--; J--; }
+    }
     ri = job_row64(jb, I);
     rj = job_row64(jb, J);
     // destination of the tile: M, or the job's private corner when both tiles lie in range B
@@ -572,6 +582,58 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
     if (!more) break;
     q = qn;
     __syncthreads();  // every wave is done with As / Bs
+  }
+}
+
+// The separator x separator part of the domain chains' trailing updates, all at once:  corner_r[I][J] = -sum_p X_I,p X_J,p^T
+// over the 64-column panels p = r, r + nsplit, ... of the domain columns [0, b0) (X = the separator rows of the factor).
+// grid = lower 64x64 tiles of the separator square x nsplit; the next panel's tiles are fetched during the MFMAs.
+__global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ M, int ld, int b0, int nsplit, double* __restrict__ corners,
+                                                      int ldc) {
+  __shared__ double sm[2 * 64 * LDT];
+  double* As = sm;
+  double* Bs = sm + 64 * LDT;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4;
+  const int tile = blockIdx.x / nsplit, r = blockIdx.x % nsplit;
+  int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > tile) I--;
+  while ((I + 1) * (I + 2) / 2 <= tile) I++;
+  const int J = tile - I * (I + 1) / 2;
+  const int ri = b0 + 64 * I, rj = b0 + 64 * J, np = b0 / 64;
+  d4 acc00 = {0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+  d2 va[8], vb[8];
+  auto fetch = [&](int p) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, row = e >> 5, c2 = (e & 31) * 2;
+      va[it] = *reinterpret_cast<const d2*>(&M[(size_t)(ri + row) * ld + 64 * p + c2]);
+      vb[it] = *reinterpret_cast<const d2*>(&M[(size_t)(rj + row) * ld + 64 * p + c2]);
+    }
+  };
+  int p = r;
+  if (p < np) fetch(p);
+  for (; p < np; p += nsplit) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, row = e >> 5, c2 = (e & 31) * 2;
+      As[row * LDT + c2] = -va[it].x;
+      As[row * LDT + c2 + 1] = -va[it].y;
+      Bs[row * LDT + c2] = vb[it].x;
+      Bs[row * LDT + c2 + 1] = vb[it].y;
+    }
+    __syncthreads();
+    if (p + nsplit < np) fetch(p + nsplit);
+    quad_abt(As, Bs, wr, wc, lr, lk, acc00, acc01, acc10, acc11);
+    __syncthreads();
+  }
+  double* C = corners + (size_t)r * ldc * ldc + (size_t)(64 * I) * ldc + 64 * J;
+  const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double* c0 = &C[(size_t)(qrow + 4 * i) * ldc + qcol];
+    double* c1 = &C[(size_t)(qrow + 16 + 4 * i) * ldc + qcol];
+    c0[0] = acc00[i]; c0[16] = acc01[i]; c1[0] = acc10[i]; c1[16] = acc11[i];
   }
 }
 
@@ -726,7 +788,7 @@ static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /
     jb.ntile = nt * (nt + 1) / 2;
   }
   jb.nwg = jb.ncw + bulk_workgroups(jb.ntile);
-  jb.wg0 = 0; jb.corner = corner; jb.ldc = ldc;
+  jb.wg0 = 0; jb.corner = corner; jb.ldc = ldc; jb.defer_corner = 0;
   return jb;
 }
 
@@ -746,19 +808,23 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     const int K = plan->K, sb = plan->sep_begin, ldc = plan->ldc;
     if (K > 8 || sb % NB || !plan->corners || ldc < 64 * cdiv(nrows - sb, 64))
       return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan");
-    HIP_TRY(ctx, hipMemsetAsync(plan->corners, 0, sizeof(double) * (size_t)K * ldc * ldc, s));
     int maxp = 0;
     for (int k = 0; k < K; k++) maxp = std::max(maxp, (plan->dom_end[k] - plan->dom_begin[k]) / NB);
-    for (int l = 0; l <= maxp; l++) {
+    for (int l = 0; l < maxp; l++) {
       PanelJobs jobs;
       jobs.count = 0;
       int wg = 0;
       for (int k = 0; k < K; k++) {
         const int P = (plan->dom_end[k] - plan->dom_begin[k]) / NB;
-        if (l > P) continue;
-        const int t0 = l < P ? plan->dom_begin[k] + NB * l : -1;
+        if (l >= P) continue;
+        const int t0 = plan->dom_begin[k] + NB * l;
         const int j0 = l > 0 ? plan->dom_begin[k] + NB * (l - 1) : -1;
-        PanelJob jb = make_job(j0, t0, t0 >= 0 ? t0 : 0, t0 >= 0 ? P - l : 0, sb, nrows - sb, plan->corners + (size_t)k * ldc * ldc, ldc);
+        PanelJob jb = make_job(j0, t0, t0, P - l, sb, nrows - sb, nullptr, 0);
+        // the separator x separator tiles are formed once, after the chains (k_corner_syrk): leave them out here
+        const int nA64 = P - l, nB64 = cdiv(jb.nb16, 4);
+        jb.defer_corner = 1;
+        jb.ntile = j0 >= 0 ? nA64 * (nA64 - 1) / 2 + nB64 * (nA64 - 1) : 0;
+        jb.nwg = jb.ncw + bulk_workgroups(jb.ntile);
         jb.wg0 = wg;
         wg += jb.nwg;
         jobs.job[jobs.count++] = jb;
@@ -769,8 +835,11 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     }
     {
       KTimer t(ctx, "chol_panel_mfma");
-      const int nB64 = cdiv(nrows - sb, 64);
-      hipLaunchKernelGGL(k_merge_corners, dim3(4 * (nB64 * (nB64 + 1) / 2)), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, K);
+      const int nB64 = cdiv(nrows - sb, 64), ntile = nB64 * (nB64 + 1) / 2;
+      // K-split so that the workgroups (two fit on a CU) cover the chip once: 1 / 2 / 3 / 4 splits measured 94 / 82 / 58 / 71 us at C3
+      const int nsplit = std::min(K, std::max(1, std::min(4, 512 / std::max(1, ntile))));
+      hipLaunchKernelGGL(k_corner_syrk, dim3(ntile * nsplit), dim3(256), 0, s, M, npad, sb, nsplit, plan->corners, ldc);
+      hipLaunchKernelGGL(k_merge_corners, dim3(4 * ntile), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, nsplit);
     }
     t_first = sb;
   }

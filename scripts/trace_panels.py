@@ -3,7 +3,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-pan = [r for r in rows if 'k_panel' in r['Kernel_Name'] or 'k_merge' in r['Kernel_Name']]
+pan = [r for r in rows if any(k in r['Kernel_Name'] for k in ('k_panel', 'k_merge', 'k_corner'))]
 n = per or len(pan) // 3
 last = pan[-n:]
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000 for r in last]
