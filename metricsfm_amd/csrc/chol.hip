@@ -257,8 +257,9 @@ __device__ __forceinline__ void tile_st(double* Ls, int a, int b, int lr, int lk
 // K mutually uncoupled camera domains first and their separator last, the K domain chains advance in
 // the same launch.  A job's rows are two ranges: A = [a0, a0 + 16 na16) (rest of its own domain,
 // starting with the 64 x 64 block to factor) and B = [b0, b0 + 16 nb16) (separator + rhs row); the
-// B x B tiles of its trailing update go to a private corner buffer (summed into M afterwards), so
-// concurrent jobs never write the same tile.  The plain dense factorisation is one job with B empty.
+// B x B tiles, which every job's trailing update would write, are left out of the chains (defer_corner)
+// and formed afterwards by one SYRK over all panels (k_corner_syrk, then k_merge_corners).  The plain dense
+// factorisation is one job with B empty.
 struct PanelJob {
   int j0;          // panel to apply, < 0: none (first block of a chain)
   int t0;          // block to factor, < 0: update only
