@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects what profiles/ holds, on the GPU box:  gpurun --timeout 1100 -- 'bash scripts/collect_profiles.sh'
+# (run from the repo root; every step writes under gpurun_out/prof, copy the summaries into profiles/ afterwards).
+set -e -o pipefail
+R=$PWD
+O=$R/gpurun_out/prof
+rm -rf $O && mkdir -p $O
+export TMPDIR=/tmp
+python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+echo "bench done"; tail -c 600 $O/bench.json
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
+echo "kernel trace done"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-matching > $O/pmc_fetch.log 2>&1
+echo "pmc fetch done"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-matching > $O/pmc_write.log 2>&1
+echo "pmc write done"
+cd $R
+python3 scripts/extra_bench.py --c5 > $O/extra.json 2> $O/extra.err
+echo "extra done"
+find $O -name "*.csv" | head -20
