@@ -345,6 +345,39 @@ int msfm_track_set_size(const msfm_track_set* set, int* n_tracks, int* n_observa
 int msfm_track_set_fetch(const msfm_track_set* set, int* track_off /*[n_tracks+1]*/, int* obs_image, int* obs_feature);
 void msfm_track_set_destroy(msfm_track_set* set);
 
+/* ======================================================================================
+ *  Pose initialisers ahead of each bundle adjustment  
+ * ====================================================================================== */
+/* AbsolutePoseEstimation::AbsolutePoseWithFocalLength (SfM/src/orientation/absolute_pose_estimation.cc:42-58, called
+ * when an image is localised against the model, sfm_incremental.cc:646) for a batch of images.  Per image:
+ * AbsolutePoseEPNP::EPNPRansac (absolute_pose_via_epnp.cc:103-139) - `max_iter` (reference: 200) samples of 4
+ * correspondences, EPnP on each (:142-185; compute_pose :472-519 with OpenCV's Jacobi SVD restated), the sample
+ * whose error over its own four points is smallest is kept - then AbsolutePoseEstimation::Error over all
+ * correspondences (:67-103).  The reference samples with std::random_shuffle; here sample `it` of image `p` is a
+ * pure function of (seed, p, it), so results do not depend on the batch split.
+ * In : offsets[n+1] delimits each image's correspondences; pts_w [total][3] world points, pts_2d [total][2] centred
+ *      pixels, f[n] focal lengths.
+ * Out: R [n][9] row-major and t [n][3] with Xc = R Xw + t (zeros when no sample qualified or fewer than 4 points);
+ *      errors [total] = reprojection error, 1000.0 where it is >= 10 px; avg_error [n] = rms of the errors < 10 px
+ *      (10000.0 when there is none) - the value compared with th_mse_localization (sfm_incremental.cc:648);
+ *      best_iter [n] (may be NULL) = index of the kept sample, -1 if none. */
+int msfm_epnp_ransac_batch(msfm_ctx* ctx, int n_problems, const int* offsets, const double* pts_w,
+                           const double* pts_2d, const double* f, int max_iter, uint64_t seed, double* R,
+                           double* t, double* errors, double* avg_error, int* best_iter);
+/* RelativePoseEstimation::RelativePoseWithFocalLength (SfM/src/orientation/relative_pose_estimation.cc:91-120,
+ * called for the seed pair, sfm_incremental.cc:309) for a batch of image pairs.  Per pair, on points divided by the
+ * focal lengths: EssentialMatrixFivePoints::FivePointEssentialMatrixRANSAC (essential_matrix_five_point.cc:30-92) -
+ * `ransac_times` (reference: 100) samples of 5 matches (all matches at once when there are 5..9), Nister's solver
+ * through the 10x10 action matrix (:97-178; Eigen's FullPivLU / EigenSolver restated), every real solution scored
+ * by the Sampson sum over all matches (:333-349), fewer than 4 solutions in total = failure - then
+ * RelativePoseFromEssentialMatrix::ReltivePoseFromEMatrix (relative_pose_from_essential_matrix.cc:33-104): SVD of
+ * E, four (R, t) hypotheses, each match votes for the first hypothesis that puts it in front of both cameras.
+ * Out: E [n][9] row-major with x_cur^T E x_ref = 0 on (pixel / f, 1); R [n][9], t [n][3] exactly as the reference
+ *      returns them in RTPoseRelative; ok [n]; n_candidates [n] (may be NULL) = number of essential matrices scored. */
+int msfm_relpose_5pt_batch(msfm_ctx* ctx, int n_pairs, const int* offsets, const double* pts_ref,
+                           const double* pts_cur, const double* f_ref, const double* f_cur, int ransac_times,
+                           uint64_t seed, double* E, double* R, double* t, uint8_t* ok, int* n_candidates);
+
 #ifdef __cplusplus
 }
 #endif

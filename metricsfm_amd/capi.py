@@ -24,6 +24,7 @@ SYMBOLS = [
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
     "msfm_epipolar_filter_batch", "msfm_tracks_build", "msfm_track_set_size", "msfm_track_set_fetch", "msfm_track_set_destroy",
+    "msfm_epnp_ransac_batch", "msfm_relpose_5pt_batch",
 ]
 
 
@@ -87,6 +88,10 @@ def lib():
     L.msfm_fundamental_ransac_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, C.POINTER(A.FransacOptions),
                                                 A.c_double_p, A.c_u8_p, A.c_int_p, A.c_u8_p]
     L.msfm_epipolar_filter_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, A.c_double_p, A.c_u8_p, d, A.c_u8_p]
+    L.msfm_epnp_ransac_batch.argtypes = [vp, i, A.c_int_p, A.c_double_p, A.c_double_p, A.c_double_p, i, C.c_uint64, A.c_double_p,
+                                         A.c_double_p, A.c_double_p, A.c_double_p, A.c_int_p]
+    L.msfm_relpose_5pt_batch.argtypes = [vp, i, A.c_int_p, A.c_double_p, A.c_double_p, A.c_double_p, A.c_double_p, i, C.c_uint64,
+                                         A.c_double_p, A.c_double_p, A.c_double_p, A.c_u8_p, A.c_int_p]
     L.msfm_tracks_build.argtypes = [i, A.c_int_p, i, A.c_int_p, A.c_int_p, A.c_int_p, C.POINTER(vp)]
     L.msfm_track_set_size.argtypes = [vp, A.c_int_p, A.c_int_p]
     L.msfm_track_set_fetch.argtypes = [vp, A.c_int_p, A.c_int_p, A.c_int_p]
@@ -285,6 +290,40 @@ class Context:
                                                        A.ptr(pt2, A.c_float_p), C.byref(o), A.ptr(F, A.c_double_p),
                                                        A.ptr(inl, A.c_u8_p), A.ptr(nin, A.c_int_p), A.ptr(ok, A.c_u8_p)))
         return F, inl[:len(pt1)], nin[:n_pairs], ok[:n_pairs]
+
+    def epnp_ransac(self, offsets, pts_w, pts_2d, f, max_iter=200, seed=0x4D53464D50):
+        """AbsolutePoseEstimation::AbsolutePoseWithFocalLength for a batch of images (absolute_pose_estimation.cc:42-58):
+        EPnP RANSAC over 4-point samples + the reprojection errors of all correspondences.
+        Returns R [n][3][3], t [n][3], errors [total], avg_error [n], best_iter [n]."""
+        offsets = A.as_c(offsets, np.int32)
+        pts_w = A.as_c(np.asarray(pts_w, dtype=np.float64).reshape(-1, 3), np.float64)
+        pts_2d = A.as_c(np.asarray(pts_2d, dtype=np.float64).reshape(-1, 2), np.float64)
+        n = len(offsets) - 1
+        f = A.as_c(np.broadcast_to(np.asarray(f, dtype=np.float64), (n,)).copy(), np.float64)
+        R = np.zeros((max(1, n), 3, 3)); t = np.zeros((max(1, n), 3)); err = np.zeros(max(1, len(pts_w))); avg = np.zeros(max(1, n))
+        best = np.zeros(max(1, n), dtype=np.int32)
+        self.check(lib().msfm_epnp_ransac_batch(self._h, n, A.ptr(offsets, A.c_int_p), A.ptr(pts_w, A.c_double_p), A.ptr(pts_2d, A.c_double_p),
+                                                A.ptr(f, A.c_double_p), max_iter, seed, A.ptr(R, A.c_double_p), A.ptr(t, A.c_double_p),
+                                                A.ptr(err, A.c_double_p), A.ptr(avg, A.c_double_p), A.ptr(best, A.c_int_p)))
+        return R[:n], t[:n], err[:len(pts_w)], avg[:n], best[:n]
+
+    def relpose_5pt(self, offsets, pts_ref, pts_cur, f_ref, f_cur, ransac_times=100, seed=0x4D53464D45):
+        """RelativePoseEstimation::RelativePoseWithFocalLength for a batch of image pairs (relative_pose_estimation.cc:91-120):
+        five-point RANSAC + decomposition of the best essential matrix.
+        Returns E [n][3][3], R [n][3][3], t [n][3], ok [n], n_candidates [n]."""
+        offsets = A.as_c(offsets, np.int32)
+        pts_ref = A.as_c(np.asarray(pts_ref, dtype=np.float64).reshape(-1, 2), np.float64)
+        pts_cur = A.as_c(np.asarray(pts_cur, dtype=np.float64).reshape(-1, 2), np.float64)
+        n = len(offsets) - 1
+        f_ref = A.as_c(np.broadcast_to(np.asarray(f_ref, dtype=np.float64), (n,)).copy(), np.float64)
+        f_cur = A.as_c(np.broadcast_to(np.asarray(f_cur, dtype=np.float64), (n,)).copy(), np.float64)
+        E = np.zeros((max(1, n), 3, 3)); R = np.zeros((max(1, n), 3, 3)); t = np.zeros((max(1, n), 3))
+        ok = np.zeros(max(1, n), dtype=np.uint8); nc = np.zeros(max(1, n), dtype=np.int32)
+        self.check(lib().msfm_relpose_5pt_batch(self._h, n, A.ptr(offsets, A.c_int_p), A.ptr(pts_ref, A.c_double_p), A.ptr(pts_cur, A.c_double_p),
+                                                A.ptr(f_ref, A.c_double_p), A.ptr(f_cur, A.c_double_p), ransac_times, seed,
+                                                A.ptr(E, A.c_double_p), A.ptr(R, A.c_double_p), A.ptr(t, A.c_double_p), A.ptr(ok, A.c_u8_p),
+                                                A.ptr(nc, A.c_int_p)))
+        return E[:n], R[:n], t[:n], ok[:n], nc[:n]
 
     def epipolar_filter_batch(self, offsets, pt1, pt2, F, ok=None, th=3.0):
         offsets = A.as_c(offsets, np.int32)

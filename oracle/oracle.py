@@ -17,10 +17,10 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "msfm_oracle.cpp")
-    hdr = os.path.join(_HERE, "..", "include", "msfm.h")
+    srcs = [os.path.join(_HERE, "msfm_oracle.cpp"), os.path.join(_HERE, "pose_oracle.cpp"),
+            os.path.join(_HERE, "..", "include", "msfm.h")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(f) for f in srcs)):
         return _LIB_PATH
     subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
@@ -259,3 +259,99 @@ def ratio_codes(ids, sqd, ratio_good=0.6, ratio_all=0.85):
     lib().orc_ratio_codes(A.ptr(ids, A.c_int_p), A.ptr(sqd, A.c_float_p), len(ids), ratio_good, ratio_all,
                           A.ptr(code, A.c_int_p), C.byref(na), C.byref(ng))
     return code, na.value, ng.value
+
+
+def epnp_ransac(offsets, pts_w, pts_2d, f, max_iter=200, seed=0x4D53464D50):
+    """AbsolutePoseEstimation::AbsolutePoseWithFocalLength (absolute_pose_estimation.cc:42-58) per image of a batch:
+    EPNPRansac (absolute_pose_via_epnp.cc:103-139) + Error (:67-103).  Returns R [n,3,3], t [n,3], errors [total],
+    avg_error [n], best_iter [n]."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    pts_w = np.ascontiguousarray(np.asarray(pts_w, dtype=np.float64).reshape(-1, 3))
+    pts_2d = np.ascontiguousarray(np.asarray(pts_2d, dtype=np.float64).reshape(-1, 2))
+    n = len(offsets) - 1
+    f = np.ascontiguousarray(np.broadcast_to(np.asarray(f, dtype=np.float64), (n,)))
+    R = np.zeros((max(1, n), 3, 3)); t = np.zeros((max(1, n), 3)); err = np.zeros(max(1, len(pts_w))); avg = np.zeros(max(1, n))
+    best = np.zeros(max(1, n), dtype=np.int32)
+    fn = lib().orc_epnp_ransac
+    fn.argtypes = [C.c_int, A.c_int_p, A.c_double_p, A.c_double_p, A.c_double_p, C.c_int, C.c_uint64, A.c_double_p, A.c_double_p,
+                   A.c_double_p, A.c_double_p, A.c_int_p]
+    rc = fn(n, A.ptr(offsets, A.c_int_p), A.ptr(pts_w, A.c_double_p), A.ptr(pts_2d, A.c_double_p), A.ptr(f, A.c_double_p), max_iter, seed,
+            A.ptr(R, A.c_double_p), A.ptr(t, A.c_double_p), A.ptr(err, A.c_double_p), A.ptr(avg, A.c_double_p), A.ptr(best, A.c_int_p))
+    if rc != 0:
+        raise ValueError("orc_epnp_ransac rc=%d" % rc)
+    return R[:n], t[:n], err[:len(pts_w)], avg[:n], best[:n]
+
+
+def relpose_5pt(offsets, pts_ref, pts_cur, f_ref, f_cur, ransac_times=100, seed=0x4D53464D45):
+    """RelativePoseEstimation::RelativePoseWithFocalLength (relative_pose_estimation.cc:91-120) per image pair of a batch.
+    Returns E [n,3,3] (x_cur^T E x_ref = 0 on pixel / f), R [n,3,3], t [n,3], ok [n], n_candidates [n]."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    pts_ref = np.ascontiguousarray(np.asarray(pts_ref, dtype=np.float64).reshape(-1, 2))
+    pts_cur = np.ascontiguousarray(np.asarray(pts_cur, dtype=np.float64).reshape(-1, 2))
+    n = len(offsets) - 1
+    f_ref = np.ascontiguousarray(np.broadcast_to(np.asarray(f_ref, dtype=np.float64), (n,)))
+    f_cur = np.ascontiguousarray(np.broadcast_to(np.asarray(f_cur, dtype=np.float64), (n,)))
+    E = np.zeros((max(1, n), 3, 3)); R = np.zeros((max(1, n), 3, 3)); t = np.zeros((max(1, n), 3))
+    ok = np.zeros(max(1, n), dtype=np.uint8); nc = np.zeros(max(1, n), dtype=np.int32)
+    fn = lib().orc_relpose_5pt
+    fn.argtypes = [C.c_int, A.c_int_p, A.c_double_p, A.c_double_p, A.c_double_p, A.c_double_p, C.c_int, C.c_uint64, A.c_double_p,
+                   A.c_double_p, A.c_double_p, A.c_u8_p, A.c_int_p]
+    rc = fn(n, A.ptr(offsets, A.c_int_p), A.ptr(pts_ref, A.c_double_p), A.ptr(pts_cur, A.c_double_p), A.ptr(f_ref, A.c_double_p),
+            A.ptr(f_cur, A.c_double_p), ransac_times, seed, A.ptr(E, A.c_double_p), A.ptr(R, A.c_double_p), A.ptr(t, A.c_double_p),
+            A.ptr(ok, A.c_u8_p), A.ptr(nc, A.c_int_p))
+    if rc != 0:
+        raise ValueError("orc_relpose_5pt rc=%d" % rc)
+    return E[:n], R[:n], t[:n], ok[:n], nc[:n]
+
+
+def _test_jacobi_svd(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    m, n = a.shape
+    W = np.zeros(n); Ut = np.zeros((n, m)); Vt = np.zeros((n, n))
+    fn = lib().orc_test_jacobi_svd
+    fn.argtypes = [A.c_double_p, C.c_int, C.c_int, A.c_double_p, A.c_double_p, A.c_double_p]
+    fn.restype = None
+    fn(A.ptr(a, A.c_double_p), m, n, A.ptr(W, A.c_double_p), A.ptr(Ut, A.c_double_p), A.ptr(Vt, A.c_double_p))
+    return W, Ut, Vt
+
+
+def _test_eig10(a):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(10, 10)
+    wr = np.zeros(10); wi = np.zeros(10)
+    fn = lib().orc_test_eig10
+    fn.argtypes = [A.c_double_p, A.c_double_p, A.c_double_p]
+    ok = fn(A.ptr(a, A.c_double_p), A.ptr(wr, A.c_double_p), A.ptr(wi, A.c_double_p))
+    return bool(ok), wr, wi
+
+
+def _test_five_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+    Es = np.zeros((10, 9))
+    fn = lib().orc_test_five_point
+    fn.argtypes = [A.c_double_p, A.c_double_p, C.c_int, A.c_double_p]
+    c = fn(A.ptr(x1, A.c_double_p), A.ptr(x2, A.c_double_p), len(x1), A.ptr(Es, A.c_double_p))
+    return Es[:c].reshape(c, 3, 3).transpose(0, 2, 1)   # column-major entries -> E[r, c]
+
+
+def _test_epnp4(Xw, x2d, f):
+    Xw = np.ascontiguousarray(Xw, dtype=np.float64).reshape(4, 3)
+    x2d = np.ascontiguousarray(x2d, dtype=np.float64).reshape(4, 2)
+    R = np.zeros((3, 3)); t = np.zeros(3); e = C.c_double(0)
+    fn = lib().orc_test_epnp4
+    fn.argtypes = [A.c_double_p, A.c_double_p, C.c_double, A.c_double_p, A.c_double_p, C.POINTER(C.c_double)]
+    fn.restype = None
+    fn(A.ptr(Xw, A.c_double_p), A.ptr(x2d, A.c_double_p), f, A.ptr(R, A.c_double_p), A.ptr(t, A.c_double_p), C.byref(e))
+    return R, t, e.value
+
+
+def _test_epnp_n(Xw, x2d, f):
+    """EPnP on all given correspondences (n >= 4); returns R, t, mean reprojection error."""
+    Xw = np.ascontiguousarray(Xw, dtype=np.float64).reshape(-1, 3)
+    x2d = np.ascontiguousarray(x2d, dtype=np.float64).reshape(-1, 2)
+    R = np.zeros((3, 3)); t = np.zeros(3)
+    fn = lib().orc_test_epnp_n
+    fn.argtypes = [A.c_double_p, A.c_double_p, C.c_int, C.c_double, A.c_double_p, A.c_double_p]
+    fn.restype = C.c_double
+    e = fn(A.ptr(Xw, A.c_double_p), A.ptr(x2d, A.c_double_p), len(Xw), f, A.ptr(R, A.c_double_p), A.ptr(t, A.c_double_p))
+    return R, t, e

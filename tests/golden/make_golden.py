@@ -57,6 +57,19 @@ def main():
     toff, timg, tfeat = O.build_tracks(pairs, matches)
     np.savez_compressed(os.path.join(HERE, "tracks_small.npz"), pairs=np.array(pairs, np.int32), match_off=np.cumsum([0] + [len(m) for m in matches]),
                         matches=np.concatenate(matches), track_off=toff, obs_image=timg, obs_feature=tfeat)
+    # pose initialisers: EPnP RANSAC for three images, five-point RANSAC for three pairs (one with 8 matches: the
+    # all-points branch), oracle output
+    from twoview import make_pnp_batch, make_relpose_batch  # noqa: E402
+    seed = 0x4D53
+    poff, X, x, _, _ = make_pnp_batch(77, [60, 4, 25], outlier_frac=0.2)
+    pf = np.array([4800.0, 4800.0, 4000.0])
+    R, t, err, avg, best = O.epnp_ransac(poff, X, x, pf, max_iter=50, seed=seed)
+    roff, a, b, _, _ = make_relpose_batch(78, [80, 8, 30], outlier_frac=0.1)
+    f1 = np.array([4800.0, 4800.0, 4000.0]); f2 = np.array([4800.0, 4700.0, 4000.0])
+    E, R2, t2, ok, nc = O.relpose_5pt(roff, a, b, f1, f2, ransac_times=40, seed=seed)
+    np.savez_compressed(os.path.join(HERE, "pose_small.npz"), seed=seed, pnp_off=poff, pnp_X=X, pnp_x=x, pnp_f=pf, pnp_iters=50, pnp_R=R,
+                        pnp_t=t, pnp_err=err, pnp_avg=avg, pnp_best=best, rel_off=roff, rel_a=a, rel_b=b, rel_f1=f1, rel_f2=f2,
+                        rel_times=40, rel_E=E, rel_R=R2, rel_t=t2, rel_ok=ok, rel_nc=nc)
 
 
 if __name__ == "__main__":
