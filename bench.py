@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matching", action="store_true")
     ap.add_argument("--verify-pairs", type=int, default=2048, help="image pairs in the geometric-verification leg")
+    ap.add_argument("--pose-images", type=int, default=1024, help="images / pairs in the pose-initialiser leg")
     ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL)")
     args = ap.parse_args()
 
@@ -293,6 +294,68 @@ def main():
             O.fundamental_ransac(voff[:5], v1[:4 * n_vm], v2[:4 * n_vm])
             out["geo_verification"]["cpu_baseline"] = dict(value=4 / (time.perf_counter() - t0), unit="pairs/s", cores=1, kind="port",
                                                            sample="4 pairs by the sequential CPU oracle (adaptive stop active)")
+
+    # ------------------------------------------------------------------ pose-initialiser leg
+    if not args.no_matching and rank == 0:
+        rng = np.random.default_rng(0x4D53464D + 3)
+        n_img, n_corr = args.pose_images, 256
+
+        def rod(a):
+            th = np.linalg.norm(a)
+            K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]]) / th
+            return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+        def pnp(n):
+            X = np.column_stack([rng.uniform(-40, 40, n), rng.uniform(-30, 30, n), rng.uniform(-5, 5, n)])
+            R = rod(np.array([np.pi, 0.0, 0.0]) + rng.normal(0, 0.05, 3))
+            t = -R @ np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), 100.0])
+            Xc = X @ R.T + t
+            return X, 4800 * Xc[:, :2] / Xc[:, 2:3] + rng.normal(0, 0.5, (n, 2))
+
+        def rel(n):
+            X = np.column_stack([rng.uniform(-40, 40, n), rng.uniform(-30, 30, n), rng.uniform(80, 120, n)])
+            Xc = X @ rod(rng.normal(0, 0.05, 3)).T + np.array([10.0, 1.0, 0.5])
+            return (4800 * X[:, :2] / X[:, 2:3] + rng.normal(0, 0.5, (n, 2)), 4800 * Xc[:, :2] / Xc[:, 2:3] + rng.normal(0, 0.5, (n, 2)))
+
+        pn = [pnp(n_corr) for _ in range(64)]
+        pX = np.concatenate([pn[p % 64][0] for p in range(n_img)])
+        px = np.concatenate([pn[p % 64][1] for p in range(n_img)])
+        rl = [rel(n_corr) for _ in range(64)]
+        ra = np.concatenate([rl[p % 64][0] for p in range(n_img)])
+        rb = np.concatenate([rl[p % 64][1] for p in range(n_img)])
+        poff = (np.arange(n_img + 1) * n_corr).astype(np.int32)
+        ctx.epnp_ransac(poff[:9], pX[:8 * n_corr], px[:8 * n_corr], 4800.0)      # warm-up
+        ctx.relpose_5pt(poff[:9], ra[:8 * n_corr], rb[:8 * n_corr], 4800.0, 4800.0)
+        ctx.profile(True)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        _, _, _, pavg, _ = ctx.epnp_ransac(poff, pX, px, 4800.0)
+        p_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, _, _, rok, rnc = ctx.relpose_5pt(poff, ra, rb, 4800.0, 4800.0)
+        r_s = time.perf_counter() - t0
+        pst = ctx.profile_get()
+        ctx.profile(False)
+        pk = sum(pst[k]["total_ms"] for k in ("pose_epnp_hyp", "pose_epnp_select") if k in pst)
+        rk = sum(pst[k]["total_ms"] for k in ("pose_e5_hyp", "pose_e5_score", "pose_e5_select") if k in pst)
+        out["pose_initialisers"] = dict(
+            absolute=dict(metric="images localised/sec", value=n_img / p_s, unit="images/s", images=n_img, correspondences_per_image=n_corr,
+                          samples_per_image=200, localised=int((pavg < 5.0).sum()), kernel_ms=pk,
+                          kernel_images_per_sec=(n_img / (pk * 1e-3)) if pk else None, kernels={k: pst[k] for k in pst if k.startswith("pose_epnp")}),
+            relative=dict(metric="pairs oriented/sec", value=n_img / r_s, unit="pairs/s", pairs=n_img, matches_per_pair=n_corr, samples_per_pair=100,
+                          oriented=int(rok.sum()), mean_candidates=float(rnc.mean()), kernel_ms=rk,
+                          kernel_pairs_per_sec=(n_img / (rk * 1e-3)) if rk else None, kernels={k: pst[k] for k in pst if k.startswith("pose_e5")}),
+            dtype="f64", note="host arrays in, host arrays out (PCIe inclusive); EPnP on 4-point samples / Nister five-point, one GPU thread per sample")
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            t0 = time.perf_counter()
+            O.epnp_ransac(poff[:33], pX[:32 * n_corr], px[:32 * n_corr], 4800.0)
+            out["pose_initialisers"]["absolute"]["cpu_baseline"] = dict(value=32 / (time.perf_counter() - t0), unit="images/s", cores=1, kind="port",
+                                                                        sample="32 images by the sequential CPU oracle")
+            t0 = time.perf_counter()
+            O.relpose_5pt(poff[:33], ra[:32 * n_corr], rb[:32 * n_corr], 4800.0, 4800.0)
+            out["pose_initialisers"]["relative"]["cpu_baseline"] = dict(value=32 / (time.perf_counter() - t0), unit="pairs/s", cores=1, kind="port",
+                                                                        sample="32 pairs by the sequential CPU oracle")
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     if world == 1 and not args.no_cpu_baseline:

@@ -366,6 +366,60 @@ bool GeoVerification::GeoVerificationFundamental(std::vector<Point2f>& pt1, std:
   return true;
 }
 
+// ---- pose initialisers ----
+static const uint64_t kPoseSeed = 0x4D53464D50ull;
+
+void AbsolutePoseBatch(const std::vector<std::vector<Vec3>>& pts_w, const std::vector<std::vector<Vec2>>& pts_2d, const std::vector<double>& f,
+                       std::vector<RTPose>& poses, std::vector<std::vector<double>>& errors, std::vector<double>& avg_error) {
+  const int n = (int)pts_w.size();
+  std::vector<int> off(n + 1, 0);
+  for (int p = 0; p < n; p++) off[p + 1] = off[p] + (int)pts_w[p].size();
+  std::vector<double> X(3 * (size_t)std::max(1, off[n])), x(2 * (size_t)std::max(1, off[n])), R(9 * (size_t)std::max(1, n)),
+      t(3 * (size_t)std::max(1, n)), err(std::max(1, off[n]));
+  for (int p = 0; p < n; p++)
+    for (size_t i = 0; i < pts_w[p].size(); i++) {
+      const size_t e = off[p] + i;
+      for (int k = 0; k < 3; k++) X[3 * e + k] = pts_w[p][i][k];
+      x[2 * e] = pts_2d[p][i].x; x[2 * e + 1] = pts_2d[p][i].y;
+    }
+  avg_error.assign(std::max(1, n), 0.0);
+  check(msfm_epnp_ransac_batch(Context(), n, off.data(), X.data(), x.data(), f.data(), 200, kPoseSeed, R.data(), t.data(), err.data(),
+                               avg_error.data(), nullptr), "epnp_ransac_batch");
+  avg_error.resize(n);
+  poses.resize(n); errors.resize(n);
+  for (int p = 0; p < n; p++) {
+    for (int k = 0; k < 9; k++) poses[p].R.m[k] = R[9 * (size_t)p + k];
+    for (int k = 0; k < 3; k++) poses[p].t[k] = t[3 * (size_t)p + k];
+    errors[p].assign(err.begin() + off[p], err.begin() + off[p + 1]);
+  }
+}
+
+bool AbsolutePoseEstimation::AbsolutePoseWithFocalLength(std::vector<Vec3>& pts_w, std::vector<Vec2>& pts_2d, double f, RTPose& pose_absolute,
+                                                         std::vector<double>& errors, double& avg_error) {
+  std::vector<RTPose> poses;
+  std::vector<std::vector<double>> errs;
+  std::vector<double> avg;
+  AbsolutePoseBatch({pts_w}, {pts_2d}, {f}, poses, errs, avg);
+  pose_absolute = poses[0];
+  errors = errs[0];
+  avg_error = avg[0];
+  return true;  // the reference always returns true; the caller gates on avg_error (sfm_incremental.cc:648)
+}
+
+bool RelativePoseEstimation::RelativePoseWithFocalLength(std::vector<Vec2>& pts_ref, std::vector<Vec2>& pts_cur, double f_ref, double f_cur,
+                                                         RTPoseRelative& pose_relative) {
+  const int off[2] = {0, (int)pts_cur.size()};
+  std::vector<double> a(2 * (size_t)std::max(1, off[1])), b(a.size());
+  for (int i = 0; i < off[1]; i++) { a[2 * i] = pts_ref[i].x; a[2 * i + 1] = pts_ref[i].y; b[2 * i] = pts_cur[i].x; b[2 * i + 1] = pts_cur[i].y; }
+  double E[9], R[9], t[3];
+  uint8_t ok = 0;
+  check(msfm_relpose_5pt_batch(Context(), 1, off, a.data(), b.data(), &f_ref, &f_cur, 100, kPoseSeed, E, R, t, &ok, nullptr), "relpose_5pt_batch");
+  if (!ok) return false;
+  for (int k = 0; k < 9; k++) pose_relative.R.m[k] = R[k];
+  for (int k = 0; k < 3; k++) pose_relative.t[k] = t[k];
+  return true;
+}
+
 std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<PairMatches>& matches,
                                                           const std::vector<std::vector<Point2f>>& keypoints) {
   const int np = (int)matches.size();

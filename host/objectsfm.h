@@ -159,6 +159,25 @@ class GeoVerification {
 std::vector<std::vector<std::pair<int, int>>> VerifyPairs(const std::vector<PairMatches>& matches,
                                                           const std::vector<std::vector<Point2f>>& keypoints);
 
+// Pose initialisers (SfM/src/orientation/{absolute,relative}_pose_estimation.h).  Eigen::Vector3d / Vector2d / Matrix3d
+// become Vec3 / Vec2 / Mat3; RTPoseRelative has the fields of RTPose (basic_structs.h:126-138).
+typedef RTPose RTPoseRelative;
+class AbsolutePoseEstimation {
+ public:
+  // EPnP RANSAC (200 samples of 4 correspondences) + per-point reprojection errors   (absolute_pose_estimation.cc:42-58)
+  static bool AbsolutePoseWithFocalLength(std::vector<Vec3>& pts_w, std::vector<Vec2>& pts_2d, double f, RTPose& pose_absolute,
+                                          std::vector<double>& errors, double& avg_error);
+};
+class RelativePoseEstimation {
+ public:
+  // five-point RANSAC on points / f, then the pose from the best essential matrix     (relative_pose_estimation.cc:91-120)
+  static bool RelativePoseWithFocalLength(std::vector<Vec2>& pts_ref, std::vector<Vec2>& pts_cur, double f_ref, double f_cur,
+                                          RTPoseRelative& pose_relative);
+};
+// Many images / pairs in one call each (the batched form the GPU wants; same results as the per-item calls above).
+void AbsolutePoseBatch(const std::vector<std::vector<Vec3>>& pts_w, const std::vector<std::vector<Vec2>>& pts_2d, const std::vector<double>& f,
+                       std::vector<RTPose>& poses, std::vector<std::vector<double>>& errors, std::vector<double>& avg_error);
+
 // The per-image feature file of the extraction stage (Database::WriteoutImageFeature / ReadinImageFeatures,
 // SfM/src/database.cc:490-541, :352-423): header, centred keypoints, raw descriptors.  cv::Mat -> flat float rows.
 struct ImageInfo {  // basic_structs.h ImageInfo

@@ -6,6 +6,7 @@
 // `int main`, no hard-coded Windows paths; exits non-zero if a stage misbehaves.
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <numeric>
 #include <random>
@@ -153,6 +154,55 @@ int main() {
   for (size_t i = 0; i < pp.size(); i++) { n_ok += ok[i] != 0; pp[i]->is_bad_estimated_ = !ok[i]; }
   std::printf("triangulation: %zu tracks, %zu accepted\n", pp.size(), n_ok);
   if (n_ok < 0.9 * pp.size()) { std::printf("FAIL: triangulation\n"); return 1; }
+  // --- stage 2b: the pose initialisers of the incremental loop ---
+  // seed pair (sfm_incremental.cc:296-318): relative pose of image 1 against image 0 from their verified matches
+  {
+    size_t k1 = 0;
+    while (k1 < ids0.size() && ids0[k1] != 1) k1++;
+    if (k1 == ids0.size()) { std::printf("FAIL: no matches between images 0 and 1\n"); return 1; }
+    std::vector<Vec2> pts1, pts2;
+    for (auto& m : m0[k1]) { pts1.push_back(kp[0][m.first]); pts2.push_back(kp[1][m.second]); }
+    RTPoseRelative rt21;
+    if (!RelativePoseEstimation::RelativePoseWithFocalLength(pts1, pts2, f, f, rt21)) { std::printf("FAIL: RelativePoseWithFocalLength\n"); return 1; }
+    Mat3 Rt;  // Xc1 = R1 R0^T Xc0 + ...
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        Rt(r, c) = 0;
+        for (int k = 0; k < 3; k++) Rt(r, c) += cams[1].pos_rt_.R(r, k) * cams[0].pos_rt_.R(c, k);
+      }
+    double dR = 0;
+    for (int k = 0; k < 9; k++) dR = std::max(dR, std::fabs(rt21.R.m[k] - Rt.m[k]));
+    std::printf("seed pair: %zu matches, relative rotation off by %.2e\n", pts1.size(), dR);
+    if (!(dR < 2e-2)) { std::printf("FAIL: relative pose\n"); return 1; }
+  }
+  // localisation (sfm_incremental.cc:560-700): every camera against the triangulated points it observes, EPnP RANSAC
+  {
+    std::vector<std::vector<Vec3>> pw(n_cams);
+    std::vector<std::vector<Vec2>> p2(n_cams);
+    for (Point3D* p : pp) {
+      if (p->is_bad_estimated_) continue;
+      for (auto& o : p->pts2d_) {
+        Vec3 xw; for (int k = 0; k < 3; k++) xw[k] = p->data[k];
+        pw[o.first].push_back(xw);
+        p2[o.first].push_back(o.second);
+      }
+    }
+    std::vector<RTPose> poses;
+    std::vector<std::vector<double>> errs;
+    std::vector<double> avg;
+    AbsolutePoseBatch(pw, p2, std::vector<double>(n_cams, f), poses, errs, avg);
+    double worst_avg = 0, worst_R = 0;
+    for (int i = 0; i < n_cams; i++) {
+      worst_avg = std::max(worst_avg, avg[i]);
+      for (int k = 0; k < 9; k++) worst_R = std::max(worst_R, std::fabs(poses[i].R.m[k] - cams[i].pos_rt_.R.m[k]));
+    }
+    std::printf("localisation: %d cameras, worst avg_error %.3f px (th_mse_localization 5.0), worst rotation error %.2e\n", n_cams, worst_avg, worst_R);
+    if (!(worst_avg < 5.0) || !(worst_R < 2e-2)) { std::printf("FAIL: absolute pose\n"); return 1; }
+    // the single-image entry point gives the same answer as its row of the batch
+    RTPose one; std::vector<double> e1; double a1 = 0;
+    AbsolutePoseEstimation::AbsolutePoseWithFocalLength(pw[0], p2[0], f, one, e1, a1);
+    if (a1 != avg[0] || std::memcmp(one.R.m, poses[0].R.m, sizeof one.R.m) != 0) { std::printf("FAIL: batch / single mismatch\n"); return 1; }
+  }
   // --- stage 3: full bundle adjustment as the seed reconstruction runs it (is_initial_run = true) ---
   std::vector<Camera*> cp;
   for (auto& c : cams) cp.push_back(&c);
