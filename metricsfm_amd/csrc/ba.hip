@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <thread>
 
 #include "ba_device.h"
 #include "common.h"
@@ -780,6 +781,10 @@ __global__ void k_check_finite(int n, const double* __restrict__ z, int* fail) {
 }
 
 __global__ void k_zero_int(int* p) { *p = 0; }
+__global__ void k_fill(int n, double v, double* __restrict__ p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
 
 // Multi-rank exchange of the camera-camera part of the reduced system: only the 6x6 blocks that
 // exist on some rank travel (C3: 9335 blocks = 2.7 MB instead of the 72 MB dense square).
@@ -990,6 +995,27 @@ static int partition_cameras(const CamGraph& G, int tail_cols, int force_depth, 
 
 static bool is_mut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
 
+// Host-side helper of msfm_ba_create: the index structures of a 10^6-observation problem are built by a few threads
+// (MSFM_HOST_THREADS, default min(hardware threads, 8)); fn(t, begin, end) gets one contiguous range per thread.
+static int host_threads() {
+  static const int n = [] {
+    const char* e = getenv("MSFM_HOST_THREADS");
+    const int v = e ? atoi(e) : std::min(8, (int)std::thread::hardware_concurrency());
+    return std::max(1, std::min(v, 64));
+  }();
+  return n;
+}
+template <class F>
+static void par_ranges(size_t n, int nt, F&& fn) {
+  nt = (int)std::max<size_t>(1, std::min<size_t>(nt, n / 4096 + 1));
+  if (nt == 1) { fn(0, (size_t)0, n); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; t++) th.emplace_back([&fn, t, n, nt] { fn(t, n * t / nt, n * (t + 1) / nt); });
+  fn(0, (size_t)0, n / nt);
+  for (auto& x : th) x.join();
+}
+
 // Build chunk / block lists from pair entries already sorted by block key.
 static int finish_jobs(msfm_ba* ba, PairJobs& J, const std::vector<int>& pa, const std::vector<int>& pb,
                        const std::vector<long>& key_first /*per present block: first entry*/, const std::vector<int>& brow,
@@ -1059,11 +1085,20 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   for (int c = 0; c < P->n_cams; c++)
     if (P->cam_model_of_cam[c] < 0 || P->cam_model_of_cam[c] >= P->n_models)
       return msfm_set_error(ctx, MSFM_E_INVAL, "cam_model_of_cam[%d] out of range", c);
-  for (int o = 0; o < P->n_obs; o++) {
-    if (P->obs_cam[o] < 0 || P->obs_cam[o] >= P->n_cams || P->obs_pt[o] < 0 || P->obs_pt[o] >= P->n_points)
-      return msfm_set_error(ctx, MSFM_E_INVAL, "observation %d: index out of range", o);
-    if (o > 0 && P->obs_pt[o] < P->obs_pt[o - 1])
-      return msfm_set_error(ctx, MSFM_E_INVAL, "obs_pt must be non-decreasing (gather order, optimizer.cc:62)");
+  {
+    const int nt = host_threads();
+    std::vector<long> bad_range(nt, -1), bad_order(nt, -1);
+    par_ranges((size_t)P->n_obs, nt, [&](int t, size_t o0, size_t o1) {
+      for (size_t o = o0; o < o1; o++) {
+        if (bad_range[t] < 0 && (P->obs_cam[o] < 0 || P->obs_cam[o] >= P->n_cams || P->obs_pt[o] < 0 || P->obs_pt[o] >= P->n_points)) bad_range[t] = (long)o;
+        if (bad_order[t] < 0 && o > 0 && P->obs_pt[o] < P->obs_pt[o - 1]) bad_order[t] = (long)o;
+      }
+    });
+    for (int t = 0; t < nt; t++) {   // the first offender in input order, range errors first (as the sequential check reported them)
+      if (bad_range[t] >= 0 && (bad_order[t] < 0 || bad_range[t] <= bad_order[t]))
+        return msfm_set_error(ctx, MSFM_E_INVAL, "observation %d: index out of range", (int)bad_range[t]);
+      if (bad_order[t] >= 0) return msfm_set_error(ctx, MSFM_E_INVAL, "obs_pt must be non-decreasing (gather order, optimizer.cc:62)");
+    }
   }
   const auto t0 = std::chrono::steady_clock::now();
   const bool verbose = getenv("MSFM_VERBOSE") != nullptr;
@@ -1080,15 +1115,25 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   const int Nc = ba->Nc = P->n_cams, Nm = ba->Nm = P->n_models, Np = ba->Np = P->n_points, No = P->n_obs;
   // ---- which parameter blocks exist (a block exists iff some residual uses it) ----
   std::vector<int> cam_slot(Nc, -1), model_slot(Nm, -1), pt_slot(Np, -1);
+  std::vector<int> run_first;
   {
     std::vector<char> cu(Nc, 0), mu(Nm, 0), pu(Np, 0);
-    for (int o = 0; o < No; o++) {
-      const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
-      const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
-      if (!cm && !pm) continue;
-      if (pm) pu[p] = 1;
-      if (cm) { cu[c] = 1; if (is_mut(P->model_mutable, m)) mu[m] = 1; }
-    }
+    par_ranges((size_t)No, host_threads(), [&](int, size_t o0, size_t o1) {   // all stores write 1: relaxed byte stores
+      for (size_t o = o0; o < o1; o++) {
+        const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
+        const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
+        if (!cm && !pm) continue;
+        if (pm && !pu[p]) __atomic_store_n(&pu[p], (char)1, __ATOMIC_RELAXED);
+        if (cm) {
+          if (!cu[c]) __atomic_store_n(&cu[c], (char)1, __ATOMIC_RELAXED);
+          if (is_mut(P->model_mutable, m) && !mu[m]) __atomic_store_n(&mu[m], (char)1, __ATOMIC_RELAXED);
+        }
+      }
+    });
+    // input runs per point (obs_pt is non-decreasing)
+    run_first.assign(Np + 1, 0);
+    for (int o = 0; o < No; o++) run_first[P->obs_pt[o] + 1]++;
+    for (int p = 0; p < Np; p++) run_first[p + 1] += run_first[p];
     if (P->gps_xyz) for (int c = 0; c < Nc; c++) if (is_mut(P->cam_mutable, c)) cu[c] = 1;
     if (ctx->world > 1) {
       // points are sharded over ranks: the block structure of the reduced system must be the same
@@ -1108,19 +1153,21 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     const int force = env ? atoi(env) : -1;
     if (ng >= 128 && ng <= 4096 && force != 0) {
       // adjacency as a 0/1 matrix: cameras sharing an eliminated point; max-reduced over the ranks' shards
-      std::vector<double> adjm((size_t)ng * ng, 0.0);
-      std::vector<int> run;
-      for (int o = 0; o < No;) {
-        const int p = P->obs_pt[o];
-        run.clear();
-        int e = o;
-        for (; e < No && P->obs_pt[e] == p; e++)
-          if (gnode[P->obs_cam[e]] >= 0) run.push_back(gnode[P->obs_cam[e]]);
-        if (is_mut(P->pt_mutable, p))
-          for (int a : run) for (int b : run) if (a != b) adjm[(size_t)a * ng + b] = 1.0;
-        o = e;
-      }
+      std::vector<char> adjb((size_t)ng * ng, 0);
+      par_ranges((size_t)Np, host_threads(), [&](int, size_t p0, size_t p1) {
+        std::vector<int> run;
+        for (size_t p = p0; p < p1; p++) {
+          if (!is_mut(P->pt_mutable, (int)p)) continue;
+          run.clear();
+          for (int e = run_first[p]; e < run_first[p + 1]; e++)
+            if (gnode[P->obs_cam[e]] >= 0) run.push_back(gnode[P->obs_cam[e]]);
+          for (int a : run) for (int b : run) if (a != b && !adjb[(size_t)a * ng + b]) __atomic_store_n(&adjb[(size_t)a * ng + b], (char)1, __ATOMIC_RELAXED);
+        }
+      });
+      std::vector<double> adjm;
       if (ctx->world > 1) {
+        adjm.resize((size_t)ng * ng);
+        for (size_t k = 0; k < adjm.size(); k++) adjm[k] = adjb[k] ? 1.0 : 0.0;
         DevBuf<double> dadj;
         HIP_TRY(ctx, dadj.from(adjm, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1128,12 +1175,13 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
         if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce hook failed: %d", rc);
         HIP_TRY(ctx, hipMemcpyAsync(adjm.data(), dadj.p, sizeof(double) * adjm.size(), hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        for (size_t k = 0; k < adjm.size(); k++) adjb[k] = adjm[k] != 0.0;
       }
       CamGraph G;
       G.n = ng;
       G.adj.resize(ng);
       for (int a = 0; a < ng; a++)
-        for (int b = 0; b < ng; b++) if (adjm[(size_t)a * ng + b] != 0.0) G.adj[a].push_back(b);
+        for (int b = 0; b < ng; b++) if (adjb[(size_t)a * ng + b]) G.adj[a].push_back(b);
       K = partition_cameras(G, 3 * ba->nmb + 1, force, label);
       if (getenv("MSFM_VERBOSE") && ctx->rank == 0) {
         std::vector<int> cnt(K + 1, 0);
@@ -1170,25 +1218,38 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     if (!getenv("MSFM_POINT_ORDER") || atoi(getenv("MSFM_POINT_ORDER")) != 0) {
       // key: the four smallest camera blocks, 16 bits each (21 bits x 3 when there are more than 65535 blocks)
       const bool wide = ba->ncb >= 0xFFFF;
-      std::vector<std::pair<uint64_t, int>> keyed;
-      keyed.reserve(ba->h_pb_pt.size());
-      std::vector<int> cams;
-      for (int o = 0; o < No;) {
-        const int p = P->obs_pt[o];
-        cams.clear();
-        int e = o;
-        for (; e < No && P->obs_pt[e] == p; e++)
-          if (cam_slot[P->obs_cam[e]] >= 0) cams.push_back(cam_slot[P->obs_cam[e]]);
-        if (pu[p]) {
+      std::vector<std::pair<uint64_t, int>> keyed(ba->h_pb_pt.size());
+      const int nk = wide ? 3 : 4, bits = wide ? 21 : 16;
+      par_ranges(keyed.size(), host_threads(), [&](int, size_t i0, size_t i1) {
+        std::vector<int> cams;
+        for (size_t i = i0; i < i1; i++) {
+          const int p = ba->h_pb_pt[i];   // still in ascending point order here
+          cams.clear();
+          for (int e = run_first[p]; e < run_first[p + 1]; e++)
+            if (cam_slot[P->obs_cam[e]] >= 0) cams.push_back(cam_slot[P->obs_cam[e]]);
           std::sort(cams.begin(), cams.end());
           uint64_t k = 0;
-          const int nk = wide ? 3 : 4, bits = wide ? 21 : 16;
-          for (int i = 0; i < nk; i++) k = (k << bits) | (uint64_t)(i < (int)cams.size() ? cams[i] : ((1 << bits) - 1));
-          keyed.push_back({k, p});
+          for (int q = 0; q < nk; q++) k = (k << bits) | (uint64_t)(q < (int)cams.size() ? cams[q] : ((1 << bits) - 1));
+          keyed[i] = {k, p};
         }
-        o = e;
+      });
+      {  // sort: pieces in parallel, then pairwise merges (ties fall back to the caller's point index)
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>(host_threads(), keyed.size() / 8192 + 1));
+        std::vector<size_t> cut(nt + 1);
+        for (int t = 0; t <= nt; t++) cut[t] = keyed.size() * t / nt;
+        {
+          std::vector<std::thread> th;
+          for (int t = 1; t < nt; t++) th.emplace_back([&, t] { std::sort(keyed.begin() + cut[t], keyed.begin() + cut[t + 1]); });
+          std::sort(keyed.begin() + cut[0], keyed.begin() + cut[1]);
+          for (auto& x : th) x.join();
+        }
+        for (int w = 1; w < nt; w *= 2) {
+          std::vector<std::thread> th;
+          for (int t = 0; t + w < nt; t += 2 * w)
+            th.emplace_back([&, t, w] { std::inplace_merge(keyed.begin() + cut[t], keyed.begin() + cut[t + w], keyed.begin() + cut[std::min(nt, t + 2 * w)]); });
+          for (auto& x : th) x.join();
+        }
       }
-      std::sort(keyed.begin(), keyed.end());  // ties fall back to the caller's point index
       if (keyed.size() == ba->h_pb_pt.size())
         for (size_t i = 0; i < keyed.size(); i++) ba->h_pb_pt[i] = keyed[i].second;
     }
@@ -1212,62 +1273,86 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   ba->gps_weight = P->gps_weight;
   lap("blocks + orders");
   // ---- active observations: eliminated-point rows first (point-major), then the rest ----
+  // Every observation of an eliminated point is active (its point block is free), so row i of point block pb is
+  // input observation run_first[p] + (i - pt_first[pb]): the arrays are filled in place by a few threads.
   std::vector<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
   std::vector<double> o_x, o_y, o_w;
   std::vector<int> pt_first(npb + 1, 0);
-  for (auto* v : {&o_cam, &o_model, &o_pt, &o_cb, &o_mb, &o_pb}) v->reserve(No);
-  for (auto* v : {&o_x, &o_y, &o_w}) v->reserve(No);
-  // input runs per point (obs_pt is non-decreasing): pass 0 walks the eliminated points in block order
-  std::vector<int> run_first(Np + 1, 0);
-  for (int o = 0; o < No; o++) run_first[P->obs_pt[o] + 1]++;
-  for (int p = 0; p < Np; p++) run_first[p + 1] += run_first[p];
-  auto take = [&](int o, int pass) {
-    const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
-    const bool cm = is_mut(P->cam_mutable, c), pm = is_mut(P->pt_mutable, p);
-    if (!cm && !pm) return;
-    if ((pass == 0) != pm) return;
-    o_cam.push_back(c); o_model.push_back(m); o_pt.push_back(p);
-    o_cb.push_back(cm ? cam_slot[c] : -1);
-    o_mb.push_back((cm && is_mut(P->model_mutable, m)) ? model_slot[m] : -1);
-    o_pb.push_back(pm ? pt_slot[p] : -1);
-    if (pm) pt_first[pt_slot[p] + 1]++;
-    o_x.push_back(P->obs_xy[2 * (size_t)o]); o_y.push_back(P->obs_xy[2 * (size_t)o + 1]);
-    o_w.push_back(P->pt_weight ? P->pt_weight[p] : 1.0);
-  };
-  // pass 0: the eliminated points in block order (their input runs are scattered: fetch a few points ahead)
-  for (int pb = 0; pb < ba->npb; pb++) {
-    if (pb + 8 < ba->npb) {
-      const int on = run_first[ba->h_pb_pt[pb + 8]];
-      __builtin_prefetch(&P->obs_cam[on]);
-      __builtin_prefetch(&P->obs_xy[2 * (size_t)on]);
-      __builtin_prefetch(&P->obs_xy[2 * (size_t)on + 8]);
-    }
-    for (int o = run_first[ba->h_pb_pt[pb]]; o < run_first[ba->h_pb_pt[pb] + 1]; o++) take(o, 0);
+  for (int pb = 0; pb < npb; pb++) pt_first[pb + 1] = pt_first[pb] + (run_first[ba->h_pb_pt[pb] + 1] - run_first[ba->h_pb_pt[pb]]);
+  ba->AE = pt_first[npb];
+  {
+    const size_t AE = (size_t)ba->AE;
+    for (auto* v : {&o_cam, &o_model, &o_pt, &o_cb, &o_mb, &o_pb}) v->resize(AE);
+    for (auto* v : {&o_x, &o_y, &o_w}) v->resize(AE);
+    par_ranges((size_t)npb, host_threads(), [&](int, size_t b0, size_t b1) {
+      for (size_t pb = b0; pb < b1; pb++) {
+        const int p = ba->h_pb_pt[pb];
+        int i = pt_first[pb];
+        const double w = P->pt_weight ? P->pt_weight[p] : 1.0;
+        for (int o = run_first[p]; o < run_first[p + 1]; o++, i++) {
+          const int c = P->obs_cam[o], m = P->cam_model_of_cam[c];
+          const bool cm = is_mut(P->cam_mutable, c);
+          o_cam[i] = c; o_model[i] = m; o_pt[i] = p;
+          o_cb[i] = cm ? cam_slot[c] : -1;
+          o_mb[i] = (cm && is_mut(P->model_mutable, m)) ? model_slot[m] : -1;
+          o_pb[i] = (int)pb;
+          o_x[i] = P->obs_xy[2 * (size_t)o]; o_y[i] = P->obs_xy[2 * (size_t)o + 1];
+          o_w[i] = w;
+        }
+      }
+    });
   }
-  ba->AE = (int)o_cam.size();
-  // pass 1: observations of frozen points by free cameras, in input order
-  if (P->pt_mutable) for (int o = 0; o < No; o++) take(o, 1);  // (no mask: every point is eliminated)
-  for (int i = 0; i < npb; i++) pt_first[i + 1] += pt_first[i];
+  // pass 1: observations of frozen points by free cameras, in input order (only with a point mask)
+  if (P->pt_mutable)
+    for (int o = 0; o < No; o++) {
+      const int c = P->obs_cam[o], p = P->obs_pt[o], m = P->cam_model_of_cam[c];
+      if (is_mut(P->pt_mutable, p) || !is_mut(P->cam_mutable, c)) continue;
+      o_cam.push_back(c); o_model.push_back(m); o_pt.push_back(p);
+      o_cb.push_back(cam_slot[c]);
+      o_mb.push_back(is_mut(P->model_mutable, m) ? model_slot[m] : -1);
+      o_pb.push_back(-1);
+      o_x.push_back(P->obs_xy[2 * (size_t)o]); o_y.push_back(P->obs_xy[2 * (size_t)o + 1]);
+      o_w.push_back(P->pt_weight ? P->pt_weight[p] : 1.0);
+    }
   const int A = ba->A = (int)o_cam.size();
   ba->n_residuals = 2 * A + (ba->has_gps ? 3 * ncb : 0);
   lap("active observations");
-  // ---- camera-major positions ----
+  // ---- camera-major positions (a counting sort by camera block that keeps the row order inside a block) ----
   std::vector<int> cam_first(ncb + 1, 0);
-  for (int i = 0; i < A; i++) if (o_cb[i] >= 0) cam_first[o_cb[i] + 1]++;
-  for (int c = 0; c < ncb; c++) cam_first[c + 1] += cam_first[c];
-  const int NCR = ba->NCR = cam_first[ncb];
   o_cpos.assign(A, -1);
-  std::vector<int> cpos_pb(std::max(1, NCR), -1), cpos_cb(std::max(1, NCR), -1);
+  int NCR = 0;
+  std::vector<int> cpos_pb, cpos_cb;
   {
-    std::vector<int> fill(cam_first.begin(), cam_first.end() - 1);
-    for (int i = 0; i < A; i++)
-      if (o_cb[i] >= 0) {
-        const int pos = fill[o_cb[i]]++;
-        o_cpos[i] = pos;
-        cpos_pb[pos] = o_pb[i];
-        cpos_cb[pos] = o_cb[i];
-      }
+    const int nt = host_threads();
+    std::vector<std::vector<int>> hist(nt, std::vector<int>(ncb + 1, 0));
+    std::vector<size_t> lo(nt, 0), hi(nt, 0);
+    par_ranges((size_t)A, nt, [&](int t, size_t i0, size_t i1) {
+      lo[t] = i0; hi[t] = i1;
+      int* h = hist[t].data();
+      for (size_t i = i0; i < i1; i++) if (o_cb[i] >= 0) h[o_cb[i]]++;
+    });
+    // hist[t][c] -> first position of thread t's rows of camera c
+    int run = 0;
+    for (int c = 0; c < ncb; c++) {
+      cam_first[c] = run;
+      for (int t = 0; t < nt; t++) { const int n = hist[t][c]; hist[t][c] = run; run += n; }
+    }
+    cam_first[ncb] = NCR = run;
+    cpos_pb.assign(std::max(1, NCR), -1);
+    cpos_cb.assign(std::max(1, NCR), -1);
+    par_ranges((size_t)A, nt, [&](int t, size_t, size_t) {
+      int* h = hist[t].data();
+      for (size_t i = lo[t]; i < hi[t]; i++)
+        if (o_cb[i] >= 0) {
+          const int pos = h[o_cb[i]]++;
+          o_cpos[i] = pos;
+          cpos_pb[pos] = o_pb[i];
+          cpos_cb[pos] = o_cb[i];
+        }
+    });
   }
+  ba->NCR = NCR;
+  lap("  camera positions");
   // ---- (point, intrinsics block) entries ----
   std::vector<int> pm_first(npb + 1, 0), pm_mb;
   o_pm.assign(A, -1);
@@ -1317,9 +1402,13 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   auto build_pairs = [&](int kind, PairJobs& J, int nout) -> int {
     // kind 0: cam-cam (rows cb_a >= cols cb_b), 1: intr-cam, 2: intr-intr (mb_a >= mb_b)
     const long nrow = kind == 0 ? ncb : nmb, ncol = kind == 2 ? nmb : ncb;
-    std::vector<long> cnt((size_t)(nrow * ncol) + 1, 0);
-    auto visit = [&](auto&& emit) {
-      for (int pb = 0; pb < npb; pb++) {
+    const size_t nkey = (size_t)(nrow * ncol);
+    // counting sort by block key with one histogram per thread (each thread owns a contiguous range of points, so the
+    // entries of a block stay in point order); the histograms are capped at 256 MB in total
+    int nt = host_threads();
+    while (nt > 1 && nkey * sizeof(int) * nt > (size_t)256 << 20) nt--;
+    auto visit = [&](size_t pb0, size_t pb1, auto&& emit) {
+      for (size_t pb = pb0; pb < pb1; pb++) {
         const int f = pt_first[pb], l = pt_first[pb + 1];
         if (kind == 0) {
           for (int i = f; i < l; i++) {
@@ -1338,15 +1427,36 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
         }
       }
     };
-    visit([&](int r, int c, int, int) { cnt[(size_t)r * ncol + c + 1]++; });
-    if (kind == 0) for (int c = 0; c < ncb; c++) (void)c;  // diagonal blocks are forced below
-    std::vector<long> first(cnt.size(), 0);
-    for (size_t k = 1; k < cnt.size(); k++) first[k] = first[k - 1] + cnt[k];
-    const long total = first.back();
+    std::vector<std::vector<int>> hist(nt);
+    std::vector<size_t> lo(nt, 0), hi(nt, 0);
+    par_ranges((size_t)npb, nt, [&](int t, size_t b0, size_t b1) {
+      lo[t] = b0; hi[t] = b1;
+      hist[t].assign(nkey, 0);
+      int* h = hist[t].data();
+      visit(b0, b1, [&](int r, int c, int, int) { h[(size_t)r * ncol + c]++; });
+    });
+    if (kind == 0) lap("  pairs: counted");
+    std::vector<long> first(nkey + 1, 0);
+    std::vector<std::vector<long>> fill(nt);
+    for (int t = 0; t < nt; t++) if (!hist[t].empty()) fill[t].assign(nkey, 0);
+    {
+      long run = 0;
+      for (size_t k = 0; k < nkey; k++) {
+        first[k] = run;
+        for (int t = 0; t < nt; t++) if (!hist[t].empty()) { fill[t][k] = run; run += hist[t][k]; }
+      }
+      first[nkey] = run;
+    }
+    const long total = first[nkey];
     if (total > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_NOMEM, "pair list too long");
+    if (kind == 0) lap("  pairs: offsets");
     std::vector<int> pa((size_t)total), pbv((size_t)total);
-    std::vector<long> fill(first.begin(), first.end() - 1);
-    visit([&](int r, int c, int a, int b) { const long q = fill[(size_t)r * ncol + c]++; pa[q] = a; pbv[q] = b; });
+    par_ranges((size_t)npb, nt, [&](int t, size_t, size_t) {
+      if (fill[t].empty()) return;
+      long* fl = fill[t].data();
+      visit(lo[t], hi[t], [&](int r, int c, int a, int b) { const long q = fl[(size_t)r * ncol + c]++; pa[q] = a; pbv[q] = b; });
+    });
+    if (kind == 0) lap("  pairs: filled");
     std::vector<long> key_first;
     std::vector<int> brow, bcol;
     for (long r = 0; r < nrow; r++)
@@ -1356,6 +1466,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
         if (first[k + 1] > first[k] || force) { key_first.push_back(first[k]); brow.push_back((int)r); bcol.push_back((int)c); }
       }
     key_first.push_back(total);
+    if (kind == 0) lap("  pairs: blocks");
     // key_first of forced empty blocks must still be monotone: it is (first[k] == first[k+1]).
     return finish_jobs(ba, J, pa, pbv, key_first, brow, bcol, nout);
   };
@@ -1383,6 +1494,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   lap("pairs cc");
   MSFM_TRY(build_pairs(1, ba->mc, 18));
   MSFM_TRY(build_pairs(2, ba->mm, 12));
+  lap("pairs mc mm");
   if (ctx->world > 1 && ncb > 0 && ncb <= 4096) {
     // union over ranks of the camera-camera block structure: a 0/1 matrix, max-reduced once
     std::vector<double> ind((size_t)ncb * ncb, 0.0);
@@ -1437,6 +1549,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     for (const void* q : must)
       if (!q) return msfm_set_error(ctx, MSFM_E_NOMEM, "msfm_ba_create: a device buffer was not allocated");
   }
+  lap("allocations");
   ba->swrite = ctx->world > 1 ? ba->sloc.p : ba->scal.p;
   HIP_TRY(ctx, hipMemsetAsync(ba->scal.p, 0, sizeof(double) * S_N, s));
   HIP_TRY(ctx, hipMemsetAsync(ba->sloc.p, 0, sizeof(double) * S_N, s));
@@ -1730,6 +1843,11 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   hipEvent_t ev0, ev1;
+  const auto run_t0 = std::chrono::steady_clock::now();
+  const bool verbose = getenv("MSFM_VERBOSE") != nullptr && ctx->rank == 0;
+  auto lap = [&](const char* what) {
+    if (verbose) fprintf(stderr, "msfm: run %-31s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - run_t0).count());
+  };
   HIP_TRY(ctx, hipEventCreate(&ev0));
   HIP_TRY(ctx, hipEventCreate(&ev1));
   HIP_TRY(ctx, hipEventRecord(ev0, s));
@@ -1743,20 +1861,16 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     rows++;
   };
   const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
-  auto fill_ones = [&](DevBuf<double>& b, size_t n) -> int {
-    std::vector<double> ones(std::max<size_t>(1, n), 1.0);
-    HIP_TRY(ctx, hipMemcpyAsync(b.p, ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    return MSFM_OK;
-  };
-  MSFM_TRY(fill_ones(ba->scale_c, 6 * (size_t)ncb));
-  MSFM_TRY(fill_ones(ba->scale_m, 3 * (size_t)nmb));
-  MSFM_TRY(fill_ones(ba->scale_p, 3 * (size_t)npb));
+  if (ncb) hipLaunchKernelGGL(k_fill, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, 6 * ncb, 1.0, ba->scale_c.p);
+  if (nmb) hipLaunchKernelGGL(k_fill, dim3(cdiv(3 * nmb, 256)), dim3(256), 0, s, 3 * nmb, 1.0, ba->scale_m.p);
+  if (npb) hipLaunchKernelGGL(k_fill, dim3(cdiv(3 * npb, 256)), dim3(256), 0, s, 3 * npb, 1.0, ba->scale_p.p);
+  lap("scales reset");
   hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
   bool reuse_diag = false;
   // ---- IterationZero ----
   MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
+  lap("first evaluate enqueued");
   if (opt->jacobi_scaling) {
     // squared column norms of the corrected, unscaled Jacobian -> scaling -> re-linearise scaled
     MSFM_TRY(run_assemble(ba, opt, radius, false, /*mode=*/1));
@@ -1766,6 +1880,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
   }
   int iteration = 0, num_invalid = 0, termination = 0;
+  lap("iteration zero enqueued");
   // The reduced system and the trust-region step computed from it are enqueued back to back and
   // their scalars read with ONE host synchronisation per LM iteration: the step is speculative
   // only in that a gradient-tolerance stop discards it (it writes the candidate buffers only).
@@ -1787,6 +1902,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     if (it.step_is_successful && iteration > 0) sum->num_successful_steps++;
     it.trust_region_radius = radius;
     push(it);
+    if (verbose && iteration < 6) lap("iteration read back");
     if (opt->progress_to_stdout && ctx->rank == 0)
       printf("%4d  cost %.6e  change %.3e  |grad| %.3e  |step| %.3e  rho %.3e  radius %.3e\n", iteration, it.cost,
              it.cost_change, it.gradient_max_norm, it.step_norm, it.relative_decrease, radius);
@@ -1817,7 +1933,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
       if (std::fabs(it.cost_change) <= opt->function_tolerance * x_cost) { termination = MSFM_BA_CONVERGENCE_FUNCTION; break; }
       it.relative_decrease = (x_cost - cand_cost) / mcc;
       if (it.relative_decrease > opt->min_relative_decrease) {
-        std::swap(ba->cam.p, ba->cam_c.p); std::swap(ba->model.p, ba->model_c.p); std::swap(ba->pt.p, ba->pt_c.p);
+        ba->cam.swap(ba->cam_c); ba->model.swap(ba->model_c); ba->pt.swap(ba->pt_c);
         relinearise = true;
         it.step_is_successful = 1;
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
@@ -1844,8 +1960,10 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   sum->termination = termination;
   sum->num_iterations = rows - 1;
   sum->final_cost = x_cost;
+  lap("loop done");
   HIP_TRY(ctx, hipEventRecord(ev1, s));
   HIP_TRY(ctx, hipEventSynchronize(ev1));
+  lap("synchronised");
   float ms = 0;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ev0, ev1));
   sum->solve_ms = ms;

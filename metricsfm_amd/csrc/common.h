@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/msfm.h"
@@ -56,25 +57,41 @@ struct KTimer {
   ~KTimer();
 };
 
+// Device memory comes from a per-process cache of freed blocks (ctx.hip): a bundle adjustment of the incremental loop
+// allocates ~60 buffers / > 1 GB, and a fresh VRAM allocation costs far more than the hipMalloc call itself (the first
+// kernels that touch it wait 10-20 ms at config 3).  Blocks are returned only after their stream has been synchronised.
+hipError_t msfm_pool_alloc(void** p, size_t bytes, size_t* capacity);
+void msfm_pool_free(void* p, size_t capacity);
+void msfm_pool_trim(int device);
+
 // Simple owning device buffer.
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t cap = 0;  // bytes of the underlying block
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
+  void swap(DevBuf& o) {  // exchanges the blocks (same element count expected by the callers), capacities included
+    std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap);
+  }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) msfm_pool_free(p, cap);
     p = nullptr;
     n = 0;
+    cap = 0;
   }
   hipError_t alloc(size_t count) {
     release();
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
+    void* q = nullptr;
+    const hipError_t e = msfm_pool_alloc(&q, count * sizeof(T), &cap);
+    p = static_cast<T*>(q);
+    if (e != hipSuccess) { p = nullptr; n = 0; cap = 0; }
+    return e;
   }
   hipError_t upload(const T* h, size_t count, hipStream_t s) {
     if (count == 0) return hipSuccess;

@@ -32,10 +32,105 @@ MSFM_API int msfm_ctx_create(int device, msfm_ctx** out) {
   return MSFM_OK;
 }
 
+// ---- cache of freed device blocks (see common.h) ----
+#include <map>
+#include <mutex>
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::map<void*, size_t> live;   // MSFM_POOL_DEBUG: blocks handed out -> capacity
+  std::multimap<std::pair<int, size_t>, void*> free_blocks;  // (device, capacity) -> block
+  size_t cached_bytes = 0;
+  size_t limit() {
+    static const size_t v = [] { const char* e = getenv("MSFM_POOL_MB"); return (size_t)(e ? atol(e) : 16384) << 20; }();
+    return v;
+  }
+};
+Pool& pool() { static Pool* p = new Pool(); return *p; }  // intentionally never destroyed (no hipFree at process exit)
+size_t round_capacity(size_t bytes) {
+  if (bytes <= 4096) return 4096;
+  if (bytes <= ((size_t)2 << 20)) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }   // powers of two up to 2 MB
+  return (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);                            // then multiples of 2 MB
+}
+}  // namespace
+
+hipError_t msfm_pool_alloc(void** p, size_t bytes, size_t* capacity) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t want = round_capacity(bytes);
+  Pool& P = pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    // the smallest cached block that fits and wastes at most half of itself
+    auto it = P.free_blocks.lower_bound({dev, want});
+    if (it != P.free_blocks.end() && it->first.first == dev && it->first.second <= 2 * want) {
+      *p = it->second;
+      *capacity = it->first.second;
+      P.cached_bytes -= it->first.second;
+      P.free_blocks.erase(it);
+      if (getenv("MSFM_POOL_DEBUG")) {
+        if (P.live.count(*p)) { fprintf(stderr, "msfm pool: block %p handed out twice\n", *p); abort(); }
+        P.live[*p] = *capacity;
+      }
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(p, want);
+  if (e != hipSuccess) {  // give the cache back to the driver and try once more
+    msfm_pool_trim(dev);
+    (void)hipGetLastError();
+    e = hipMalloc(p, want);
+  }
+  *capacity = want;
+  if (e == hipSuccess && getenv("MSFM_POOL_DEBUG")) {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (P.live.count(*p)) { fprintf(stderr, "msfm pool: hipMalloc returned a live block %p\n", *p); abort(); }
+    for (auto& kv : P.free_blocks) if (kv.second == *p) { fprintf(stderr, "msfm pool: hipMalloc returned a cached block %p\n", *p); abort(); }
+    P.live[*p] = want;
+  }
+  return e;
+}
+
+void msfm_pool_free(void* p, size_t capacity) {
+  if (!p) return;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Pool& P = pool();
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    if (getenv("MSFM_POOL_DEBUG")) {
+      auto it = P.live.find(p);
+      if (it == P.live.end()) { fprintf(stderr, "msfm pool: free of unknown block %p (capacity %zu)\n", p, capacity); abort(); }
+      if (it->second != capacity) { fprintf(stderr, "msfm pool: block %p freed with capacity %zu, allocated with %zu\n", p, capacity, it->second); abort(); }
+      P.live.erase(it);
+    }
+    if (capacity > 0 && P.cached_bytes + capacity <= P.limit()) {
+      P.free_blocks.insert({{dev, capacity}, p});
+      P.cached_bytes += capacity;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+void msfm_pool_trim(int device) {
+  Pool& P = pool();
+  std::vector<void*> drop;
+  {
+    std::lock_guard<std::mutex> g(P.mu);
+    for (auto it = P.free_blocks.begin(); it != P.free_blocks.end();) {
+      if (it->first.first == device) { drop.push_back(it->second); P.cached_bytes -= it->first.second; it = P.free_blocks.erase(it); }
+      else ++it;
+    }
+  }
+  for (void* q : drop) (void)hipFree(q);
+}
+
 MSFM_API void msfm_ctx_destroy(msfm_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  msfm_pool_trim(ctx->device);
   for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);

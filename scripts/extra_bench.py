@@ -15,9 +15,10 @@ ctx = capi.Context(0)
 out = {}
 # ---- general float descriptors (VLFeat 512*x floats): exact FP64 path ----
 rng = np.random.default_rng(0)
-d = [(rng.gamma(0.6, 1.0, (4096, 128)) * 40).astype(np.float32) for _ in range(4)]
+n_float_images = 24   # 552 ordered pairs: enough workgroups to fill the chip (12 pairs leave it two thirds idle)
+d = [(rng.gamma(0.6, 1.0, (4096, 128)) * 40).astype(np.float32) for _ in range(n_float_images)]
 ds = ctx.descset(d)
-pairs = scene.all_pairs(4)
+pairs = scene.all_pairs(n_float_images)
 res = ds.match_pairs(pairs)
 ctx.synchronize()
 t0 = time.perf_counter()

@@ -1,6 +1,10 @@
 """Parity of the HIP bundle adjustment (through the C ABI) with the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from metricsfm_amd import _abi as A
 from metricsfm_amd import scene
@@ -241,3 +245,22 @@ def test_ba_domains_with_window_masks(ctx, oracle, monkeypatch):
     _, _, a = check_parity(ctx, oracle, arrays, dict(max_num_iterations=10), tol_cost=1e-8)
     np.testing.assert_array_equal(a.cam_pose[cam_mut == 0], sc.cam_pose[cam_mut == 0])     # frozen blocks untouched
     np.testing.assert_array_equal(a.point[pt_mut == 0], sc.point[pt_mut == 0])
+
+
+def test_host_thread_count_does_not_change_the_result():
+    """msfm_ba_create builds its index structures with a few host threads (counting sorts that keep the input order):
+    1 thread and 8 threads must give the same structure, hence bitwise the same solve."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from metricsfm_amd import _abi as A, capi, scene\n"
+            "sc = scene.make_aerial_scene(140, 6000, seed=11)\n"
+            "a = A.BaArrays.from_scene(sc)\n"
+            "r = capi.Context(0).ba_solve(a, capi.default_options(max_num_iterations=8))\n"
+            "print(repr(r['final_cost']), r['num_iterations'], repr(float(a.cam_pose.sum())), repr(float(a.point.sum())))\n") % ROOT
+    outs = []
+    for n in ("1", "8"):
+        env = dict(os.environ, MSFM_HOST_THREADS=n, MSFM_CHOL_DOMAINS="1")
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300))
+        assert outs[-1].returncode == 0, outs[-1].stderr[-2000:]
+    assert outs[0].stdout == outs[1].stdout and outs[0].stdout.strip()
