@@ -1075,9 +1075,28 @@ MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
   delete ba;
 }
 
+// Host work arrays of msfm_ba_create that scale with the observation count; owned by the context and reused.
+struct BaScratch {
+  std::vector<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm, run_first, pt_first, cpos_pb, cpos_cb, pa, pb;
+  std::vector<double> o_x, o_y, o_w;
+  std::vector<std::pair<uint64_t, int>> keyed;
+};
+static BaScratch& ba_scratch(msfm_ctx* ctx) {
+  if (!ctx->ba_scratch) {
+    ctx->ba_scratch = new BaScratch();
+    ctx->ba_scratch_free = [](void* p) { delete static_cast<BaScratch*>(p); };
+  }
+  return *static_cast<BaScratch*>(ctx->ba_scratch);
+}
+
 MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** out) {
   if (!ctx || !P || !out) return MSFM_E_INVAL;
   *out = nullptr;
+  struct ExitLap {   // declared first, destroyed last: the time to the very end of the call, host vectors released
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    bool on = getenv("MSFM_VERBOSE") != nullptr;
+    ~ExitLap() { if (on) fprintf(stderr, "msfm: create returned after          %7.2f ms (from entry)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); }
+  } exit_lap;
   if (P->n_cams <= 0 || P->n_models <= 0 || P->n_points < 0 || P->n_obs < 0 || !P->cam_pose || !P->cam_model ||
       !P->cam_model_of_cam || (P->n_points > 0 && !P->point) ||
       (P->n_obs > 0 && (!P->obs_cam || !P->obs_pt || !P->obs_xy)))
@@ -1102,6 +1121,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   }
   const auto t0 = std::chrono::steady_clock::now();
   const bool verbose = getenv("MSFM_VERBOSE") != nullptr;
+  if (verbose) fprintf(stderr, "msfm: create input checked after     %7.2f ms (from entry)\n", std::chrono::duration<double, std::milli>(t0 - exit_lap.t).count());
   auto lap = [&](const char* what) {
     if (verbose && ctx->rank == 0)
       fprintf(stderr, "msfm: create %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -1114,8 +1134,9 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   ba->world_at_create = ctx->world;
   const int Nc = ba->Nc = P->n_cams, Nm = ba->Nm = P->n_models, Np = ba->Np = P->n_points, No = P->n_obs;
   // ---- which parameter blocks exist (a block exists iff some residual uses it) ----
+  BaScratch& H = ba_scratch(ctx);
   std::vector<int> cam_slot(Nc, -1), model_slot(Nm, -1), pt_slot(Np, -1);
-  std::vector<int> run_first;
+  std::vector<int>& run_first = H.run_first;
   {
     std::vector<char> cu(Nc, 0), mu(Nm, 0), pu(Np, 0);
     par_ranges((size_t)No, host_threads(), [&](int, size_t o0, size_t o1) {   // all stores write 1: relaxed byte stores
@@ -1218,7 +1239,8 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     if (!getenv("MSFM_POINT_ORDER") || atoi(getenv("MSFM_POINT_ORDER")) != 0) {
       // key: the four smallest camera blocks, 16 bits each (21 bits x 3 when there are more than 65535 blocks)
       const bool wide = ba->ncb >= 0xFFFF;
-      std::vector<std::pair<uint64_t, int>> keyed(ba->h_pb_pt.size());
+      std::vector<std::pair<uint64_t, int>>& keyed = H.keyed;
+      keyed.resize(ba->h_pb_pt.size());
       const int nk = wide ? 3 : 4, bits = wide ? 21 : 16;
       par_ranges(keyed.size(), host_threads(), [&](int, size_t i0, size_t i1) {
         std::vector<int> cams;
@@ -1275,9 +1297,10 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   // ---- active observations: eliminated-point rows first (point-major), then the rest ----
   // Every observation of an eliminated point is active (its point block is free), so row i of point block pb is
   // input observation run_first[p] + (i - pt_first[pb]): the arrays are filled in place by a few threads.
-  std::vector<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
-  std::vector<double> o_x, o_y, o_w;
-  std::vector<int> pt_first(npb + 1, 0);
+  std::vector<int>&o_cam = H.o_cam, &o_model = H.o_model, &o_pt = H.o_pt, &o_cb = H.o_cb, &o_mb = H.o_mb, &o_pb = H.o_pb,
+                   &o_cpos = H.o_cpos, &o_pm = H.o_pm, &pt_first = H.pt_first;
+  std::vector<double>&o_x = H.o_x, &o_y = H.o_y, &o_w = H.o_w;
+  pt_first.assign(npb + 1, 0);
   for (int pb = 0; pb < npb; pb++) pt_first[pb + 1] = pt_first[pb] + (run_first[ba->h_pb_pt[pb] + 1] - run_first[ba->h_pb_pt[pb]]);
   ba->AE = pt_first[npb];
   {
@@ -1321,7 +1344,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   std::vector<int> cam_first(ncb + 1, 0);
   o_cpos.assign(A, -1);
   int NCR = 0;
-  std::vector<int> cpos_pb, cpos_cb;
+  std::vector<int>&cpos_pb = H.cpos_pb, &cpos_cb = H.cpos_cb;
   {
     const int nt = host_threads();
     std::vector<std::vector<int>> hist(nt, std::vector<int>(ncb + 1, 0));
@@ -1450,7 +1473,8 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     const long total = first[nkey];
     if (total > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_NOMEM, "pair list too long");
     if (kind == 0) lap("  pairs: offsets");
-    std::vector<int> pa((size_t)total), pbv((size_t)total);
+    std::vector<int>&pa = H.pa, &pbv = H.pb;
+    pa.resize((size_t)total); pbv.resize((size_t)total);
     par_ranges((size_t)npb, nt, [&](int t, size_t, size_t) {
       if (fill[t].empty()) return;
       long* fl = fill[t].data();

@@ -29,6 +29,10 @@ struct msfm_ctx {
   struct Pending { int stat; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
+  // host work arrays of msfm_ba_create, kept between calls (ba.hip): a C3-sized problem touches ~150 MB of them, and
+  // mapping + unmapping that much fresh memory on every call cost a quarter of the setup time
+  void* ba_scratch = nullptr;
+  void (*ba_scratch_free)(void*) = nullptr;
 };
 
 int msfm_set_error(msfm_ctx* ctx, int code, const char* fmt, ...);

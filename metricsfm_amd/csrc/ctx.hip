@@ -131,6 +131,7 @@ MSFM_API void msfm_ctx_destroy(msfm_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   msfm_pool_trim(ctx->device);
+  if (ctx->ba_scratch && ctx->ba_scratch_free) ctx->ba_scratch_free(ctx->ba_scratch);
   for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
