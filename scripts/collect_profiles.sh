@@ -4,7 +4,7 @@
 set -e -o pipefail
 R=$PWD
 O=$R/gpurun_out/prof
-rm -rf $O && mkdir -p $O
+rm -rf $O && mkdir -p $O   # (the local copy under gpurun_out/ keeps older run directories: delete it before a new collection)
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 echo "bench done"; tail -c 600 $O/bench.json
