@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict_
 // k_point: thread per eliminated point.  mode 0: full; mode 1: raw squared column norms only.
 // --------------------------------------------------------------------------------------
 struct PointPtrs {
-  int A, npb;
+  int A, npb, NCR;
   const int *pt_first, *o_cpos, *o_mb, *pm_first, *pm_mb;
   const double *lin_r, *lin_Jc, *lin_Jm, *lin_Jp;
   double *diag_p;
@@ -299,9 +299,11 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
           double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cp);
 #pragma unroll
           for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
-          double2* To = reinterpret_cast<double2*>(P.T + 18 * (size_t)cp);  // camera-major: the pair kernel's gathers stay inside one camera's segment
+          // component-major (T[k][position], positions camera-major): records of consecutive points of a camera are
+          // neighbours in every component plane, so these stores and the pair kernel's loads coalesce over the runs of
+          // points that share their cameras instead of touching one 16-byte piece per lane and instruction
 #pragma unroll
-          for (int k = 0; k < 9; k++) To[k] = make_double2(T[2 * k], T[2 * k + 1]);
+          for (int k = 0; k < 18; k++) P.T[(size_t)k * P.NCR + cp] = T[k];
         }
       }
     }
@@ -486,7 +488,7 @@ template <int DA, int DB, bool WITH_U>
 __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
                                                 const int* __restrict__ pa, const int* __restrict__ pb,
                                                 const double* __restrict__ TA, const double* __restrict__ TB,
-                                                const double* __restrict__ UA, double* __restrict__ partial) {
+                                                const double* __restrict__ UA, size_t plane, double* __restrict__ partial) {
   constexpr int NOUT = DA * DB + (WITH_U ? DA : 0);
   // XCD-aware chunk order: workgroups b, b+8, ... share an XCD (and its L2), so hand each XCD a
   // contiguous range of chunks — chunks are sorted by (row camera, col camera), a contiguous range
@@ -502,21 +504,21 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
   for (int e = ch_start[chunk] + lane; e < ch_end[chunk]; e += 64) {
     const int ia = pa[e], ib = pb[e];
     double ta[DA * 3], tb[DB * 3];
-    const double* pa_ = TA + (size_t)ia * (DA * 3);
-    const double* pb_ = TB + (size_t)ib * (DB * 3);
-    if constexpr (DA == 6) {  // 144-byte records are 16-byte aligned: nine 16-byte loads
-      const double2* v = reinterpret_cast<const double2*>(pa_);
+    // 6-row records (camera blocks) live component-major, T[k][position] with `plane` positions per component;
+    // 3-row records (intrinsics entries) are small contiguous records
+    if constexpr (DA == 6) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) { const double2 t = v[k]; ta[2 * k] = t.x; ta[2 * k + 1] = t.y; }
+      for (int k = 0; k < 18; k++) ta[k] = TA[(size_t)k * plane + ia];
     } else {
+      const double* pa_ = TA + (size_t)ia * (DA * 3);
 #pragma unroll
       for (int k = 0; k < DA * 3; k++) ta[k] = pa_[k];
     }
     if constexpr (DB == 6) {
-      const double2* v = reinterpret_cast<const double2*>(pb_);
 #pragma unroll
-      for (int k = 0; k < 9; k++) { const double2 t = v[k]; tb[2 * k] = t.x; tb[2 * k + 1] = t.y; }
+      for (int k = 0; k < 18; k++) tb[k] = TB[(size_t)k * plane + ib];
     } else {
+      const double* pb_ = TB + (size_t)ib * (DB * 3);
 #pragma unroll
       for (int k = 0; k < DB * 3; k++) tb[k] = pb_[k];
     }
@@ -1692,7 +1694,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   {
     KTimer t(ctx, "ba_point");
     PointPtrs Q;
-    Q.A = ba->A; Q.npb = npb; Q.pt_first = ba->pt_first.p; Q.o_cpos = ba->o_cpos.p; Q.o_mb = ba->o_mb.p;
+    Q.A = ba->A; Q.npb = npb; Q.NCR = std::max(1, ba->NCR); Q.pt_first = ba->pt_first.p; Q.o_cpos = ba->o_cpos.p; Q.o_mb = ba->o_mb.p;
     Q.pm_first = ba->pm_first.p; Q.pm_mb = ba->pm_mb.p;
     Q.lin_r = ba->lin_r.p; Q.lin_Jc = ba->lin_Jc.p; Q.lin_Jm = ba->lin_Jm.p; Q.lin_Jp = ba->lin_Jp.p;
     Q.diag_p = ba->diag_p.p; Q.scale_p = ba->scale_p.p; Q.ptL = ba->ptL.p; Q.ptg = ba->ptg.p;
@@ -1730,13 +1732,13 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     KTimer t(ctx, "ba_schur_pairs");
     if (ba->cc.n_chunks)
       hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, s, ba->cc.n_chunks, ba->cc.ch_start.p,
-                         ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, ba->cc.partial.p);
+                         ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
     if (ba->mc.n_chunks)
       hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->mc.n_chunks, 4)), dim3(256), 0, s, ba->mc.n_chunks, ba->mc.ch_start.p,
-                         ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, ba->mc.partial.p);
+                         ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->mc.partial.p);
     if (ba->mm.n_chunks)
       hipLaunchKernelGGL((k_pairs<3, 3, true>), dim3(cdiv(ba->mm.n_chunks, 4)), dim3(256), 0, s, ba->mm.n_chunks, ba->mm.ch_start.p,
-                         ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, ba->mm.partial.p);
+                         ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, (size_t)0, ba->mm.partial.p);
   }
   {
     KTimer t(ctx, "ba_assemble");
