@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU path through the C ABI against the CPU oracle) beyond the fixed cases of tests/:
+many seeds, ragged and degenerate batches.  Exact comparisons for the RANSAC / pose / matching legs, the tolerances of
+the parity gates for bundle adjustment.  usage: stress_parity.py [n_rounds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from metricsfm_amd import _abi as A, capi, scene  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from twoview import make_batch, make_pnp_batch, make_relpose_batch  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+ctx = capi.Context(0)
+rng = np.random.default_rng(2026)
+bad = 0
+t_start = time.time()
+
+
+def same(name, g, o, seed):
+    global bad
+    for k, (a, b) in enumerate(zip(g, o)):
+        if not np.array_equal(a, b, equal_nan=True):
+            bad += 1
+            neq = ~((a == b) | (np.isnan(a) & np.isnan(b))) if a.dtype.kind == "f" else (a != b)
+            print("MISMATCH %s output %d seed %d: %d entries differ, first at %s" % (name, k, seed, int(neq.sum()), np.argwhere(neq)[:1].tolist()))
+            return
+
+
+for r in range(rounds):
+    seed = int(rng.integers(1, 1 << 30))
+    sizes = [int(x) for x in rng.choice([0, 3, 4, 5, 6, 9, 10, 17, 40, 130, 700, 1500], size=rng.integers(1, 7))]
+    of = float(rng.choice([0.0, 0.1, 0.4, 0.7]))
+    noise = float(rng.choice([0.0, 0.5, 3.0]))
+    # absolute pose
+    off, X, x, _, _ = make_pnp_batch(seed, sizes, outlier_frac=of, noise=noise)
+    if r % 5 == 0 and len(X):   # degenerate geometry: all points on one plane / one line
+        X = X.copy()
+        X[:, 2] = 0.0
+        if r % 10 == 0:
+            X[:, 1] = 2 * X[:, 0]
+    f = rng.choice([800.0, 4800.0, 12000.0], size=len(sizes))
+    it = int(rng.choice([1, 17, 64, 200]))
+    same("epnp", ctx.epnp_ransac(off, X, x, f, max_iter=it, seed=seed), O.epnp_ransac(off, X, x, f, max_iter=it, seed=seed), seed)
+    # relative pose
+    off, a, b, _, _ = make_relpose_batch(seed + 1, sizes, outlier_frac=of, noise=noise)
+    if r % 7 == 0 and len(a):
+        b = a + 5.0     # pure image translation: degenerate for the essential matrix
+    tm = int(rng.choice([1, 9, 100]))
+    f2 = f[::-1].copy()
+    same("relpose", ctx.relpose_5pt(off, a, b, f, f2, ransac_times=tm, seed=seed), O.relpose_5pt(off, a, b, f, f2, ransac_times=tm, seed=seed), seed)
+    # fundamental-matrix RANSAC (float32 points)
+    sz = [s for s in sizes if s != 1500] or [40]
+    off, p1, p2, _ = make_batch(seed + 2, sz, outlier_frac=of, noise=max(noise, 0.1))
+    mi = int(rng.choice([50, 500, 2000]))
+    same("fransac", ctx.fundamental_ransac(off, p1, p2, seed=seed, max_iterations=mi), O.fundamental_ransac(off, p1, p2, seed=seed, max_iterations=mi), seed)
+    # matching on integer descriptors
+    n1, n2 = int(rng.integers(2, 700)), int(rng.integers(1, 700))
+    d1 = scene._sift_like(np.random.default_rng(seed), n1).astype(np.float32)
+    d2 = scene._sift_like(np.random.default_rng(seed + 9), n2).astype(np.float32)
+    if r % 4 == 0:
+        h = min(n2, n1) // 2
+        d2[:h] = d1[:h]   # planted duplicates: ties by index
+    same("knn2", ctx.knn2(d1, d2), O.knn2(d1, d2, fast=True), seed)
+    # bundle adjustment on a small random scene
+    if r % 4 == 0:
+        sc = scene.make_ring_scene(int(rng.integers(4, 14)), int(rng.integers(50, 400)), seed=seed)
+        g, o = A.BaArrays.from_scene(sc), A.BaArrays.from_scene(sc)
+        rg = ctx.ba_solve(g, capi.default_options(max_num_iterations=12))
+        ro = O.ba_solve(o, O.default_options(max_num_iterations=12))
+        ok = (rg["num_iterations"] == ro["num_iterations"] and abs(rg["final_cost"] - ro["final_cost"]) <= 1e-9 * abs(ro["final_cost"])
+              and np.abs(g.cam_pose - o.cam_pose).max() <= 1e-5 * np.abs(o.cam_pose).max())
+        if not ok:
+            bad += 1
+            print("MISMATCH ba seed %d: iterations %d / %d, cost %.12e / %.12e" % (seed, rg["num_iterations"], ro["num_iterations"], rg["final_cost"], ro["final_cost"]))
+    if r % 10 == 9:
+        print("round %d done, %.0f s, %d mismatches" % (r + 1, time.time() - t_start, bad), flush=True)
+print("stress parity: %d rounds, %d mismatches" % (rounds, bad))
+sys.exit(1 if bad else 0)
