@@ -20,7 +20,6 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
-#include <thread>
 
 #include "ba_device.h"
 #include "common.h"
@@ -996,27 +995,6 @@ static int partition_cameras(const CamGraph& G, int tail_cols, int force_depth, 
 }
 
 static bool is_mut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
-
-// Host-side helper of msfm_ba_create: the index structures of a 10^6-observation problem are built by a few threads
-// (MSFM_HOST_THREADS, default min(hardware threads, 8)); fn(t, begin, end) gets one contiguous range per thread.
-static int host_threads() {
-  static const int n = [] {
-    const char* e = getenv("MSFM_HOST_THREADS");
-    const int v = e ? atoi(e) : std::min(8, (int)std::thread::hardware_concurrency());
-    return std::max(1, std::min(v, 64));
-  }();
-  return n;
-}
-template <class F>
-static void par_ranges(size_t n, int nt, F&& fn) {
-  nt = (int)std::max<size_t>(1, std::min<size_t>(nt, n / 4096 + 1));
-  if (nt == 1) { fn(0, (size_t)0, n); return; }
-  std::vector<std::thread> th;
-  th.reserve(nt - 1);
-  for (int t = 1; t < nt; t++) th.emplace_back([&fn, t, n, nt] { fn(t, n * t / nt, n * (t + 1) / nt); });
-  fn(0, (size_t)0, n / nt);
-  for (auto& x : th) x.join();
-}
 
 // Build chunk / block lists from pair entries already sorted by block key.
 static int finish_jobs(msfm_ba* ba, PairJobs& J, const std::vector<int>& pa, const std::vector<int>& pb,

@@ -6,7 +6,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -109,6 +112,28 @@ struct DevBuf {
 };
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Host-side helper: the index structures of a 10^6-observation problem (msfm_ba_create) and the per-pair iteration tables
+// of the RANSAC (geo.hip) are built by a few threads (MSFM_HOST_THREADS, default min(hardware threads, 8));
+// fn(t, begin, end) gets one contiguous range per thread.
+static inline int host_threads() {
+  static const int n = [] {
+    const char* e = getenv("MSFM_HOST_THREADS");
+    const int v = e ? atoi(e) : std::min(8, (int)std::thread::hardware_concurrency());
+    return std::max(1, std::min(v, 64));
+  }();
+  return n;
+}
+template <class F>
+static inline void par_ranges(size_t n, int nt, F&& fn, size_t grain = 4096) {   // at least `grain` items per thread
+  nt = (int)std::max<size_t>(1, std::min<size_t>(nt, n / grain + 1));
+  if (nt == 1) { fn(0, (size_t)0, n); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; t++) th.emplace_back([&fn, t, n, nt] { fn(t, n * t / nt, n * (t + 1) / nt); });
+  fn(0, (size_t)0, n / nt);
+  for (auto& x : th) x.join();
+}
 
 // Elimination structure of the reduced system (chol.hip): columns [dom_begin[k], dom_end[k]) are K
 // mutually uncoupled camera domains (64-aligned, identity padding inside), [sep_begin, n) is their

@@ -383,11 +383,13 @@ MSFM_API int msfm_fundamental_ransac_batch(msfm_ctx* ctx, int n_pairs, const int
   const int H = opt->max_iterations;
   // R[g] per pair (N + 1 entries each)
   std::vector<int> tab((size_t)total + n_pairs);
-  for (int p = 0; p < n_pairs; p++) {
-    const int o = offsets[p], N = offsets[p + 1] - o;
-    int* R = tab.data() + o + p;
-    for (int g = 0; g <= N; g++) R[g] = N > 0 ? geo_update_num_iters(opt->confidence, (double)(N - g) / N, 7, H) : H;
-  }
+  par_ranges((size_t)n_pairs, host_threads(), [&](int, size_t p0, size_t p1) {   // (N + 1) log / pow evaluations per pair
+    for (size_t p = p0; p < p1; p++) {
+      const int o = offsets[p], N = offsets[p + 1] - o;
+      int* R = tab.data() + o + p;
+      for (int g = 0; g <= N; g++) R[g] = N > 0 ? geo_update_num_iters(opt->confidence, (double)(N - g) / N, 7, H) : H;
+    }
+  }, 16);
   DevBuf<int> d_off, d_tab, d_counts, d_nin;
   DevBuf<float> d1, d2;
   DevBuf<double> dF;
