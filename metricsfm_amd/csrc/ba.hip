@@ -1359,27 +1359,48 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   // ---- (point, intrinsics block) entries ----
   std::vector<int> pm_first(npb + 1, 0), pm_mb;
   o_pm.assign(A, -1);
-  for (int pb = 0; pb < npb; pb++) {
-    pm_first[pb] = (int)pm_mb.size();
-    int tmp[64];
-    int nt = 0;
-    for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++) {
-      const int mb = o_mb[i];
-      if (mb < 0) continue;
-      bool seen = false;
-      for (int k = 0; k < nt; k++) seen |= tmp[k] == mb;
-      if (!seen) {
-        if (nt == 64) return msfm_set_error(ctx, MSFM_E_INVAL, "point %d touches more than 64 intrinsics blocks", ba->h_pb_pt[pb]);
-        tmp[nt++] = mb;
+  {
+    // the sorted distinct intrinsics blocks of a point's rows: counted, prefix-summed, then written (two parallel passes)
+    auto distinct = [&](int pb, int* tmp) -> int {
+      int nt = 0;
+      for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++) {
+        const int mb = o_mb[i];
+        if (mb < 0) continue;
+        bool seen = false;
+        for (int k = 0; k < nt; k++) seen |= tmp[k] == mb;
+        if (!seen) {
+          if (nt == 64) return -1;
+          tmp[nt++] = mb;
+        }
       }
-    }
-    std::sort(tmp, tmp + nt);
-    for (int k = 0; k < nt; k++) pm_mb.push_back(tmp[k]);
-    for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++)
-      if (o_mb[i] >= 0)
-        for (int k = 0; k < nt; k++) if (tmp[k] == o_mb[i]) o_pm[i] = pm_first[pb] + k;
+      std::sort(tmp, tmp + nt);
+      return nt;
+    };
+    const int nth = host_threads();
+    std::vector<int> too_many(nth, -1);
+    par_ranges((size_t)npb, nth, [&](int t, size_t b0, size_t b1) {
+      int tmp[64];
+      for (size_t pb = b0; pb < b1; pb++) {
+        const int nt = distinct((int)pb, tmp);
+        if (nt < 0) { if (too_many[t] < 0) too_many[t] = (int)pb; pm_first[pb + 1] = 0; }
+        else pm_first[pb + 1] = nt;
+      }
+    });
+    for (int t = 0; t < nth; t++)
+      if (too_many[t] >= 0) return msfm_set_error(ctx, MSFM_E_INVAL, "point %d touches more than 64 intrinsics blocks", ba->h_pb_pt[too_many[t]]);
+    for (int pb = 0; pb < npb; pb++) pm_first[pb + 1] += pm_first[pb];
+    pm_mb.resize(pm_first[npb]);
+    par_ranges((size_t)npb, nth, [&](int, size_t b0, size_t b1) {
+      int tmp[64];
+      for (size_t pb = b0; pb < b1; pb++) {
+        const int nt = distinct((int)pb, tmp);
+        for (int k = 0; k < nt; k++) pm_mb[pm_first[pb] + k] = tmp[k];
+        for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++)
+          if (o_mb[i] >= 0)
+            for (int k = 0; k < nt; k++) if (tmp[k] == o_mb[i]) o_pm[i] = pm_first[pb] + k;
+      }
+    });
   }
-  pm_first[npb] = (int)pm_mb.size();
   const int NPM = ba->NPM = (int)pm_mb.size();
   lap("positions + pm entries");
   // ---- FTF chunks (camera-major rows) ----
@@ -1440,13 +1461,13 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     });
     if (kind == 0) lap("  pairs: counted");
     std::vector<long> first(nkey + 1, 0);
-    std::vector<std::vector<long>> fill(nt);
-    for (int t = 0; t < nt; t++) if (!hist[t].empty()) fill[t].assign(nkey, 0);
+    // write cursors per thread, in place of its histogram (32-bit: the total is checked against 2^31 before they are used)
     {
       long run = 0;
       for (size_t k = 0; k < nkey; k++) {
         first[k] = run;
-        for (int t = 0; t < nt; t++) if (!hist[t].empty()) { fill[t][k] = run; run += hist[t][k]; }
+        for (int t = 0; t < nt; t++)
+          if (!hist[t].empty()) { const int n = hist[t][k]; hist[t][k] = (int)run; run += n; }
       }
       first[nkey] = run;
     }
@@ -1456,9 +1477,9 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
     std::vector<int>&pa = H.pa, &pbv = H.pb;
     pa.resize((size_t)total); pbv.resize((size_t)total);
     par_ranges((size_t)npb, nt, [&](int t, size_t, size_t) {
-      if (fill[t].empty()) return;
-      long* fl = fill[t].data();
-      visit(lo[t], hi[t], [&](int r, int c, int a, int b) { const long q = fl[(size_t)r * ncol + c]++; pa[q] = a; pbv[q] = b; });
+      if (hist[t].empty()) return;
+      int* fl = hist[t].data();
+      visit(lo[t], hi[t], [&](int r, int c, int a, int b) { const int q = fl[(size_t)r * ncol + c]++; pa[q] = a; pbv[q] = b; });
     });
     if (kind == 0) lap("  pairs: filled");
     std::vector<long> key_first;
