@@ -160,9 +160,19 @@ __global__ __launch_bounds__(256) void k_gps(int ncb, const int* __restrict__ cb
 
 // Sum (or max) `n` partials in a fixed order into scal[slot]: one workgroup of 1024 threads, each
 // thread a fixed strided subset (independent loads in flight), then a fixed wave / block tree.
-__global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ scal,
-                                                        int slot, int is_max) {
+// Up to four independent reductions of per-workgroup partials in one launch (block b = job b), each in the fixed order
+// of the single-job form; block 0 can also publish the failure flag.  One launch instead of one per scalar: every tiny
+// dependent launch costs ~4.5 us on the LM iteration's critical path.
+struct ReduceJobs {
+  int count;
+  struct { const double* p; int n; int slot; int is_max; } job[4];
+  const int* fail;
+  int fail_slot;
+};
+__global__ __launch_bounds__(1024) void k_reduce(ReduceJobs J, double* __restrict__ scal) {
   __shared__ double sh[16];
+  const double* __restrict__ partial = J.job[blockIdx.x].p;
+  const int n = J.job[blockIdx.x].n, slot = J.job[blockIdx.x].slot, is_max = J.job[blockIdx.x].is_max;
   double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
   int i = threadIdx.x;
   for (; i + 3072 < n; i += 4096) {
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const double* __restrict_
     double t = sh[0];
     for (int w = 1; w < 16; w++) t = is_max ? fmax(t, sh[w]) : t + sh[w];
     scal[slot] = t;
+    if (blockIdx.x == 0 && J.fail) scal[J.fail_slot] = (double)*J.fail;
   }
 }
 
@@ -538,11 +549,11 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
 // Assembly of the padded dense system M (row-major npad x npad, lower triangle; row n = rhs).
 // --------------------------------------------------------------------------------------
 // camera-camera blocks: 64 threads (36 used) per block.
-__global__ __launch_bounds__(64) void k_asm_cc(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
-                                                const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
-                                                const double* __restrict__ camftf, const double* __restrict__ diag_c,
-                                                double radius, const int* __restrict__ cb_off, double* __restrict__ M, int ld, int lead) {
-  const int b = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void asm_cc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                       const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                       const double* __restrict__ camftf, const double* __restrict__ diag_c,
+                                       double radius, const int* __restrict__ cb_off, double* __restrict__ M, int ld, int lead) {
+  const int t = threadIdx.x;
   if (t >= 36) return;
   const int rb = blk_row[b], cbk = blk_col[b];
   double s = 0.0;
@@ -557,11 +568,11 @@ __global__ __launch_bounds__(64) void k_asm_cc(const int* __restrict__ blk_row, 
 }
 
 // intrinsics-camera blocks (rows 6*ncb + 3*mb.., cols 6*cb..): 18 used threads.
-__global__ __launch_bounds__(64) void k_asm_mc(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
-                                                const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
-                                                const double* __restrict__ camftf, const int* __restrict__ cb_mb,
-                                                const int* __restrict__ cb_off, int mo, double* __restrict__ M, int ld, int lead) {
-  const int b = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ void asm_mc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                       const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                       const double* __restrict__ camftf, const int* __restrict__ cb_mb,
+                                       const int* __restrict__ cb_off, int mo, double* __restrict__ M, int ld, int lead) {
+  const int t = threadIdx.x;
   if (t >= 18) return;
   const int mb = blk_row[b], cb = blk_col[b];
   double s = 0.0;
@@ -574,11 +585,11 @@ __global__ __launch_bounds__(64) void k_asm_mc(const int* __restrict__ blk_row, 
 
 // intrinsics-intrinsics blocks: one wave per block, lanes strided over chunks.
 // partial layout per chunk: 9 (Tm Tm'^T) + 3 (sum Tm.u, self pairs only).
-__global__ __launch_bounds__(64) void k_asm_mm(const int* __restrict__ blk_row, const int* __restrict__ blk_col,
-                                                const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
-                                                const double* __restrict__ modelsum, const double* __restrict__ diag_m, double radius,
-                                                int mo, int n, double* __restrict__ M, int ld, int lead) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void asm_mm(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                       const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                       const double* __restrict__ modelsum, const double* __restrict__ diag_m, double radius,
+                                       int mo, int n, double* __restrict__ M, int ld, int lead) {
+  const int lane = threadIdx.x;
   const int rb = blk_row[b], cbk = blk_col[b];
   double acc[12];
 #pragma unroll
@@ -609,13 +620,33 @@ __global__ __launch_bounds__(64) void k_asm_mm(const int* __restrict__ blk_row, 
 
 // rhs of the camera columns + intrinsics blocks that have no (point, intrinsics) entries.
 // camftf is already global (summed over ranks), so only the lead rank contributes it.
-__global__ void k_asm_rhs_cam(int ncb, const double* __restrict__ camftf, const int* __restrict__ cb_off, double* __restrict__ M, int ld,
-                              int n, int lead) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void asm_rhs_cam(int i, int ncb, const double* __restrict__ camftf, const int* __restrict__ cb_off,
+                                            double* __restrict__ M, int ld, int n, int lead) {
   if (i >= 6 * ncb) return;
   const int cb = i / 6, a = i % 6;
   const double* f = camftf + (size_t)cb * PSTRIDE;
   M[(size_t)n * ld + cb_off[cb] + a] = lead ? f[F_JCR + a] - f[F_TU + a] : 0.0;
+}
+
+// The four assembly passes in one launch of 64-thread workgroups: [0, n_cc) camera-camera blocks, then intrinsics-camera
+// blocks, intrinsics-intrinsics blocks, and the camera part of the rhs row (64 entries per workgroup).
+struct AsmArgs {
+  int n_cc, n_mc, n_mm, n_rhs;
+  const int *cc_row, *cc_col, *cc_first, *mc_row, *mc_col, *mc_first, *mm_row, *mm_col, *mm_first, *cb_mb, *cb_off;
+  const double *cc_partial, *mc_partial, *mm_partial, *camftf, *diag_c, *modelsum, *diag_m;
+  double radius;
+  int ncb, mo, n, ld, lead;
+  double* M;
+};
+__global__ __launch_bounds__(64) void k_asm_all(AsmArgs a) {
+  int b = blockIdx.x;
+  if (b < a.n_cc) { asm_cc(b, a.cc_row, a.cc_col, a.cc_first, a.cc_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead); return; }
+  b -= a.n_cc;
+  if (b < a.n_mc) { asm_mc(b, a.mc_row, a.mc_col, a.mc_first, a.mc_partial, a.camftf, a.cb_mb, a.cb_off, a.mo, a.M, a.ld, a.lead); return; }
+  b -= a.n_mc;
+  if (b < a.n_mm) { asm_mm(b, a.mm_row, a.mm_col, a.mm_first, a.mm_partial, a.modelsum, a.diag_m, a.radius, a.mo, a.n, a.M, a.ld, a.lead); return; }
+  b -= a.n_mm;
+  asm_rhs_cam(b * 64 + (int)threadIdx.x, a.ncb, a.camftf, a.cb_off, a.M, a.ld, a.n, a.lead);
 }
 
 // identity on the padding columns that align the camera domains to 64 (their solution component is 0)
@@ -625,13 +656,28 @@ __global__ void k_pad_diag(int npadcol, const int* __restrict__ padcol, double* 
 }
 
 // solver order (domains, padding, separator, intrinsics) -> block order of the BA kernels
-__global__ void k_gather_z(int ncb, int nmb, const int* __restrict__ cb_off, int mo, const double* __restrict__ zsys, double* __restrict__ z) {
+// the solution in block order (the system is solved in elimination order), with the finiteness check on the way
+__global__ void k_gather_z(int ncb, int nmb, const int* __restrict__ cb_off, int mo, const double* __restrict__ zsys, double* __restrict__ z,
+                           int* __restrict__ fail) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 6 * ncb) z[i] = zsys[cb_off[i / 6] + i % 6];
-  else if (i < 6 * ncb + 3 * nmb) z[i] = zsys[mo + (i - 6 * ncb)];
+  double v;
+  if (i < 6 * ncb) v = zsys[cb_off[i / 6] + i % 6];
+  else if (i < 6 * ncb + 3 * nmb) v = zsys[mo + (i - 6 * ncb)];
+  else return;
+  z[i] = v;
+  if (!isfinite(v)) atomicOr(fail, 4);
+}
+// candidate buffers start as copies of x so that inactive blocks carry over: the three copies in one launch
+__global__ __launch_bounds__(256) void k_copy3(size_t n0, const double* __restrict__ a0, double* __restrict__ b0, size_t n1,
+                                               const double* __restrict__ a1, double* __restrict__ b1, size_t n2,
+                                               const double* __restrict__ a2, double* __restrict__ b2) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n0) b0[i] = a0[i];
+  if (i < n1) b1[i] = a1[i];
+  if (i < n2) b2[i] = a2[i];
 }
 
-__global__ void k_fail_to_scal(const int* __restrict__ fail, double* __restrict__ scal, int slot) { scal[slot] = (double)*fail; }
+
 __global__ void k_scale_scal(double* __restrict__ scal, int slot, double f) { scal[slot] *= f; }
 
 // --------------------------------------------------------------------------------------
@@ -774,11 +820,6 @@ __global__ __launch_bounds__(256) void k_mcc_rest(int A, int AE, int ncb, const 
   }
   const double s = block_sum256(mcc, sh);
   if (threadIdx.x == 0) mcc_partial[blockIdx.x] = s;
-}
-
-__global__ void k_check_finite(int n, const double* __restrict__ z, int* fail) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && !isfinite(z[i])) atomicOr(fail, 4);
 }
 
 __global__ void k_zero_int(int* p) { *p = 0; }
@@ -1663,7 +1704,7 @@ static int allreduce(msfm_ba* ba, double* buf, size_t count, int op) {
 
 // cost (and, with jac, the stored linearisation) at x or at the candidate -> scal[slot]
 // (local partial; summed over ranks by the caller together with the other scalars)
-static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int slot) {
+static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int slot, bool with_fail = false) {
   msfm_ctx* ctx = ba->ctx;
   hipStream_t s = ctx->stream;
   const bool lead = ctx->rank == 0;
@@ -1679,7 +1720,12 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int
       if (jac) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
       else hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, nb + (lead ? ng : 0), ba->swrite, slot, 0);
+    ReduceJobs rj;
+    rj.count = 1;
+    rj.job[0] = {ba->partial.p, nb + (lead ? ng : 0), slot, 0};
+    rj.fail = with_fail ? ba->fail.p : nullptr;   // after the solve: the factorisation's / finiteness failure bits are final here
+    rj.fail_slot = S_FAIL;
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, rj, ba->swrite);
   }
   return MSFM_OK;
 }
@@ -1724,9 +1770,14 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
                          ba->diag_m.p, ba->scale_m.p, reuse_diag ? 1 : 0, mode, opt->min_lm_diagonal, opt->max_lm_diagonal, gmax_m);
   }
   if (mode == 1) return MSFM_OK;
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, ba->swrite,
-                     S_GMAX, 1);
-  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->swrite, S_FAIL);
+  {
+    ReduceJobs rj;
+    rj.count = 1;
+    rj.job[0] = {ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, S_GMAX, 1};
+    rj.fail = ba->fail.p;
+    rj.fail_slot = S_FAIL;
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, rj, ba->swrite);
+  }
   {
     KTimer t(ctx, "ba_schur_pairs");
     if (ba->cc.n_chunks)
@@ -1742,16 +1793,15 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   {
     KTimer t(ctx, "ba_assemble");
     HIP_TRY(ctx, hipMemsetAsync(ba->M.p, 0, sizeof(double) * (size_t)ba->npad * ba->npad, s));
-    if (ba->cc.n_blocks)
-      hipLaunchKernelGGL(k_asm_cc, dim3(ba->cc.n_blocks), dim3(64), 0, s, ba->cc.blk_row.p, ba->cc.blk_col.p, ba->cc.blk_chunk_first.p,
-                         ba->cc.partial.p, ba->camftf.p, ba->diag_c.p, radius, ba->cb_off.p, ba->M.p, ba->npad, lead);
-    if (ba->mc.n_blocks)
-      hipLaunchKernelGGL(k_asm_mc, dim3(ba->mc.n_blocks), dim3(64), 0, s, ba->mc.blk_row.p, ba->mc.blk_col.p, ba->mc.blk_chunk_first.p,
-                         ba->mc.partial.p, ba->camftf.p, ba->cb_mb.p, ba->cb_off.p, ba->mo, ba->M.p, ba->npad, lead);
-    if (ba->mm.n_blocks)
-      hipLaunchKernelGGL(k_asm_mm, dim3(ba->mm.n_blocks), dim3(64), 0, s, ba->mm.blk_row.p, ba->mm.blk_col.p, ba->mm.blk_chunk_first.p,
-                         ba->mm.partial.p, ba->modelsum.p, ba->diag_m.p, radius, ba->mo, ba->nsys, ba->M.p, ba->npad, lead);
-    if (ncb) hipLaunchKernelGGL(k_asm_rhs_cam, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, ncb, ba->camftf.p, ba->cb_off.p, ba->M.p, ba->npad, ba->nsys, lead);
+    AsmArgs aa;
+    aa.n_cc = ba->cc.n_blocks; aa.n_mc = ba->mc.n_blocks; aa.n_mm = ba->mm.n_blocks; aa.n_rhs = cdiv(6 * ncb, 64);
+    aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
+    aa.mc_row = ba->mc.blk_row.p; aa.mc_col = ba->mc.blk_col.p; aa.mc_first = ba->mc.blk_chunk_first.p; aa.mc_partial = ba->mc.partial.p;
+    aa.mm_row = ba->mm.blk_row.p; aa.mm_col = ba->mm.blk_col.p; aa.mm_first = ba->mm.blk_chunk_first.p; aa.mm_partial = ba->mm.partial.p;
+    aa.cb_mb = ba->cb_mb.p; aa.cb_off = ba->cb_off.p; aa.camftf = ba->camftf.p; aa.diag_c = ba->diag_c.p; aa.modelsum = ba->modelsum.p;
+    aa.diag_m = ba->diag_m.p; aa.radius = radius; aa.ncb = ncb; aa.mo = ba->mo; aa.n = ba->nsys; aa.ld = ba->npad; aa.lead = lead; aa.M = ba->M.p;
+    const int nasm = aa.n_cc + aa.n_mc + aa.n_mm + aa.n_rhs;
+    if (nasm) hipLaunchKernelGGL(k_asm_all, dim3(nasm), dim3(64), 0, s, aa);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "assemble launch: %s", hipGetErrorString(e));
@@ -1818,16 +1868,17 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
   if (ba->nred > 0) {
     MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, ba->zsys.p, ba->fail.p,
                                     ba->plan.K > 1 ? &ba->plan : nullptr));
-    hipLaunchKernelGGL(k_gather_z, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ncb, nmb, ba->cb_off.p, ba->mo, ba->zsys.p, ba->z.p);
-    hipLaunchKernelGGL(k_check_finite, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ba->nred, ba->z.p, ba->fail.p);
+    hipLaunchKernelGGL(k_gather_z, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ncb, nmb, ba->cb_off.p, ba->mo, ba->zsys.p, ba->z.p, ba->fail.p);
   }
   {
     KTimer t(ctx, "ba_backsub");
     const int nbc = cdiv(std::max(1, 6 * ncb), 256), nbm = cdiv(std::max(1, 3 * nmb), 256), nbp = ba->nblk_pt;
     // candidate buffers start as copies of x so inactive blocks carry over
-    HIP_TRY(ctx, hipMemcpyAsync(ba->cam_c.p, ba->cam.p, sizeof(double) * 6 * (size_t)ba->Nc, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ba->model_c.p, ba->model.p, sizeof(double) * 3 * (size_t)ba->Nm, hipMemcpyDeviceToDevice, s));
-    if (ba->Np) HIP_TRY(ctx, hipMemcpyAsync(ba->pt_c.p, ba->pt.p, sizeof(double) * 3 * (size_t)ba->Np, hipMemcpyDeviceToDevice, s));
+    {
+      const size_t n0 = 6 * (size_t)ba->Nc, n1 = 3 * (size_t)ba->Nm, n2 = 3 * (size_t)ba->Np;
+      hipLaunchKernelGGL(k_copy3, dim3(cdiv((long)std::max(n0, std::max(n1, n2)), 256)), dim3(256), 0, s, n0, ba->cam.p, ba->cam_c.p, n1,
+                         ba->model.p, ba->model_c.p, n2, ba->pt.p, ba->pt_c.p);
+    }
     int off = 0;
     const double wrep = lead ? 1.0 : 0.0;
     // partial2 = |dx|^2 partials, partial3 = |x|^2 partials, partial = model cost partials
@@ -1849,12 +1900,16 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
                          ba->lin_Jc.p, ba->lin_Jm.p, ba->z.p, ngps ? 1 : 0, ba->g_r.p, ba->g_J.p, ba->partial.p + moff);
       moff += cdiv(nrest, 256);
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial.p, moff, ba->swrite, S_MCC, 0);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial2.p, off, ba->swrite, S_DX2, 0);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, ba->partial3.p, off, ba->swrite, S_X2, 0);
+    ReduceJobs rj;
+    rj.count = 3;
+    rj.job[0] = {ba->partial.p, moff, S_MCC, 0};
+    rj.job[1] = {ba->partial2.p, off, S_DX2, 0};
+    rj.job[2] = {ba->partial3.p, off, S_X2, 0};
+    rj.fail = nullptr;
+    rj.fail_slot = S_FAIL;
+    hipLaunchKernelGGL(k_reduce, dim3(3), dim3(1024), 0, s, rj, ba->swrite);
   }
-  MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/false, opt->huber_delta, S_COST));
-  hipLaunchKernelGGL(k_fail_to_scal, dim3(1), dim3(1), 0, s, ba->fail.p, ba->swrite, S_FAIL);
+  MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/false, opt->huber_delta, S_COST, /*with_fail=*/true));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "solve launch: %s", hipGetErrorString(e));
   return MSFM_OK;
