@@ -422,7 +422,10 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
 // are folded in by the lead rank only (the buffer is summed over ranks afterwards).
 __global__ __launch_bounds__(128) void k_camftf(int ncb, const int* __restrict__ cam_chunk_first,
                                                  const double* __restrict__ partial, double* __restrict__ camftf,
-                                                 const double* __restrict__ g_r, const double* __restrict__ g_J, int add_gps) {
+                                                 const double* __restrict__ g_r, const double* __restrict__ g_J, int add_gps, int post,
+                                                 double* __restrict__ diag_c, const double* __restrict__ scale_c, int reuse_diag, int mode,
+                                                 double dmin, double dmax, double* __restrict__ gmax_c) {
+  __shared__ double sums[PSTRIDE];
   const int cb = blockIdx.x, t = threadIdx.x;
   if (t < PSTRIDE) {
     double s = 0.0;
@@ -437,6 +440,16 @@ __global__ __launch_bounds__(128) void k_camftf(int ncb, const int* __restrict__
       }
     }
     camftf[(size_t)cb * PSTRIDE + t] = s;
+    sums[t] = s;
+  }
+  if (!post) return;   // with several ranks the per-camera sums are all-reduced first, k_cam_post follows the exchange
+  __syncthreads();
+  if (t < 6) {
+    const int i = 6 * cb + t;
+    const double d = sums[F_JCJC + t * 6 + t];
+    if (mode == 1) diag_c[i] = d;
+    else if (!reuse_diag) diag_c[i] = fmin(fmax(d, dmin), dmax);
+    gmax_c[i] = fabs(sums[F_JCR + t] / scale_c[i]);
   }
 }
 
@@ -631,7 +644,8 @@ __device__ __forceinline__ void asm_rhs_cam(int i, int ncb, const double* __rest
 // The four assembly passes in one launch of 64-thread workgroups: [0, n_cc) camera-camera blocks, then intrinsics-camera
 // blocks, intrinsics-intrinsics blocks, and the camera part of the rhs row (64 entries per workgroup).
 struct AsmArgs {
-  int n_cc, n_mc, n_mm, n_rhs;
+  int n_cc, n_mc, n_mm, n_rhs, n_padcol;   // n_padcol > 0 only on a single rank (with several, the padding follows the exchange)
+  const int* padcol;
   const int *cc_row, *cc_col, *cc_first, *mc_row, *mc_col, *mc_first, *mm_row, *mm_col, *mm_first, *cb_mb, *cb_off;
   const double *cc_partial, *mc_partial, *mm_partial, *camftf, *diag_c, *modelsum, *diag_m;
   double radius;
@@ -646,7 +660,10 @@ __global__ __launch_bounds__(64) void k_asm_all(AsmArgs a) {
   b -= a.n_mc;
   if (b < a.n_mm) { asm_mm(b, a.mm_row, a.mm_col, a.mm_first, a.mm_partial, a.modelsum, a.diag_m, a.radius, a.mo, a.n, a.M, a.ld, a.lead); return; }
   b -= a.n_mm;
-  asm_rhs_cam(b * 64 + (int)threadIdx.x, a.ncb, a.camftf, a.cb_off, a.M, a.ld, a.n, a.lead);
+  if (b < a.n_rhs) { asm_rhs_cam(b * 64 + (int)threadIdx.x, a.ncb, a.camftf, a.cb_off, a.M, a.ld, a.n, a.lead); return; }
+  b -= a.n_rhs;
+  const int i = b * 64 + (int)threadIdx.x;   // identity on the padding columns (k_pad_diag)
+  if (i < a.n_padcol) a.M[(size_t)a.padcol[i] * a.ld + a.padcol[i]] = 1.0;
 }
 
 // identity on the padding columns that align the camera domains to 64 (their solution component is 0)
@@ -1757,12 +1774,13 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
                          ba->camrow.p, ba->Tu.p, ba->cpos_pb.p, ba->f_partial.p);
     if (ncb)
       hipLaunchKernelGGL(k_camftf, dim3(ncb), dim3(128), 0, s, ncb, ba->cam_chunk_first.p, ba->f_partial.p, ba->camftf.p,
-                         ba->g_r.p, ba->g_J.p, (ba->has_gps && lead) ? 1 : 0);
+                         ba->g_r.p, ba->g_J.p, (ba->has_gps && lead) ? 1 : 0, ctx->world <= 1 ? 1 : 0, ba->diag_c.p, ba->scale_c.p,
+                         reuse_diag ? 1 : 0, mode, opt->min_lm_diagonal, opt->max_lm_diagonal, gmax_c);
   }
   if (ncb) MSFM_TRY(allreduce(ba, ba->camftf.p, (size_t)ncb * PSTRIDE, MSFM_REDUCE_SUM));  // per-camera sums over all shards
   {
     KTimer t(ctx, "ba_ftf");
-    if (ncb)
+    if (ncb && ctx->world > 1)
       hipLaunchKernelGGL(k_cam_post, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, ncb, ba->camftf.p, ba->diag_c.p, ba->scale_c.p,
                          reuse_diag ? 1 : 0, mode, opt->min_lm_diagonal, opt->max_lm_diagonal, gmax_c);
     if (nmb)
@@ -1800,7 +1818,9 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     aa.mm_row = ba->mm.blk_row.p; aa.mm_col = ba->mm.blk_col.p; aa.mm_first = ba->mm.blk_chunk_first.p; aa.mm_partial = ba->mm.partial.p;
     aa.cb_mb = ba->cb_mb.p; aa.cb_off = ba->cb_off.p; aa.camftf = ba->camftf.p; aa.diag_c = ba->diag_c.p; aa.modelsum = ba->modelsum.p;
     aa.diag_m = ba->diag_m.p; aa.radius = radius; aa.ncb = ncb; aa.mo = ba->mo; aa.n = ba->nsys; aa.ld = ba->npad; aa.lead = lead; aa.M = ba->M.p;
-    const int nasm = aa.n_cc + aa.n_mc + aa.n_mm + aa.n_rhs;
+    aa.n_padcol = ctx->world <= 1 ? ba->n_padcol : 0;
+    aa.padcol = ba->padcol.p;
+    const int nasm = aa.n_cc + aa.n_mc + aa.n_mm + aa.n_rhs + cdiv(aa.n_padcol, 64);
     if (nasm) hipLaunchKernelGGL(k_asm_all, dim3(nasm), dim3(64), 0, s, aa);
   }
   hipError_t e = hipGetLastError();
@@ -1823,7 +1843,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     }
   }
   // identity on the padding columns (after the exchange: they are not part of it)
-  if (ba->n_padcol) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(ba->n_padcol, 256)), dim3(256), 0, s, ba->n_padcol, ba->padcol.p, ba->M.p, ba->npad);
+  if (ba->n_padcol && ctx->world > 1) hipLaunchKernelGGL(k_pad_diag, dim3(cdiv(ba->n_padcol, 256)), dim3(256), 0, s, ba->n_padcol, ba->padcol.p, ba->M.p, ba->npad);
   return MSFM_OK;
 }
 

@@ -672,11 +672,19 @@ __global__ __launch_bounds__(256) void k_merge_corners(double* __restrict__ M, i
 // factorisation, off the critical path): from the 16x16 inverses by two doubling steps
 //   inv([A 0; B C]) = [A^-1 0; -C^-1 B A^-1  C^-1].   Linv[blk] row-major 64x64.
 // ---------------------------------------------------------------------------------------
+// Workgroups past the last diagonal block copy the eliminated rhs row (row n of M) into w for the back substitution
+// (one launch fewer on the dependent chain).
 __global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ Ldiag, int n, const double* __restrict__ Dinv,
-                                                       double* __restrict__ Linv) {
+                                                       double* __restrict__ Linv, int nblk, const double* __restrict__ M, int ld,
+                                                       double* __restrict__ w, int npad) {
   __shared__ double L[NB][NB + 1];
   __shared__ double v[NB][NB + 1];
   __shared__ double t[NB][NB + 1];
+  if ((int)blockIdx.x >= nblk) {
+    const int i = ((int)blockIdx.x - nblk) * 256 + (int)threadIdx.x;
+    if (i < npad) w[i] = (i < n) ? M[(size_t)n * ld + i] : 0.0;
+    return;
+  }
   const int blk = blockIdx.x, j0 = blk * NB, tid = threadIdx.x;
   const int ncol = min(NB, n - j0);
   for (int e = tid; e < NB * NB; e += 256) {
@@ -761,11 +769,6 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict
   part[kq][col] = acc;
   __syncthreads();
   if (tid < NB) w[i0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-}
-
-__global__ void k_copy_row(const double* __restrict__ M, int ld, int row, int n, double* __restrict__ w, int npad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npad) w[i] = (i < n) ? M[(size_t)row * ld + i] : 0.0;
 }
 
 // Host driver.  M: npad x npad, row n = rhs.  On return z[0..n) solves S z = rhs.
@@ -859,8 +862,7 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   }
   {
     KTimer t(ctx, "chol_backsolve");
-    hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB)), dim3(256), 0, s, Ldiag, n, Dinv, Linv);
-    hipLaunchKernelGGL(k_copy_row, dim3(cdiv(npad, 256)), dim3(256), 0, s, M, npad, n, n, w, npad);
+    hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB) + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, cdiv(n, NB), M, npad, w, npad);
     const int first_dense = (plan && plan->K > 1) ? plan->sep_begin / NB : 0;
     for (int jb = cdiv(n, NB) - 1; jb >= first_dense; jb--) {  // separator (or everything): couples to every block before it
       BackJobs bj;
