@@ -771,6 +771,87 @@ __global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict
   if (tid < NB) w[i0 + tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
 }
 
+// Two adjacent blocks (jb-1, jb) of the backward solve in one launch: z2 = L22^-T w2, w1' = w1 - L21^T z2,
+// z1 = L11^-T w1', then w_i -= L_{jb,i}^T z2 and w_i -= L_{jb-1,i}^T z1 for the job's earlier blocks i - the operations
+// of two consecutive k_backsolve_step launches in the same order and with the same partial-sum trees (bit-identical
+// result), every workgroup recomputing z2, w1' and z1 for itself.  Halves the dependent launches of the back substitution.
+__global__ __launch_bounds__(256) void k_backsolve_pair(const double* __restrict__ M, int ld, int n, BackJobs jobs,
+                                                         const double* __restrict__ Linv, double* __restrict__ w,
+                                                         double* __restrict__ z) {
+  __shared__ double part[4][NB];
+  __shared__ double z2[NB], z1[NB], w1p[NB];
+  int ji = 0;
+  for (int k = 1; k < jobs.count; k++)
+    if ((int)blockIdx.x >= jobs.job[k].wg0) ji = k;
+  const int jb = jobs.job[ji].jb, bl = blockIdx.x - jobs.job[ji].wg0, ni = jobs.job[ji].ni;
+  const int tid = threadIdx.x, j2 = jb * NB, j1 = (jb - 1) * NB;
+  const int col = tid & 63, kq = tid >> 6;
+  const double* Li2 = Linv + (size_t)jb * NB * NB;
+  const double* Li1 = Linv + (size_t)(jb - 1) * NB * NB;
+  const int i0 = (jobs.job[ji].ib + bl) * NB;
+  double lv2[16], lv1[16], m21[16], mv2[16], mv1[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { lv2[k] = Li2[(16 * kq + k) * NB + col]; lv1[k] = Li1[(16 * kq + k) * NB + col]; }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int r2 = j2 + 16 * kq + k, r1 = j1 + 16 * kq + k;
+    m21[k] = r2 < n ? M[(size_t)r2 * ld + j1 + col] : 0.0;
+    mv2[k] = (ni > 0 && r2 < n) ? M[(size_t)r2 * ld + i0 + col] : 0.0;
+    mv1[k] = (ni > 0 && r1 < n) ? M[(size_t)r1 * ld + i0 + col] : 0.0;
+  }
+  // z2 = L22^-T w2
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) s += lv2[k] * w[j2 + 16 * kq + k];
+  part[kq][col] = s;
+  __syncthreads();
+  if (tid < NB) {
+    const double zz = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    z2[tid] = zz;
+    if (bl == 0) z[j2 + tid] = zz;
+  }
+  __syncthreads();
+  // w1' = w1 - L21^T z2
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc += m21[k] * z2[16 * kq + k];
+  __syncthreads();
+  part[kq][col] = acc;
+  __syncthreads();
+  if (tid < NB) w1p[tid] = w[j1 + tid] - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+  __syncthreads();
+  // z1 = L11^-T w1'
+  s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) s += lv1[k] * w1p[16 * kq + k];
+  __syncthreads();
+  part[kq][col] = s;
+  __syncthreads();
+  if (tid < NB) {
+    const double zz = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    z1[tid] = zz;
+    if (bl == 0) z[j1 + tid] = zz;
+  }
+  __syncthreads();
+  if (ni == 0) return;
+  // w_i -= L_{jb,i}^T z2, then w_i -= L_{jb-1,i}^T z1
+  acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc += mv2[k] * z2[16 * kq + k];
+  __syncthreads();
+  part[kq][col] = acc;
+  __syncthreads();
+  double wi = 0.0;
+  if (tid < NB) wi = w[i0 + tid] - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+  acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) acc += mv1[k] * z1[16 * kq + k];
+  __syncthreads();
+  part[kq][col] = acc;
+  __syncthreads();
+  if (tid < NB) w[i0 + tid] = wi - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+}
+
 // Host driver.  M: npad x npad, row n = rhs.  On return z[0..n) solves S z = rhs.
 // `fail` (device int) is OR-ed with 1 when S is not positive definite.
 // work: npad*16 doubles (16x16 inverses) + npad*64 (full block inverses) + npad*64 (diagonal blocks of L).
@@ -864,27 +945,40 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     KTimer t(ctx, "chol_backsolve");
     hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB) + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, cdiv(n, NB), M, npad, w, npad);
     const int first_dense = (plan && plan->K > 1) ? plan->sep_begin / NB : 0;
-    for (int jb = cdiv(n, NB) - 1; jb >= first_dense; jb--) {  // separator (or everything): couples to every block before it
+    for (int jb = cdiv(n, NB) - 1; jb >= first_dense;) {  // separator (or everything): couples to every block before it
       BackJobs bj;
       bj.count = 1;
-      bj.job[0] = BackJob{jb, 0, jb, 0};
-      hipLaunchKernelGGL(k_backsolve_step, dim3(jb > 0 ? jb : 1), dim3(256), 0, s, M, npad, n, bj, Linv, w, z);
+      if (jb - 1 >= first_dense) {   // blocks jb and jb-1 together
+        bj.job[0] = BackJob{jb, 0, jb - 1, 0};
+        hipLaunchKernelGGL(k_backsolve_pair, dim3(jb - 1 > 0 ? jb - 1 : 1), dim3(256), 0, s, M, npad, n, bj, Linv, w, z);
+        jb -= 2;
+      } else {
+        bj.job[0] = BackJob{jb, 0, jb, 0};
+        hipLaunchKernelGGL(k_backsolve_step, dim3(jb > 0 ? jb : 1), dim3(256), 0, s, M, npad, n, bj, Linv, w, z);
+        jb -= 1;
+      }
     }
     if (first_dense) {
       int maxp = 0;
       for (int k = 0; k < plan->K; k++) maxp = std::max(maxp, (plan->dom_end[k] - plan->dom_begin[k]) / NB);
-      for (int l = 0; l < maxp; l++) {  // block P_k - 1 - l of every domain in one launch
-        BackJobs bj;
-        bj.count = 0;
-        int wg = 0;
+      for (int l = 0; 2 * l < maxp; l++) {  // blocks P_k - 1 - 2l and P_k - 2 - 2l of every domain in one launch (a domain's last odd block alone)
+        BackJobs pj, sj;
+        pj.count = sj.count = 0;
+        int pwg = 0, swg = 0;
         for (int k = 0; k < plan->K; k++) {
           const int ib = plan->dom_begin[k] / NB, P = (plan->dom_end[k] - plan->dom_begin[k]) / NB;
-          if (l >= P) continue;
-          const int jb = ib + P - 1 - l;
-          bj.job[bj.count++] = BackJob{jb, ib, jb - ib, wg};
-          wg += std::max(1, jb - ib);
+          if (2 * l >= P) continue;
+          const int jb = ib + P - 1 - 2 * l;
+          if (jb - 1 >= ib) {
+            pj.job[pj.count++] = BackJob{jb, ib, jb - 1 - ib, pwg};
+            pwg += std::max(1, jb - 1 - ib);
+          } else {
+            sj.job[sj.count++] = BackJob{jb, ib, jb - ib, swg};
+            swg += std::max(1, jb - ib);
+          }
         }
-        hipLaunchKernelGGL(k_backsolve_step, dim3(wg), dim3(256), 0, s, M, npad, n, bj, Linv, w, z);
+        if (pj.count) hipLaunchKernelGGL(k_backsolve_pair, dim3(pwg), dim3(256), 0, s, M, npad, n, pj, Linv, w, z);
+        if (sj.count) hipLaunchKernelGGL(k_backsolve_step, dim3(swg), dim3(256), 0, s, M, npad, n, sj, Linv, w, z);
       }
     }
   }
