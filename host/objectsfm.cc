@@ -235,8 +235,10 @@ void BundleAdjuster::RunOptimizetion(bool is_initial_run, double weight) {
   }
   for (Point3D* p : pts_) {
     if (p->is_bad_estimated_) continue;                 // optimizer.cc:64
-    if (p->cams_.size() == 2) p->weight = 1.0;          // optimizer.cc:69-78
-    if (p->cams_.size() >= 3) p->weight = weight;
+    if (!keep_point_weights_) {
+      if (p->cams_.size() == 2) p->weight = 1.0;        // optimizer.cc:69-78
+      if (p->cams_.size() >= 3) p->weight = weight;
+    }
     const int pid = (int)used.size();
     used.push_back(p);
     for (int k = 0; k < 3; k++) point.push_back(p->data[k]);
@@ -256,6 +258,18 @@ void BundleAdjuster::RunOptimizetion(bool is_initial_run, double weight) {
   P.obs_cam = obs_cam.data(); P.obs_pt = obs_pt.data(); P.obs_xy = obs_xy.data(); P.pt_weight = pt_weight.data();
   P.cam_mutable = cam_mut.data(); P.model_mutable = model_mut.data(); P.pt_mutable = pt_mut.data();
   P.gps_xyz = nullptr; P.gps_weight = 0;
+  std::vector<double> gps_xyz;
+  if (!cams_gps_.empty()) {
+    if (cams_gps_.size() != cams_.size()) throw std::runtime_error("SetGPS: one position per camera expected");
+    // slam_gps.cc:818-830: `double weight = count1 / cams_.size();` - both int, so the division truncates; count1 is
+    // the number of reprojection residual blocks added (rows whose camera and point are both frozen add none)
+    long count1 = 0;
+    for (size_t o = 0; o < obs_cam.size(); o++) count1 += (cam_mut[obs_cam[o]] || pt_mut[obs_pt[o]]) ? 1 : 0;
+    gps_xyz.resize(3 * cams_.size());
+    for (size_t i = 0; i < cams_.size(); i++) for (int k = 0; k < 3; k++) gps_xyz[3 * i + k] = cams_gps_[i][k];
+    P.gps_xyz = gps_xyz.data();
+    P.gps_weight = (double)(count1 / (long)cams_.size());
+  }
   iterations_.assign((size_t)options_.max_num_iterations + 2, msfm_ba_iteration());
   summary_.iterations = iterations_.data();
   summary_.iterations_capacity = (int)iterations_.size();
@@ -301,6 +315,107 @@ void BundleAdjuster::Perturb() {
     for (int k = 0; k < 3; k++) t[k] += nrm(gen) * translation_sigma;
     c->SetRTPose(c->pos_rt_.R, t);
   }
+}
+
+// ---- IncrementalSfM: window selection + the two adjustments ---------------------------------------
+void IncrementalSfM::ImmutableCamsPoints() {
+  for (Camera* c : cams_) {
+    c->SetMutable(false);
+    for (auto& kv : c->pts_) kv.second->SetMutable(false);
+  }
+}
+
+void IncrementalSfM::MutableCamsPoints() {
+  for (Camera* c : cams_) {
+    c->SetMutable(true);
+    for (auto& kv : c->pts_) kv.second->SetMutable(true);
+  }
+}
+
+void IncrementalSfM::UpdateVisibleGraph(int idx_new_cam, std::vector<int> idxs_visible_cam) {
+  cams_[idx_new_cam]->AddVisibleCamera(idx_new_cam);
+  for (int v : idxs_visible_cam) {
+    cams_[idx_new_cam]->AddVisibleCamera(v);
+    cams_[v]->AddVisibleCamera(idx_new_cam);
+  }
+}
+
+std::vector<int> IncrementalSfM::VisibleCameras(int idx_cam) const {
+  // a 2D-3D match through camera j = a point of camera j (not bad) that the new camera observes too
+  std::map<const Camera*, int> count;
+  for (auto& kv : cams_[idx_cam]->pts_) {
+    const Point3D* p = kv.second;
+    if (p->is_bad_estimated_) continue;
+    for (auto& pc : p->cams_) if (pc.second != cams_[idx_cam]) count[pc.second]++;
+  }
+  std::vector<int> vis;
+  for (size_t j = 0; j < cams_.size(); j++) {
+    auto it = count.find(cams_[j]);
+    if (it != count.end() && it->second > options_.th_visible_matches) vis.push_back((int)j);
+  }
+  return vis;
+}
+
+void IncrementalSfM::PartialBundleAdjustment(int idx) {
+  ImmutableCamsPoints();
+  // optimize only the new camera (all cameras of its model) and its visible cameras, with their good points
+  auto free_cam = [&](int idx_cam) {
+    cams_[idx_cam]->SetMutable(true);
+    for (auto& kv : cams_[idx_cam]->pts_) if (!kv.second->is_bad_estimated_) kv.second->SetMutable(true);
+  };
+  for (int idx_cam : cams_[idx]->cam_model_->idx_cams_) free_cam(idx_cam);
+  for (int idx_cam : cams_[idx]->visible_cams_) free_cam(idx_cam);
+  BundleAdjuster bundler(cams_, cam_models_, pts_);
+  bundler.SetOptions(bundle_partial_options_);
+  bundler.SetGPS(cams_gps_);
+  bundler.RunOptimizetion(!found_seed_, 2.0);
+  bundler.UpdateParameters();
+  summary_ = bundler.summary_;
+  iterations_ = bundler.iterations_;
+  summary_.iterations = iterations_.data();
+}
+
+void IncrementalSfM::FullBundleAdjustment() {
+  MutableCamsPoints();
+  BundleAdjuster bundler(cams_, cam_models_, pts_);
+  bundler.SetOptions(bundle_full_options_);
+  bundler.SetGPS(cams_gps_);
+  bundler.RunOptimizetion(!found_seed_, 1.0);
+  bundler.UpdateParameters();
+  summary_ = bundler.summary_;
+  iterations_ = bundler.iterations_;
+  summary_.iterations = iterations_.data();
+}
+
+void IncrementalSfM::RemovePointOutliers() {
+  std::vector<Point3D*> live;
+  for (Point3D* p : pts_) if (!p->is_bad_estimated_) live.push_back(p);
+  ReprojectionBatch(live);   // pts_[i]->Reprojection() for every live point, one launch
+  for (Point3D* p : live) {
+    if (std::sqrt(p->mse_) > options_.th_mse_outliers) p->is_bad_estimated_ = true;
+    p->is_new_added_ = false;
+  }
+}
+
+void SLAMGPS::FullBundleAdjustment() {
+  // slam_gps.cc:690-712 adds ReprojectionErrorPoseCamXYZ for every observation of every non-bad point with the point's
+  // own weight: everything is free, and the weight rule of BundleAdjuster does not apply
+  for (Camera* c : cams_) c->SetMutable(true);
+  for (CameraModel* m : cam_models_) m->is_mutable_ = true;
+  std::vector<double> keep;
+  for (Point3D* p : pts_) { p->SetMutable(true); keep.push_back(p->weight); }
+  BundleAdjuster bundler(cams_, cam_models_, pts_);
+  BundleAdjustOptions o;
+  o.max_num_iterations = 200; o.minimizer_progress_to_stdout = minimizer_progress_to_stdout_; o.num_threads = 8;   // slam_gps.cc:681-683
+  bundler.SetOptions(o);
+  bundler.SetGPS(cams_gps_);
+  bundler.keep_point_weights_ = true;
+  bundler.RunOptimizetion(false, 1.0);
+  for (size_t i = 0; i < pts_.size(); i++) pts_[i]->weight = keep[i];
+  bundler.UpdateParameters();   // slam_gps.cc:844-852
+  summary_ = bundler.summary_;
+  iterations_ = bundler.iterations_;
+  summary_.iterations = iterations_.data();
 }
 
 // ---- matching -----------------------------------------------------------------------------------

@@ -73,6 +73,7 @@ struct CameraModel {  // basic_structs.h:48-124
   bool is_mutable_ = true;
 };
 
+class Point3D;
 class Camera {  // camera.h:34-85
  public:
   void AssociateImage(int id_img) { id_img_ = id_img; }
@@ -82,7 +83,13 @@ class Camera {  // camera.h:34-85
   void UpdateDataFromPose();                      // camera.cc:89-111
   void UpdatePoseFromData();                      // camera.cc:113-137
   void SetMutable(bool is_mutable) { is_mutable_ = is_mutable; }
+  void AddPoints(Point3D* pt, int idx) { pts_.insert(std::make_pair(idx, pt)); }     // camera.cc:152-155
+  void AddVisibleCamera(int id_visible_cam) { visible_cams_.push_back(id_visible_cam); }  // camera.cc:157-160
+  void SetID(int id) { id_ = id; }
+  int id_ = 0;
   int id_img_ = 0;
+  std::map<int, Point3D*> pts_;      // global feature id -> 3-D point (camera.h:81)
+  std::vector<int> visible_cams_;    // camera.h:82
   CameraModel* cam_model_ = nullptr;
   RTPose pos_rt_;
   ACPose pos_ac_;
@@ -123,15 +130,67 @@ class BundleAdjuster {  // optimizer.h / optimizer.cc:31-232
   void UpdateParameters();                                      // optimizer.cc:142-153
   void Normalize();                                             // optimizer.cc:155-195
   void Perturb();                                               // optimizer.cc:197-232 (seeded std::mt19937_64, not std::rand)
+  // The absolute GPS rows SLAMGPS::FullBundleAdjustment adds after the reprojection rows (slam_gps.cc:714-832,
+  // use_absolute_gps): one GPSErrorPoseAbsolute per camera on pose[3:6], Huber(1), weight = count1 / cams_.size()
+  // (integer division, :824) with count1 = reprojection residual blocks added.  Empty = none.
+  void SetGPS(const std::vector<Vec3>& cams_gps) { cams_gps_ = cams_gps; }
   msfm_ba_summary summary_;
   std::vector<msfm_ba_iteration> iterations_;
   unsigned long long perturb_seed_ = 0x4D53464DULL;
+  bool keep_point_weights_ = false;   // SLAMGPS passes pts_[i]->weight as it is (slam_gps.cc:703)
 
  private:
   std::vector<Camera*> cams_;
   std::vector<CameraModel*> cam_models_;
   std::vector<Point3D*> pts_;
+  std::vector<Vec3> cams_gps_;
   msfm_ba_options options_;
+};
+
+// The bundle-adjustment side of the incremental loop (SfM/src/sfm_incremental.h/.cc): which cameras and points a
+// partial adjustment frees, the full adjustment, the outlier sweep.  Localisation, seed search and file handling stay
+// with their own stages (pose initialisers / matching above).
+struct IncrementalSfMOptions {       // basic_structs.h:147-227, the fields this part reads
+  double th_mse_outliers = 3.0;      // test_sfm.cc:46 (UAV), 1.0 for WEB (:57)
+  int th_visible_matches = 5;        // `count_2d3d_ij > 5`, sfm_incremental.cc:503
+  bool use_same_camera = false;      // basic_structs.h:167
+};
+class IncrementalSfM {
+ public:
+  void ImmutableCamsPoints();                                            // sfm_incremental.cc:1865-1878
+  void MutableCamsPoints();                                              // sfm_incremental.cc:1880-1893
+  void UpdateVisibleGraph(int idx_new_cam, std::vector<int> idxs_visible_cam);  // sfm_incremental.cc:1895-1903
+  // the counting loop of FindImageToLocalize (sfm_incremental.cc:455-506) for a camera whose points are attached:
+  // cameras through which it has more than th_visible_matches 2D-3D matches (non-bad points), ascending
+  std::vector<int> VisibleCameras(int idx_cam) const;
+  void PartialBundleAdjustment(int idx);                                 // sfm_incremental.cc:917-1014
+  void FullBundleAdjustment();                                           // sfm_incremental.cc:1016-1026
+  void RemovePointOutliers();                                            // sfm_incremental.cc:1831-1863 (one batched reprojection)
+  std::vector<Camera*> cams_;
+  std::vector<CameraModel*> cam_models_;
+  std::vector<Point3D*> pts_;
+  // BASELINE config 5 ("incremental-window BA with GCP constraints"): when set, both adjustments attach the
+  // absolute GPS rows of SLAMGPS::FullBundleAdjustment (slam_gps.cc:818-830) to the cameras they free
+  std::vector<Vec3> cams_gps_;
+  IncrementalSfMOptions options_;
+  BundleAdjustOptions bundle_full_options_, bundle_partial_options_;
+  bool found_seed_ = true;
+  msfm_ba_summary summary_;                  // of the last adjustment
+  std::vector<msfm_ba_iteration> iterations_;
+};
+
+// SLAMGPS::FullBundleAdjustment (SfM/src/slam_gps.cc:675-863): every non-bad point's observations as
+// ReprojectionErrorPoseCamXYZ rows with the point's weight, the absolute GPS rows, max 200 iterations, 8 threads.
+class SLAMGPS {
+ public:
+  void FullBundleAdjustment();
+  std::vector<Camera*> cams_;
+  std::vector<CameraModel*> cam_models_;
+  std::vector<Point3D*> pts_;
+  std::vector<Vec3> cams_gps_;               // cv::Point3d cams_gps_ (slam_gps.h)
+  bool minimizer_progress_to_stdout_ = true; // slam_gps.cc:682
+  msfm_ba_summary summary_;
+  std::vector<msfm_ba_iteration> iterations_;
 };
 
 // The kNN + ratio-test part of FineMatchingGraph::BuildMatchGraph (fine_matching_graph.cc:87-133),

@@ -328,3 +328,13 @@ def cameras_for_tracks(scene: Scene, pose=None, model=None):
     t = pose[:, 3:].copy()
     c = -np.einsum("nji,nj->ni", R, t)
     return R.reshape(-1, 9).copy(), t, c, model[scene.cam_model_of_cam].copy()
+
+
+def perturb_camera(scene: Scene, idx: int, rot_sigma=0.05, trans_sigma=0.5, seed=None) -> Scene:
+    """A freshly localised camera inside an already adjusted model (the state PartialBundleAdjustment starts from,
+    sfm_incremental.cc:917): camera `idx` gets BundleAdjuster::Perturb-style noise on top of its current pose
+    (rotation with the centre held, then translation), everything else is left alone.  In place."""
+    rng = np.random.Generator(np.random.PCG64([SEED_BASE + 0x300, idx] if seed is None else seed))
+    pose, _ = _perturb(rng, scene.cam_pose[idx:idx + 1], np.zeros((0, 3)), rot_sigma, trans_sigma, 0.0)
+    scene.cam_pose[idx] = pose[0]
+    return scene

@@ -14,10 +14,19 @@ import numpy as np
 from . import _abi as A
 
 
-def point_ranges(obs_pt: np.ndarray, n_points: int, world: int):
-    """Contiguous point ranges [lo, hi) per rank, balanced by sum k_p^2 (the Schur pair count)."""
-    k = np.bincount(obs_pt, minlength=n_points).astype(np.int64)
-    cost = np.cumsum(k * k + 4 * k)
+def point_ranges(obs_pt: np.ndarray, n_points: int, world: int, obs_cam=None, cam_mutable=None, pt_mutable=None):
+    """Contiguous point ranges [lo, hi) per rank, balanced by sum k_p^2 (the Schur pair count).  With window masks
+    (PartialBundleAdjustment, sfm_incremental.cc:917-945) only the work the masks leave counts: a free point costs the
+    square of its free-camera rows plus its rows, a frozen point only its free-camera rows, both frozen nothing."""
+    if cam_mutable is None and pt_mutable is None:
+        k = np.bincount(obs_pt, minlength=n_points).astype(np.int64)
+        cost = np.cumsum(k * k + 4 * k)
+    else:
+        cm = np.ones(len(obs_pt), bool) if cam_mutable is None else np.asarray(cam_mutable)[obs_cam] != 0
+        pm = np.ones(n_points, bool) if pt_mutable is None else np.asarray(pt_mutable) != 0
+        kc = np.bincount(obs_pt[cm], minlength=n_points).astype(np.int64)      # rows with a camera block
+        k = np.bincount(obs_pt, minlength=n_points).astype(np.int64)
+        cost = np.cumsum(np.where(pm, kc * kc + 4 * k, 4 * kc))
     total = cost[-1] if n_points else 0
     cuts = [0]
     for r in range(1, world):
@@ -32,7 +41,7 @@ def shard_ba_arrays(full: A.BaArrays, rank: int, world: int) -> A.BaArrays:
     """The sub-problem of `rank`: its point range and their observations; every camera."""
     if world == 1:
         return full
-    lo, hi = point_ranges(full.obs_pt, len(full.point), world)[rank]
+    lo, hi = point_ranges(full.obs_pt, len(full.point), world, full.obs_cam, full.cam_mutable, full.pt_mutable)[rank]
     sel = (full.obs_pt >= lo) & (full.obs_pt < hi)
     sub = lambda a: None if a is None else a[lo:hi]
     out = A.BaArrays(full.cam_pose, full.cam_model, full.cam_model_of_cam, full.point[lo:hi], full.obs_cam[sel],

@@ -18,9 +18,13 @@ def main():
     if which == "gps":
         sc = scene.make_aerial_scene(20, 2500, seed=21, gps_sigma=0.5, rot_sigma=0.02, trans_sigma=0.3, point_sigma=0.2)
         kw = dict(gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams))
-    elif which == "c3":   # manual check at full size (not part of the suite)
+    elif which == "c3":   # BASELINE config 4's workload: config 3 sharded over ranks
         sc = scene.config_scene(3)
         kw = {}
+    elif which == "c5w":  # config 5's shape at a size the test box generates quickly: windowed BA + GPS rows, sharded
+        from metricsfm_amd import window
+        sc = scene.make_aerial_scene(300, 60000, seed=55, n_models=300, gps_sigma=0.5, rot_sigma=2e-4, trans_sigma=0.01, point_sigma=0.02)
+        scene.perturb_camera(sc, 299)
     elif which == "domains":
         # >= 128 cameras: the union camera graph is bisected identically on every rank (MSFM_CHOL_DOMAINS forced by the test)
         sc = scene.make_aerial_scene(150, 5000, seed=8)
@@ -28,7 +32,8 @@ def main():
     else:
         sc = scene.config_scene(2)
         kw = {}
-    full = A.BaArrays.from_scene(sc, **kw)
+    make = (lambda: window.partial_bundle_adjustment_problem(sc, 299, gps=True)[0]) if which == "c5w" else (lambda: A.BaArrays.from_scene(sc, **kw))
+    full = make()
     mine = shard.shard_ba_arrays(full, rank, world)
     ctx = capi.Context(0)
     hook = shard.TorchAllReduce(dist, 0)
@@ -44,7 +49,7 @@ def main():
         for c in cams[1:]:
             assert (c == cams[0]).all(), "replicated cameras diverged between ranks"
         ctx1 = capi.Context(0)
-        ref = A.BaArrays.from_scene(sc, **kw)
+        ref = make()
         res1 = ctx1.ba_solve(ref, opts)
         np.savez(out, point=np.concatenate(pts), cam=mine.cam_pose, model=mine.cam_model, point1=ref.point, cam1=ref.cam_pose,
                  model1=ref.cam_model, cost=res["iterations"]["cost"], cost1=res1["iterations"]["cost"],

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,which,port", [(2, "c2", 29741), (3, "gps", 29742), (2, "domains", 29743)])
+@pytest.mark.parametrize("world,which,port", [(2, "c2", 29741), (3, "gps", 29742), (2, "domains", 29743), (2, "c3", 29745), (2, "c5w", 29746)])
 def test_sharded_ba_matches_single_rank(tmp_path, world, which, port):
     out = tmp_path / "mr.npz"
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
