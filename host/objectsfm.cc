@@ -437,9 +437,9 @@ std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& 
     check(msfm_match_result_fetch(res, (int)p, code.data(), nullptr, nullptr), "match_fetch");
     for (int m = 0; m < n2; m++) {  // the loop of fine_matching_graph.cc:116-133, decisions already made on the GPU
       if (code[m] < 0) continue;
-      const int id1 = code[m] & ~MSFM_MATCH_GOOD;
+      const int id1 = code[m] & MSFM_MATCH_ID_MASK;
       if (code[m] & MSFM_MATCH_GOOD) out[p].matches_good.push_back(std::make_pair(id1, m));
-      out[p].matches_all.push_back(std::make_pair(id1, m));
+      if (!(code[m] & MSFM_MATCH_NOT_ALL)) out[p].matches_all.push_back(std::make_pair(id1, m));
     }
   }
   msfm_match_result_destroy(res);

@@ -41,6 +41,8 @@ int msfm_version(void);
 /* device < 0: use the current HIP device.  Fails with MSFM_E_DEVICE when no GPU is
  * visible — there is no CPU fallback behind this ABI. */
 int msfm_ctx_create(int device, msfm_ctx** out);
+/* Objects created from a ctx (descriptor sets, match results, resident BA problems) should be destroyed first; if some
+ * are still alive the context is kept until the last of them is destroyed, then released. */
 void msfm_ctx_destroy(msfm_ctx* ctx);
 const char* msfm_last_error(const msfm_ctx* ctx);
 /* The HIP stream (hipStream_t) every kernel of this ctx is launched on. */
@@ -73,8 +75,8 @@ int msfm_ctx_profile_get(msfm_ctx* ctx, msfm_kernel_stat* stats, int cap, int* n
  *     sqdists [n_query][2]  squared L2 distance, ascending
  * Unlike the kd-tree (8 trees, 64 checks — approximate) the result is the exact 2-NN;
  * equal distances are ordered by lower train index.  n_train >= 2 is required (the
- * reference divides dists[0]/dists[1]).  dim must be a multiple of 16 and <= 256
- * (SIFT: 128).
+ * reference divides dists[0]/dists[1]).  dim must be 128 (SIFT; database.cc:412-418 stores 128 columns): the
+ * kernels are specialised for it and every other value is refused with MSFM_E_INVAL.
  */
 int msfm_knn2_f32(msfm_ctx* ctx, const float* train, int n_train, const float* query, int n_query,
                   int dim, int* ids, float* sqdists);
@@ -83,7 +85,10 @@ int msfm_knn2_f32(msfm_ctx* ctx, const float* train, int n_train, const float* q
  * every pair that touches the image (the reference re-reads `<idx2>_feature` from disk
  * per pair, fine_matching_graph.cc:91). */
 typedef struct msfm_descset msfm_descset;
-int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_descset** out);
+int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim /* 128 */, msfm_descset** out);
+/* Replaces the image's descriptors.  Waits for work already enqueued on the ctx stream (a running match may still read
+ * the old buffers).  Match results created before the upload become stale: msfm_match_pairs_rerun /
+ * msfm_match_result_fetch on them return MSFM_E_INVAL; create a new result with msfm_match_pairs. */
 int msfm_descset_upload(msfm_descset* set, int image, const float* desc, int count);
 int msfm_descset_count(const msfm_descset* set, int image);
 void msfm_descset_destroy(msfm_descset* set);
@@ -94,12 +99,17 @@ void msfm_descset_destroy(msfm_descset* set);
  * For pair p and query feature m of image idx2 (in feature order, which is the order of
  * the reference loop fine_matching_graph.cc:116-133):
  *     ratio = sqdist0 / sqdist1
- *     code  = -1                                   if !(ratio < ratio_all)
- *           = id0 | (ratio < ratio_good ? MSFM_MATCH_GOOD : 0)   otherwise
+ *     good  = ratio < ratio_good,  all = ratio < ratio_all       (two independent tests, :118-130)
+ *     code  = -1                                                  if neither
+ *           = id0 | (good ? MSFM_MATCH_GOOD : 0) | (all ? 0 : MSFM_MATCH_NOT_ALL)   otherwise
+ * With the reference's thresholds (0.6 < 0.85) a good match is always in the "all" set and MSFM_MATCH_NOT_ALL never
+ * appears; id0 = code & MSFM_MATCH_ID_MASK.
  * The codes live in device memory inside the result object; fetch copies one pair to
  * the host.  n_all / n_good are the sizes of the reference's matches_all / matches_good.
  */
 #define MSFM_MATCH_GOOD 0x40000000
+#define MSFM_MATCH_NOT_ALL 0x20000000
+#define MSFM_MATCH_ID_MASK 0x1FFFFFFF
 typedef struct msfm_match_result msfm_match_result;
 int msfm_match_pairs(msfm_descset* set, const int* pairs /*[n_pairs][2]*/, int n_pairs,
                      float ratio_good, float ratio_all, int keep_knn, msfm_match_result** out);

@@ -11,6 +11,8 @@ c_u8_p = C.POINTER(C.c_uint8)
 MSFM_OK = 0
 MSFM_E_INVAL, MSFM_E_NOMEM, MSFM_E_DEVICE, MSFM_E_NUMERIC = -1, -2, -3, -4
 MSFM_MATCH_GOOD = 0x40000000
+MSFM_MATCH_NOT_ALL = 0x20000000
+MSFM_MATCH_ID_MASK = 0x1FFFFFFF
 MSFM_MAX_KERNEL_STATS = 32
 
 TERMINATION = {1: "CONVERGENCE_FUNCTION", 2: "CONVERGENCE_GRADIENT", 3: "CONVERGENCE_PARAMETER",

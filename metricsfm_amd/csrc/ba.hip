@@ -1106,11 +1106,14 @@ MSFM_API void msfm_ba_options_default(msfm_ba_options* o) {
 
 MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
   if (!ba) return;
-  (void)hipStreamSynchronize(ba->ctx->stream);
+  msfm_ctx* ctx = ba->ctx;
+  (void)hipSetDevice(ctx->device);   // the caller's thread may have another device current (Python __del__ after set_device)
+  (void)hipStreamSynchronize(ctx->stream);
   if (ba->h_scal) (void)hipHostFree(ba->h_scal);
   if (ba->ev_scal) (void)hipEventDestroy(ba->ev_scal);
   if (ba->h_fail) (void)hipHostFree(ba->h_fail);
   delete ba;
+  msfm_ctx_child_released(ctx);
 }
 
 // Host work arrays of msfm_ba_create that scale with the observation count; owned by the context and reused.
@@ -1169,6 +1172,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   msfm_ba* ba = new msfm_ba();
   struct Guard { msfm_ba* p; ~Guard() { if (p) msfm_ba_destroy(p); } } guard{ba};
   ba->ctx = ctx;
+  ctx->children++;
   ba->world_at_create = ctx->world;
   const int Nc = ba->Nc = P->n_cams, Nm = ba->Nm = P->n_models, Np = ba->Np = P->n_points, No = P->n_obs;
   // ---- which parameter blocks exist (a block exists iff some residual uses it) ----
@@ -1873,8 +1877,20 @@ static int read_scalars(msfm_ba* ba) {
   msfm_ctx* ctx = ba->ctx;
   HIP_TRY(ctx, hipMemcpyAsync(ba->h_scal, ba->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ba->ev_scal, ctx->stream));
+  // spin: the wake-up of a blocking wait costs more than the copy.  Bounded: a wedged kernel, or a peer rank that left the
+  // loop so that a collective never completes, must surface as an error code, not as a host thread spinning forever.
+  static const double limit_s = [] { const char* e = getenv("MSFM_SYNC_TIMEOUT_S"); const double v = e ? atof(e) : 120.0; return v > 0 ? v : 120.0; }();
   hipError_t q;
-  while ((q = hipEventQuery(ba->ev_scal)) == hipErrorNotReady) {}  // spin: the wake-up of a blocking wait costs more than the copy
+  unsigned spins = 0;
+  std::chrono::steady_clock::time_point t0;
+  while ((q = hipEventQuery(ba->ev_scal)) == hipErrorNotReady) {
+    if ((++spins & 0xFFFu) == 0) {   // look at the clock every 4096 polls only
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x1000u) t0 = now;
+      else if (std::chrono::duration<double>(now - t0).count() > limit_s)
+        return msfm_set_error(ctx, MSFM_E_DEVICE, "device did not finish an LM iteration within %.0f s (MSFM_SYNC_TIMEOUT_S)", limit_s);
+    }
+  }
   HIP_TRY(ctx, q);
   return MSFM_OK;
 }
@@ -1942,7 +1958,12 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_ctx_set_allreduce must be called before msfm_ba_create");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  hipEvent_t ev0, ev1;
+  struct Events {   // destroyed on every exit path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } evs;
+  hipEvent_t& ev0 = evs.a;
+  hipEvent_t& ev1 = evs.b;
   const auto run_t0 = std::chrono::steady_clock::now();
   const bool verbose = getenv("MSFM_VERBOSE") != nullptr && ctx->rank == 0;
   auto lap = [&](const char* what) {
@@ -2067,8 +2088,6 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   float ms = 0;
   HIP_TRY(ctx, hipEventElapsedTime(&ms, ev0, ev1));
   sum->solve_ms = ms;
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
   return MSFM_OK;
 }
 

@@ -36,7 +36,12 @@ struct msfm_ctx {
   // mapping + unmapping that much fresh memory on every call cost a quarter of the setup time
   void* ba_scratch = nullptr;
   void (*ba_scratch_free)(void*) = nullptr;
+  // objects created from this context that are still alive (descriptor sets, match results, resident problems);
+  // msfm_ctx_destroy refuses while there are any, and the last child of an orphaned context destroys it
+  int children = 0;
+  bool orphaned = false;
 };
+void msfm_ctx_child_released(msfm_ctx* ctx);
 
 int msfm_set_error(msfm_ctx* ctx, int code, const char* fmt, ...);
 

@@ -33,16 +33,27 @@ MSFM_API int msfm_ctx_create(int device, msfm_ctx** out) {
 }
 
 // ---- cache of freed device blocks (see common.h) ----
+// The pool itself records the capacity and the owning device of every block it has handed out (one map lookup per
+// alloc / free, ~60 per bundle adjustment): the value a caller passes to msfm_pool_free is only cross-checked, never
+// trusted, and a block always returns to the free list of the device it was allocated on, whatever device the freeing
+// thread has current.  (A capacity mix-up in a buffer swap once put a 32 KB block on the 64 KB list; the next kernel
+// that received it wrote out of bounds.)
 #include <map>
 #include <mutex>
 namespace {
 struct Pool {
   std::mutex mu;
-  std::map<void*, size_t> live;   // MSFM_POOL_DEBUG: blocks handed out -> capacity
+  struct Live { size_t capacity; int device; };
+  std::map<void*, Live> live;   // blocks handed out
   std::multimap<std::pair<int, size_t>, void*> free_blocks;  // (device, capacity) -> block
   size_t cached_bytes = 0;
+  size_t mismatches = 0;
   size_t limit() {
     static const size_t v = [] { const char* e = getenv("MSFM_POOL_MB"); return (size_t)(e ? atol(e) : 16384) << 20; }();
+    return v;
+  }
+  bool debug() {
+    static const bool v = getenv("MSFM_POOL_DEBUG") != nullptr;
     return v;
   }
 };
@@ -68,10 +79,8 @@ hipError_t msfm_pool_alloc(void** p, size_t bytes, size_t* capacity) {
       *capacity = it->first.second;
       P.cached_bytes -= it->first.second;
       P.free_blocks.erase(it);
-      if (getenv("MSFM_POOL_DEBUG")) {
-        if (P.live.count(*p)) { fprintf(stderr, "msfm pool: block %p handed out twice\n", *p); abort(); }
-        P.live[*p] = *capacity;
-      }
+      if (P.live.count(*p)) { fprintf(stderr, "msfm pool: block %p handed out twice\n", *p); abort(); }
+      P.live[*p] = Pool::Live{*capacity, dev};
       return hipSuccess;
     }
   }
@@ -82,35 +91,48 @@ hipError_t msfm_pool_alloc(void** p, size_t bytes, size_t* capacity) {
     e = hipMalloc(p, want);
   }
   *capacity = want;
-  if (e == hipSuccess && getenv("MSFM_POOL_DEBUG")) {
+  if (e == hipSuccess) {
     std::lock_guard<std::mutex> g(P.mu);
     if (P.live.count(*p)) { fprintf(stderr, "msfm pool: hipMalloc returned a live block %p\n", *p); abort(); }
-    for (auto& kv : P.free_blocks) if (kv.second == *p) { fprintf(stderr, "msfm pool: hipMalloc returned a cached block %p\n", *p); abort(); }
-    P.live[*p] = want;
+    if (P.debug())
+      for (auto& kv : P.free_blocks) if (kv.second == *p) { fprintf(stderr, "msfm pool: hipMalloc returned a cached block %p\n", *p); abort(); }
+    P.live[*p] = Pool::Live{want, dev};
   }
   return e;
 }
 
 void msfm_pool_free(void* p, size_t capacity) {
   if (!p) return;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
   Pool& P = pool();
+  int dev = 0;
   {
     std::lock_guard<std::mutex> g(P.mu);
-    if (getenv("MSFM_POOL_DEBUG")) {
-      auto it = P.live.find(p);
-      if (it == P.live.end()) { fprintf(stderr, "msfm pool: free of unknown block %p (capacity %zu)\n", p, capacity); abort(); }
-      if (it->second != capacity) { fprintf(stderr, "msfm pool: block %p freed with capacity %zu, allocated with %zu\n", p, capacity, it->second); abort(); }
-      P.live.erase(it);
+    auto it = P.live.find(p);
+    if (it == P.live.end()) {
+      // not one of ours (or freed twice): never cache it
+      fprintf(stderr, "msfm pool: free of unknown block %p (capacity %zu)\n", p, capacity);
+      if (P.debug()) abort();
+      return;
     }
+    if (it->second.capacity != capacity) {
+      P.mismatches++;
+      fprintf(stderr, "msfm pool: block %p freed with capacity %zu, allocated with %zu\n", p, capacity, it->second.capacity);
+      if (P.debug()) abort();
+    }
+    capacity = it->second.capacity;   // the recorded values win
+    dev = it->second.device;
+    P.live.erase(it);
     if (capacity > 0 && P.cached_bytes + capacity <= P.limit()) {
       P.free_blocks.insert({{dev, capacity}, p});
       P.cached_bytes += capacity;
       return;
     }
   }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != dev) (void)hipSetDevice(dev);
   (void)hipFree(p);
+  if (cur != dev) (void)hipSetDevice(cur);
 }
 
 void msfm_pool_trim(int device) {
@@ -123,11 +145,22 @@ void msfm_pool_trim(int device) {
       else ++it;
     }
   }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != device) (void)hipSetDevice(device);
   for (void* q : drop) (void)hipFree(q);
+  if (cur != device) (void)hipSetDevice(cur);
 }
 
 MSFM_API void msfm_ctx_destroy(msfm_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->children > 0) {
+    // descriptor sets, match results and resident problems hold ctx->stream: destroying the context under them would
+    // leave their destroy functions with a dangling pointer.  Keep the context (a leak, reported) instead.
+    if (getenv("MSFM_VERBOSE")) fprintf(stderr, "msfm_ctx_destroy: %d object(s) created from this context are still alive; context kept until they go\n", ctx->children);
+    ctx->orphaned = true;
+    return;
+  }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   msfm_pool_trim(ctx->device);
@@ -136,6 +169,12 @@ MSFM_API void msfm_ctx_destroy(msfm_ctx* ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+void msfm_ctx_child_released(msfm_ctx* ctx) {
+  if (!ctx) return;
+  ctx->children--;
+  if (ctx->children == 0 && ctx->orphaned) { ctx->orphaned = false; msfm_ctx_destroy(ctx); }
 }
 
 MSFM_API const char* msfm_last_error(const msfm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }

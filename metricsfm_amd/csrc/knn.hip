@@ -47,6 +47,9 @@ struct msfm_descset {
   DevBuf<unsigned> n2max_dev;
   DevBuf<int> nonint;                    // OR of "not integer in [0,255]" over all uploads
   int h_nonint = 0;
+  // bumped by every upload: a match result remembers the generation its device pointer tables were built at and
+  // refuses to run or to be read once an image has been replaced under it
+  unsigned long generation = 0;
 };
 
 // ---- prep: f32 -> bf16, squared norms, integrality flag -------------------------------
@@ -102,6 +105,17 @@ __device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) {
   u32 r;
   asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
+}
+
+// The two ratio tests of fine_matching_graph.cc:116-130, evaluated independently of each other as the reference does
+// (a match can be "good" without being in the "all" set when ratio_good > ratio_all).  -1: in neither set.
+__device__ __forceinline__ int32_t ratio_code(float d0, float d1, int id0, float ratio_good, float ratio_all, int* n_all, int* n_good) {
+  const float ratio = d0 / d1;  // fine_matching_graph.cc:118
+  const bool good = ratio < ratio_good, all = ratio < ratio_all;
+  if (good) atomicAdd(n_good, 1);
+  if (all) atomicAdd(n_all, 1);
+  if (!good && !all) return -1;
+  return id0 | (good ? MSFM_MATCH_GOOD : 0) | (all ? 0 : MSFM_MATCH_NOT_ALL);
 }
 
 // merge candidate (d, i) into the sorted pair (d0,i0) <= (d1,i1); ties keep the earlier (lower index first)
@@ -251,16 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2_bf16(const PairTask* __restrict
       const float d0 = (float)((int)D0 - 8388608 + b2), d1 = (float)((int)D1 - 8388608 + b2);
       const size_t o = (size_t)T.out_off + q;
       if (ids) { ids[2 * o] = I0; ids[2 * o + 1] = I1; sqd[2 * o] = d0; sqd[2 * o + 1] = d1; }
-      if (code) {
-        const float ratio = d0 / d1;  // fine_matching_graph.cc:118
-        int32_t c = -1;
-        if (ratio < ratio_all) {
-          c = I0;
-          atomicAdd(&n_all[pair], 1);
-          if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
-        }
-        code[o] = c;
-      }
+      if (code) code[o] = ratio_code(d0, d1, I0, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
     }
   }
 }
@@ -412,16 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2_i8(const PairTask8* __restrict_
       const float d0 = (float)((int)D0 - (1 << 22) + beta), d1 = (float)((int)D1 - (1 << 22) + beta);
       const size_t o = (size_t)T.out_off + q;
       if (ids) { ids[2 * o] = I0; ids[2 * o + 1] = I1; sqd[2 * o] = d0; sqd[2 * o + 1] = d1; }
-      if (code) {
-        const float ratio = d0 / d1;  // fine_matching_graph.cc:118
-        int32_t c = -1;
-        if (ratio < ratio_all) {
-          c = I0;
-          atomicAdd(&n_all[pair], 1);
-          if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
-        }
-        code[o] = c;
-      }
+      if (code) code[o] = ratio_code(d0, d1, I0, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
     }
   }
 }
@@ -479,16 +475,7 @@ __global__ __launch_bounds__(64) void k_knn2_exact(const PairTaskF* __restrict__
     const float f0 = (float)d0, f1 = (float)d1;
     const size_t o = (size_t)T.out_off + q;
     if (ids) { ids[2 * o] = i0; ids[2 * o + 1] = i1; sqd[2 * o] = f0; sqd[2 * o + 1] = f1; }
-    if (code) {
-      const float ratio = f0 / f1;
-      int32_t c = -1;
-      if (ratio < ratio_all) {
-        c = i0;
-        atomicAdd(&n_all[pair], 1);
-        if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[pair], 1); }
-      }
-      code[o] = c;
-    }
+    if (code) code[o] = ratio_code(f0, f1, i0, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
   }
 }
 
@@ -775,14 +762,7 @@ __global__ __launch_bounds__(256) void k_codes(const int* __restrict__ qpair, lo
                                                 int32_t* __restrict__ code, int* __restrict__ n_all, int* __restrict__ n_good) {
   const long o = (long)blockIdx.x * 256 + threadIdx.x;
   if (o >= total_q) return;
-  const float ratio = sqd[2 * o] / sqd[2 * o + 1];
-  int32_t c = -1;
-  if (ratio < ratio_all) {
-    c = ids[2 * o];
-    atomicAdd(&n_all[qpair[o]], 1);
-    if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; atomicAdd(&n_good[qpair[o]], 1); }
-  }
-  code[o] = c;
+  code[o] = ratio_code(sqd[2 * o], sqd[2 * o + 1], ids[2 * o], ratio_good, ratio_all, &n_all[qpair[o]], &n_good[qpair[o]]);
 }
 
 // ---- host ---------------------------------------------------------------------------------
@@ -792,6 +772,7 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   msfm_descset* s = new msfm_descset();
   s->ctx = ctx; s->n_images = n_images; s->dim = dim;
+  ctx->children++;
   s->count.assign(n_images, 0);
   s->f32.assign(n_images, nullptr); s->bf16.assign(n_images, nullptr); s->norm.assign(n_images, nullptr);
   s->shi.assign(n_images, nullptr); s->slo.assign(n_images, nullptr); s->sn2.assign(n_images, nullptr); s->sn2max.assign(n_images, 0.f);
@@ -806,7 +787,9 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
 
 MSFM_API void msfm_descset_destroy(msfm_descset* s) {
   if (!s) return;
-  (void)hipStreamSynchronize(s->ctx->stream);
+  msfm_ctx* ctx = s->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
   for (auto p : s->f32) delete p;
   for (auto p : s->bf16) delete p;
   for (auto p : s->norm) delete p;
@@ -819,6 +802,7 @@ MSFM_API void msfm_descset_destroy(msfm_descset* s) {
   for (auto p : s->tpar) delete p;
   for (auto p : s->qbeta) delete p;
   delete s;
+  msfm_ctx_child_released(ctx);
 }
 
 MSFM_API int msfm_descset_count(const msfm_descset* s, int image) {
@@ -831,6 +815,10 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
   msfm_ctx* ctx = s->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  // kernels of an earlier msfm_match_pairs may still be reading this image's buffers: blocks go back to the pool only
+  // after their stream has drained (common.h)
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  s->generation++;
   delete s->f32[image]; delete s->bf16[image]; delete s->norm[image];
   delete s->shi[image]; delete s->slo[image]; delete s->sn2[image];
   s->shi[image] = new DevBuf<unsigned short>(); s->slo[image] = new DevBuf<unsigned short>(); s->sn2[image] = new DevBuf<float>();
@@ -867,6 +855,7 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
 
 struct msfm_match_result {
   msfm_descset* set;
+  msfm_ctx* ctx = nullptr;   // kept separately: the descriptor set may be destroyed before its results
   int n_pairs = 0;
   long total_q = 0;
   bool keep_knn = false;
@@ -886,7 +875,15 @@ struct msfm_match_result {
   bool use_bf16 = false;  // MSFM_KNN_BF16=1 selects the bf16 MFMA kernel instead of the int8 one
   int n_tiles = 0;
   bool exact_path = false;
+  unsigned long generation = 0;   // of the descriptor set when the task tables were built
 };
+
+static int check_generation(const msfm_match_result* R) {
+  if (R->generation != R->set->generation)
+    return msfm_set_error(R->set->ctx, MSFM_E_INVAL, "an image of the descriptor set was uploaded again after this match result was created; "
+                                                     "create a new result with msfm_match_pairs");
+  return MSFM_OK;
+}
 
 static int launch_match(msfm_match_result* R) {
   msfm_ctx* ctx = R->set->ctx;
@@ -943,7 +940,10 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
     if (s->count[a] < 2) return msfm_set_error(ctx, MSFM_E_INVAL, "pair %d: train image %d has %d < 2 descriptors", p, a, s->count[a]);
   }
   msfm_match_result* R = new msfm_match_result();
-  struct Guard { msfm_match_result* p; ~Guard() { delete p; } } guard{R};
+  struct Guard { msfm_match_result* p; msfm_ctx* c; ~Guard() { if (p) { delete p; msfm_ctx_child_released(c); } } } guard{R, ctx};
+  ctx->children++;
+  R->generation = s->generation;
+  R->ctx = ctx;
   R->set = s; R->n_pairs = n_pairs; R->keep_knn = keep_knn != 0; R->ratio_good = ratio_good; R->ratio_all = ratio_all;
   R->pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
   R->exact_path = s->h_nonint != 0;
@@ -1001,6 +1001,8 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
 
 MSFM_API int msfm_match_pairs_rerun(msfm_descset* s, msfm_match_result* R) {
   if (!s || !R || R->set != s) return MSFM_E_INVAL;
+  MSFM_TRY(check_generation(R));
+  HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
   return launch_match(R);
 }
 
@@ -1017,6 +1019,7 @@ MSFM_API int msfm_match_result_counts(msfm_match_result* R, int* n_all, int* n_g
 MSFM_API int msfm_match_result_fetch(msfm_match_result* R, int pair, int32_t* code, int* ids, float* sqdists) {
   if (!R || pair < 0 || pair >= R->n_pairs) return MSFM_E_INVAL;
   msfm_ctx* ctx = R->set->ctx;
+  MSFM_TRY(check_generation(R));
   if ((ids || sqdists) && !R->keep_knn) return msfm_set_error(ctx, MSFM_E_INVAL, "result was created without keep_knn");
   const size_t o = R->out_off[pair], n = R->nq[pair];
   hipStream_t st = ctx->stream;
@@ -1043,8 +1046,11 @@ MSFM_API int msfm_match_result_stats(msfm_match_result* R, int* n_queries, int* 
 
 MSFM_API void msfm_match_result_destroy(msfm_match_result* R) {
   if (!R) return;
-  (void)hipStreamSynchronize(R->set->ctx->stream);
+  msfm_ctx* ctx = R->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
   delete R;
+  msfm_ctx_child_released(ctx);
 }
 
 // The FLANN-shaped entry point: one train set, one query set, host buffers in and out.

@@ -62,7 +62,8 @@ def codes_to_matches(code):
     """(ptid1, ptid2) lists of the reference loop (fine_matching_graph.cc:116-133) from msfm_match_pairs codes."""
     code = np.asarray(code)
     m2 = np.nonzero(code >= 0)[0].astype(np.int32)
-    m1 = (code[m2] & ~A.MSFM_MATCH_GOOD).astype(np.int32)
+    m1 = (code[m2] & A.MSFM_MATCH_ID_MASK).astype(np.int32)
     good = (code[m2] & A.MSFM_MATCH_GOOD) != 0
+    in_all = (code[m2] & A.MSFM_MATCH_NOT_ALL) == 0      # the two ratio tests are independent (:118-130)
     allm = np.column_stack([m1, m2])
-    return allm[good], allm
+    return allm[good], allm[in_all]

@@ -1311,8 +1311,11 @@ ORC_API void orc_ratio_codes(const int* ids, const float* sqd, int n_query, floa
   for (int m = 0; m < n_query; m++) {
     const float ratio = sqd[2 * (size_t)m] / sqd[2 * (size_t)m + 1];
     int32_t c = -1;
-    if (ratio < ratio_all) { c = ids[2 * (size_t)m]; na++; if (ratio < ratio_good) { c |= MSFM_MATCH_GOOD; ng++; } }
-    else if (ratio < ratio_good) { /* unreachable when ratio_good <= ratio_all */ }
+    // two independent tests (fine_matching_graph.cc:118-130)
+    const bool good = ratio < ratio_good, all = ratio < ratio_all;
+    if (good) ng++;
+    if (all) na++;
+    if (good || all) c = ids[2 * (size_t)m] | (good ? MSFM_MATCH_GOOD : 0) | (all ? 0 : MSFM_MATCH_NOT_ALL);
     code[m] = c;
   }
   *n_all = na; *n_good = ng;

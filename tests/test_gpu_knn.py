@@ -156,7 +156,7 @@ def test_match_pairs_ratio_codes(ctx, oracle):
     i, j = pairs[0]
     good = (code >= 0) & ((code & A.MSFM_MATCH_GOOD) != 0)
     assert good.sum() > 10
-    assert (sc.feat_point[i][code[good] & 0x3FFFFFFF] == sc.feat_point[j][np.nonzero(good)[0]]).mean() > 0.95
+    assert (sc.feat_point[i][code[good] & A.MSFM_MATCH_ID_MASK] == sc.feat_point[j][np.nonzero(good)[0]]).mean() > 0.95
 
 
 def test_knn2_bad_arguments(ctx):
@@ -169,3 +169,65 @@ def test_knn2_bad_arguments(ctx):
         ctx.knn2(np.zeros((4, 64), np.float32), np.zeros((4, 64), np.float32))  # dim != 128
     ids, d = ctx.knn2(np.zeros((4, 128), np.float32), np.zeros((0, 128), np.float32))  # empty query
     assert ids.shape == (0, 2)
+
+
+def test_ratio_tests_are_independent(ctx, oracle):
+    """fine_matching_graph.cc:118-130 tests `ratio < thRatio_good` and `ratio < thRatio_all` separately: with
+    ratio_good > ratio_all a match can be good without being in the all set (MSFM_MATCH_NOT_ALL)."""
+    sc = scene.make_ring_scene(3, 600, seed=23)
+    scene.add_features(sc, 900)
+    ds = ctx.descset(sc.desc)
+    res = ds.match_pairs(np.array([[0, 1], [2, 0]], np.int32), ratio_good=0.99, ratio_all=0.9, keep_knn=True)
+    na, ng = res.counts()
+    for p in range(2):
+        code, ids, d = res.fetch(p)
+        code_r, na_r, ng_r = oracle.ratio_codes(ids, d, 0.99, 0.9)
+        np.testing.assert_array_equal(code, code_r)
+        assert (na[p], ng[p]) == (na_r, ng_r) and ng_r > na_r > 0
+        only_good = (code >= 0) & ((code & A.MSFM_MATCH_NOT_ALL) != 0)
+        assert only_good.sum() == ng_r - na_r and ((code[only_good] & A.MSFM_MATCH_GOOD) != 0).all()
+        from metricsfm_amd import matchfiles
+        good, allm = matchfiles.codes_to_matches(code)
+        assert len(good) == ng_r and len(allm) == na_r
+
+
+def test_result_goes_stale_when_an_image_is_uploaded_again(ctx):
+    """msfm_descset_upload replaces device buffers a live result still points to: rerun / fetch on the old result must
+    fail with MSFM_E_INVAL instead of reading recycled memory; a new result sees the new data (incl. the path choice:
+    non-integral data uploaded later takes the certified float path, not the int8 kernel)."""
+    import ctypes as C
+    from metricsfm_amd import capi
+    rng = np.random.default_rng(5)
+    d = [np.rint(rng.uniform(0, 255, (300, 128))).astype(np.float32) for _ in range(2)]
+    ds = ctx.descset(d)
+    res = ds.match_pairs(np.array([[0, 1]], np.int32), keep_knn=True)
+    code0, ids0, _ = res.fetch(0)
+    newd = (rng.uniform(0, 255, (300, 128))).astype(np.float32)      # non-integral
+    ctx.check(capi.lib().msfm_descset_upload(ds._h, 1, A.ptr(newd, A.c_float_p), len(newd)))
+    for call in (res.rerun, lambda: res.fetch(0)):
+        with pytest.raises(capi.MsfmError) as e:
+            call()
+        assert e.value.code == A.MSFM_E_INVAL
+    res2 = ds.match_pairs(np.array([[0, 1]], np.int32), keep_knn=True)
+    _, ids2, d2 = res2.fetch(0)
+    dd = ((newd[:, None, :].astype(np.float64) - d[0][None, :, :].astype(np.float64)) ** 2).sum(-1)
+    np.testing.assert_array_equal(ids2[:, 0], dd.argmin(1))
+    assert res2.stats()["queries"] == 300
+
+
+def test_context_outlives_its_children(oracle):
+    """msfm_ctx_destroy with live children keeps the context until the last child goes (their destroy functions use its
+    stream); destroy entry points set their own device."""
+    from metricsfm_amd import capi
+    c = capi.Context(0)
+    sc = scene.make_ring_scene(4, 200, seed=3)
+    ba = c.ba(A.BaArrays.from_scene(sc))
+    rng = np.random.default_rng(1)
+    ds = c.descset([np.rint(rng.uniform(0, 255, (64, 128))).astype(np.float32) for _ in range(2)])
+    res = ds.match_pairs(np.array([[0, 1]], np.int32))
+    c.close()                       # children alive: the library keeps the context
+    r = ba.run(capi.default_options(max_num_iterations=3))
+    assert r["num_iterations"] == 3
+    ds.close()                      # the set goes before its result
+    res.close()
+    ba.close()                      # last child: the context is released here
