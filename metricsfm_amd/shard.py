@@ -111,3 +111,8 @@ class TorchAllReduce:
                 t.copy_(h)
                 ext.synchronize()
         return 0
+
+
+def make_allreduce(dist, device_index, ctx=None, group=None):
+    """The collective the library's hook calls (msfm_ctx_set_allreduce): torch.distributed on the library's stream."""
+    return TorchAllReduce(dist, device_index, group)

@@ -27,12 +27,30 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <array>
 #include <vector>
 
 #include "../include/msfm.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_API extern "C" __attribute__((visibility("default")))
+
+// Host threads for the timing legs of bench.py (SURVEY.md 8d "(b) all host cores": the reference runs its kNN loop under
+// OpenMP, fine_matching_graph.cc:87, and SLAMGPS hands Ceres num_threads = 8, slam_gps.cc:683).  Threads only ever split
+// work whose results do not depend on the split: every sum keeps the order of the single-thread code, so a run with N
+// threads is bit-identical to the run with one (tests/test_oracle.py).
+static int g_orc_threads = 1;
+ORC_API void orc_set_num_threads(int n) { g_orc_threads = n < 1 ? 1 : n; }
+ORC_API int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 // -------------------------------------------------------------------------------------
 // Rotation helpers — SfM/src/utils/basic_funcs.cc:25-225 (in-tree copies of the Ceres
@@ -321,6 +339,10 @@ struct Ba {
   std::vector<double> step_c, step_m, step_p;      // trust_region_step_
   std::vector<double> grad_c, grad_m, grad_p;      // gradient_
   std::vector<double> lhs, rhs;
+  int threads = 1;
+  std::unique_ptr<char[]> elim_store;   // per-point products of the threaded elimination
+  size_t elim_bytes = 0;
+  std::vector<double> scratch;   // per-observation terms of a threaded pass, summed in order afterwards
 };
 
 static bool is_mut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
@@ -402,8 +424,9 @@ static double ba_evaluate(Ba& B, const std::vector<double>& cam, const std::vect
     B.grad_m.assign(3 * (size_t)B.n_model_blocks, 0.0);
     B.grad_p.assign(3 * (size_t)B.n_pt_blocks, 0.0);
   }
-  for (size_t i = 0; i < B.obs.size(); i++) {
-    Obs& ob = B.obs[i];
+  const int nt = B.threads;
+  // one residual block: returns its cost term; with `lin` the corrected Jacobian goes to ob
+  auto eval_one = [&](Obs& ob) -> double {
     double r[2], J[24], rho[3];
     const double w = P->pt_weight ? P->pt_weight[ob.pt] : 1.0;
     orc_reproj_analytic(&cam[6 * (size_t)ob.cam], &model[3 * (size_t)ob.model],
@@ -411,18 +434,37 @@ static double ba_evaluate(Ba& B, const std::vector<double>& cam, const std::vect
                         lin ? J : nullptr);
     const double s = r[0] * r[0] + r[1] * r[1];
     huber(delta, s, rho);
-    cost += 0.5 * rho[0];
-    if (!lin) continue;
-    const double sq = std::sqrt(rho[1]);
-    ob.r[0] = sq * r[0]; ob.r[1] = sq * r[1];
-    for (int k = 0; k < 2; k++) {
-      for (int j = 0; j < 6; j++) ob.Jc[k * 6 + j] = sq * J[k * 12 + j];
-      for (int j = 0; j < 3; j++) ob.Jm[k * 3 + j] = sq * J[k * 12 + 6 + j];
-      for (int j = 0; j < 3; j++) ob.Jp[k * 3 + j] = sq * J[k * 12 + 9 + j];
+    if (lin) {
+      const double sq = std::sqrt(rho[1]);
+      ob.r[0] = sq * r[0]; ob.r[1] = sq * r[1];
+      for (int k = 0; k < 2; k++) {
+        for (int j = 0; j < 6; j++) ob.Jc[k * 6 + j] = sq * J[k * 12 + j];
+        for (int j = 0; j < 3; j++) ob.Jm[k * 3 + j] = sq * J[k * 12 + 6 + j];
+        for (int j = 0; j < 3; j++) ob.Jp[k * 3 + j] = sq * J[k * 12 + 9 + j];
+      }
     }
+    return 0.5 * rho[0];
+  };
+  auto grad_one = [&](const Obs& ob) {
     if (ob.cslot >= 0) for (int j = 0; j < 6; j++) B.grad_c[ob.cslot + j] += ob.Jc[j] * ob.r[0] + ob.Jc[6 + j] * ob.r[1];
     if (ob.mslot >= 0) for (int j = 0; j < 3; j++) B.grad_m[ob.mslot - 6 * B.n_cam_blocks + j] += ob.Jm[j] * ob.r[0] + ob.Jm[3 + j] * ob.r[1];
     if (ob.pslot >= 0) for (int j = 0; j < 3; j++) B.grad_p[3 * (size_t)ob.pslot + j] += ob.Jp[j] * ob.r[0] + ob.Jp[3 + j] * ob.r[1];
+  };
+  if (nt <= 1) {
+    for (size_t i = 0; i < B.obs.size(); i++) {
+      cost += eval_one(B.obs[i]);
+      if (lin) grad_one(B.obs[i]);
+    }
+  } else {
+    // the projections (sincos, divisions) run on all threads; the sums that follow keep the single-thread order
+    B.scratch.resize(B.obs.size());
+    const long n = (long)B.obs.size();
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (long i = 0; i < n; i++) B.scratch[i] = eval_one(B.obs[i]);
+    for (long i = 0; i < n; i++) {
+      cost += B.scratch[i];
+      if (lin) grad_one(B.obs[i]);
+    }
   }
   for (size_t i = 0; i < B.gps.size(); i++) {
     GpsRes& g = B.gps[i];
@@ -468,20 +510,55 @@ static void ba_scale_columns(Ba& B) {
 // In-place Cholesky A = L L^T on the lower triangle of a row-major n x n matrix
 // (what `lhs.selfadjointView<Upper>().llt()` does in DenseSchurComplementSolver).
 // Row-oriented so the inner loop is a contiguous dot product.  Returns false if not PD.
-static bool dense_cholesky_lower(double* A, int n) {
-  for (int i = 0; i < n; i++) {
-    double* Ai = A + (size_t)i * n;
-    for (int j = 0; j <= i; j++) {
-      const double* Aj = A + (size_t)j * n;
-      double s = 0.0;
+static __attribute__((noinline)) double chol_dot(const double* a, const double* b, int n) {
+  double s = 0.0;
 #pragma omp simd reduction(+ : s)
-      for (int k = 0; k < j; k++) s += Ai[k] * Aj[k];
-      if (i == j) {
-        const double d = Ai[i] - s;
-        if (!(d > 0.0)) return false;
-        Ai[i] = std::sqrt(d);
-      } else {
-        Ai[j] = (Ai[j] - s) / Aj[j];
+  for (int k = 0; k < n; k++) s += a[k] * b[k];
+  return s;
+}
+static bool dense_cholesky_lower(double* A, int n, int nt = 1) {
+  if (nt <= 1) {
+    for (int i = 0; i < n; i++) {
+      double* Ai = A + (size_t)i * n;
+      for (int j = 0; j <= i; j++) {
+        const double* Aj = A + (size_t)j * n;
+        const double s = chol_dot(Ai, Aj, j);
+        if (i == j) {
+          const double d = Ai[i] - s;
+          if (!(d > 0.0)) return false;
+          Ai[i] = std::sqrt(d);
+        } else {
+          Ai[j] = (Ai[j] - s) / Aj[j];
+        }
+      }
+    }
+    return true;
+  }
+  // The same row-oriented recurrence, every entry from the same dot product: a block of rows first takes its columns
+  // left of the block on all threads (they only need finished rows), then the small triangle inside the block in order.
+  const int RB = 48;
+  for (int r0 = 0; r0 < n; r0 += RB) {
+    const int r1 = std::min(n, r0 + RB);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+    for (int i = r0; i < r1; i++) {
+      double* Ai = A + (size_t)i * n;
+      for (int j = 0; j < r0; j++) {
+        const double* Aj = A + (size_t)j * n;
+        Ai[j] = (Ai[j] - chol_dot(Ai, Aj, j)) / Aj[j];
+      }
+    }
+    for (int i = r0; i < r1; i++) {
+      double* Ai = A + (size_t)i * n;
+      for (int j = r0; j <= i; j++) {
+        const double* Aj = A + (size_t)j * n;
+        const double s = chol_dot(Ai, Aj, j);
+        if (i == j) {
+          const double d = Ai[i] - s;
+          if (!(d > 0.0)) return false;
+          Ai[i] = std::sqrt(d);
+        } else {
+          Ai[j] = (Ai[j] - s) / Aj[j];
+        }
       }
     }
   }
@@ -530,6 +607,14 @@ static void chol3_solve(const double* L, double* b) {  // solves (L L^T) x = b i
 // Returns false for LINEAR_SOLVER_FAILURE (step stays invalid).
 static bool ba_compute_step(Ba& B, double radius, bool reuse_diagonal, double* model_cost_change,
                             bool assemble_only = false) {
+  static const bool verbose = getenv("ORC_VERBOSE") != nullptr;
+  auto tlast = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "orc: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tlast).count());
+    tlast = now;
+  };
   const int n = B.nred, mo = 6 * B.n_cam_blocks;
   const size_t ncc = B.scale_c.size(), nmc = B.scale_m.size(), npc = B.scale_p.size();
   if (!reuse_diagonal) {
@@ -572,9 +657,147 @@ static bool ba_compute_step(Ba& B, double radius, bool reuse_diagonal, double* m
       }
   };
 
-  // per eliminated point: chunk elimination
   std::vector<double> Lp(9 * (size_t)B.n_pt_blocks), gp(3 * (size_t)B.n_pt_blocks);
   struct Ent { int slot, dim; double W[18]; };  // W = F_b^T E, dim x 3
+  const int nt = B.threads;
+  if (nt > 1) {
+    // Threaded elimination with the single-thread arithmetic.  Phase 1 (all threads, one point each): V, g, the
+    // per-f-block products W, the 3x3 factor, V^-1 g and Z = V^-1 W^T.  Phase 2: every thread walks ALL points in order
+    // but applies only the updates whose row block it owns, so each entry of S / rhs receives its terms in exactly the
+    // order of the single-thread loop.
+    struct PEnt { int slot, dim; double W[18], Z[18]; };
+    const int npb = B.n_pt_blocks;
+    std::vector<long> ent_first(npb + 1, 0);
+    for (int pb = 0; pb < npb; pb++) {
+      const int k = B.pt_first[pb + 1] - B.pt_first[pb];
+      ent_first[pb + 1] = ent_first[pb] + k + std::min(k, std::max(1, B.n_model_blocks));
+    }
+    // not zero-filled (first touched by the thread that fills it) and kept for the next linear solve
+    const size_t pents_bytes = sizeof(PEnt) * (size_t)ent_first[npb];
+    if (B.elim_bytes < pents_bytes) { B.elim_store.reset(new char[pents_bytes]); B.elim_bytes = pents_bytes; }
+    PEnt* const pents_data = reinterpret_cast<PEnt*>(B.elim_store.get());
+    std::vector<int> ent_count(npb, 0);
+    std::vector<double> vgs(3 * (size_t)npb);
+    int failed = 0;
+#pragma omp parallel for num_threads(nt) schedule(static, 256)
+    for (int pb = 0; pb < npb; pb++) {
+      double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+      PEnt* ents = pents_data + ent_first[pb];
+      int ne = 0;
+      for (int i = B.pt_first[pb]; i < B.pt_first[pb + 1]; i++) {
+        const Obs& ob = B.obs[i];
+        for (int a = 0; a < 3; a++) {
+          for (int b = 0; b < 3; b++) V[a * 3 + b] += ob.Jp[a] * ob.Jp[b] + ob.Jp[3 + a] * ob.Jp[3 + b];
+          g[a] += ob.Jp[a] * ob.r[0] + ob.Jp[3 + a] * ob.r[1];
+        }
+        for (int which = 0; which < 2; which++) {
+          const int slot = which == 0 ? ob.cslot : ob.mslot;
+          if (slot < 0) continue;
+          const int dim = which == 0 ? 6 : 3;
+          const double* Jf = which == 0 ? ob.Jc : ob.Jm;
+          PEnt* e = nullptr;
+          for (int q = 0; q < ne; q++) if (ents[q].slot == slot) { e = &ents[q]; break; }
+          if (!e) { e = &ents[ne++]; e->slot = slot; e->dim = dim; std::fill(e->W, e->W + 18, 0.0); }
+          for (int a = 0; a < dim; a++) for (int b = 0; b < 3; b++) e->W[a * 3 + b] += Jf[a] * ob.Jp[b] + Jf[dim + a] * ob.Jp[3 + b];
+        }
+      }
+      for (int a = 0; a < 3; a++) V[a * 3 + a] += d2(B.diag_p[3 * (size_t)pb + a]);
+      double* L = &Lp[9 * (size_t)pb];
+      if (!chol3(V, L)) {
+#pragma omp atomic write
+        failed = 1;
+        continue;
+      }
+      for (int a = 0; a < 3; a++) gp[3 * (size_t)pb + a] = g[a];
+      std::sort(ents, ents + ne, [](const PEnt& a, const PEnt& b) { return a.slot < b.slot; });
+      double vg[3] = {g[0], g[1], g[2]};
+      chol3_solve(L, vg);
+      for (int a = 0; a < 3; a++) vgs[3 * (size_t)pb + a] = vg[a];
+      for (int j = 0; j < ne; j++) {
+        PEnt& ej = ents[j];
+        for (int a = 0; a < ej.dim; a++) {
+          double col[3] = {ej.W[a * 3 + 0], ej.W[a * 3 + 1], ej.W[a * 3 + 2]};
+          chol3_solve(L, col);
+          for (int b = 0; b < 3; b++) ej.Z[b * ej.dim + a] = col[b];
+        }
+      }
+      ent_count[pb] = ne;
+    }
+    if (failed) return false;
+    lap("eliminate: per point");
+    // Row blocks are owned in contiguous ranges (cameras that see a point are neighbours in index on survey-like
+    // scenes, so a point usually concerns one or two owners), balanced by the rows' observation counts; every owner gets
+    // the ordered list of the points it has work for and never looks at the others.
+    const int nblk = B.n_cam_blocks + B.n_model_blocks;
+    std::vector<long> blk_work(nblk, 0);
+    for (const Obs& ob : B.obs) {
+      if (ob.cslot >= 0) blk_work[ob.cslot / 6] += 4;
+      if (ob.mslot >= 0) blk_work[B.n_cam_blocks + (ob.mslot - mo) / 3] += 1;
+    }
+    long total_work = 0;
+    for (long w : blk_work) total_work += w;
+    std::vector<int> blk_owner(nblk, 0);
+    {
+      long run = 0;
+      for (int b = 0; b < nblk; b++) { blk_owner[b] = (int)std::min<long>(nt - 1, run * nt / std::max<long>(1, total_work)); run += blk_work[b]; }
+    }
+    auto owner = [&](int slot) { return blk_owner[slot < mo ? slot / 6 : B.n_cam_blocks + (slot - mo) / 3]; };
+    std::vector<std::vector<int>> my_points(nt);
+    {
+      std::vector<char> seen(nt);
+      for (int pb = 0; pb < npb; pb++) {
+        std::fill(seen.begin(), seen.end(), 0);
+        const PEnt* ents = pents_data + ent_first[pb];
+        for (int j = 0; j < ent_count[pb]; j++) seen[owner(ents[j].slot)] = 1;
+        for (int t = 0; t < nt; t++) if (seen[t]) my_points[t].push_back(pb);
+      }
+    }
+    lap("eliminate: work lists");
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+      const int t = omp_get_thread_num();
+#else
+      const int t = 0;
+#endif
+      for (int pb : my_points[t]) {
+        for (int i = B.pt_first[pb]; i < B.pt_first[pb + 1]; i++) {   // add_ftf, rows owned by this thread
+          const Obs& ob = B.obs[i];
+          if (ob.cslot >= 0 && owner(ob.cslot) == t) {
+            for (int a = 0; a < 6; a++) {
+              for (int b = a; b < 6; b++) S[(size_t)(ob.cslot + a) * n + ob.cslot + b] += ob.Jc[a] * ob.Jc[b] + ob.Jc[6 + a] * ob.Jc[6 + b];
+              B.rhs[ob.cslot + a] += ob.Jc[a] * ob.r[0] + ob.Jc[6 + a] * ob.r[1];
+            }
+            if (ob.mslot >= 0)
+              for (int a = 0; a < 6; a++) for (int b = 0; b < 3; b++)
+                S[(size_t)(ob.cslot + a) * n + ob.mslot + b] += ob.Jc[a] * ob.Jm[b] + ob.Jc[6 + a] * ob.Jm[3 + b];
+          }
+          if (ob.mslot >= 0 && owner(ob.mslot) == t)
+            for (int a = 0; a < 3; a++) {
+              for (int b = a; b < 3; b++) S[(size_t)(ob.mslot + a) * n + ob.mslot + b] += ob.Jm[a] * ob.Jm[b] + ob.Jm[3 + a] * ob.Jm[3 + b];
+              B.rhs[ob.mslot + a] += ob.Jm[a] * ob.r[0] + ob.Jm[3 + a] * ob.r[1];
+            }
+        }
+        const PEnt* ents = pents_data + ent_first[pb];
+        const int ne = ent_count[pb];
+        const double* vg = &vgs[3 * (size_t)pb];
+        for (int j = 0; j < ne; j++) {
+          const PEnt& ej = ents[j];
+          if (owner(ej.slot) == t)
+            for (int a = 0; a < ej.dim; a++) B.rhs[ej.slot + a] -= ej.W[a * 3 + 0] * vg[0] + ej.W[a * 3 + 1] * vg[1] + ej.W[a * 3 + 2] * vg[2];
+          for (int i = 0; i <= j; i++) {
+            const PEnt& ei = ents[i];
+            if (owner(ei.slot) != t) continue;
+            for (int a = 0; a < ei.dim; a++) for (int b = 0; b < ej.dim; b++) {
+              if (i == j && b < a) continue;  // upper triangle only
+              S[(size_t)(ei.slot + a) * n + ej.slot + b] -= ei.W[a * 3 + 0] * ej.Z[0 * ej.dim + b] + ei.W[a * 3 + 1] * ej.Z[1 * ej.dim + b] + ei.W[a * 3 + 2] * ej.Z[2 * ej.dim + b];
+            }
+          }
+        }
+      }
+    }
+  } else {
+  // per eliminated point: chunk elimination
   std::vector<Ent> ents;
   for (int pb = 0; pb < B.n_pt_blocks; pb++) {
     double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
@@ -625,6 +848,8 @@ static bool ba_compute_step(Ba& B, double radius, bool reuse_diagonal, double* m
       }
     }
   }
+  }
+  lap("eliminate: total");
   // rows without an e-block (SchurEliminator::NoEBlockRowsUpdate) and GPS rows
   for (size_t i = B.n_erows; i < B.obs.size(); i++) add_ftf(B.obs[i]);
   for (const GpsRes& g : B.gps) for (int k = 0; k < 3; k++) {
@@ -636,13 +861,16 @@ static bool ba_compute_step(Ba& B, double radius, bool reuse_diagonal, double* m
   std::vector<double> z(B.rhs);
   if (n > 0) {
     for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) S[(size_t)i * n + j] = S[(size_t)j * n + i];
-    if (!dense_cholesky_lower(S, n)) return false;
+    lap("before cholesky");
+    if (!dense_cholesky_lower(S, n, nt)) return false;
+    lap("cholesky");
     dense_cholesky_solve(S, n, z.data());
   }
   // back substitution: y_p = V^-1 sum_rows Jp^T (r - Jc z_c - Jm z_m)
   B.step_c.assign(ncc, 0.0); B.step_m.assign(nmc, 0.0); B.step_p.assign(npc, 0.0);
   for (size_t i = 0; i < ncc; i++) B.step_c[i] = -z[i];
   for (size_t i = 0; i < nmc; i++) B.step_m[i] = -z[mo + i];
+#pragma omp parallel for num_threads(nt) schedule(static, 256) if (nt > 1)
   for (int pb = 0; pb < B.n_pt_blocks; pb++) {
     double y[3] = {0, 0, 0};
     for (int i = B.pt_first[pb]; i < B.pt_first[pb + 1]; i++) {
@@ -660,18 +888,28 @@ static bool ba_compute_step(Ba& B, double radius, bool reuse_diagonal, double* m
   for (double v : B.step_p) if (!std::isfinite(v)) return false;
   // model_cost_change = -(J step)^T (r + J step / 2)
   double mcc = 0.0;
-  for (const Obs& ob : B.obs) {
+  auto mcc_one = [&](const Obs& ob) {
     double m[2] = {0, 0};
     if (ob.cslot >= 0) for (int j = 0; j < 6; j++) { m[0] += ob.Jc[j] * B.step_c[ob.cslot + j]; m[1] += ob.Jc[6 + j] * B.step_c[ob.cslot + j]; }
     if (ob.mslot >= 0) for (int j = 0; j < 3; j++) { m[0] += ob.Jm[j] * B.step_m[ob.mslot - mo + j]; m[1] += ob.Jm[3 + j] * B.step_m[ob.mslot - mo + j]; }
     if (ob.pslot >= 0) for (int j = 0; j < 3; j++) { m[0] += ob.Jp[j] * B.step_p[3 * (size_t)ob.pslot + j]; m[1] += ob.Jp[3 + j] * B.step_p[3 * (size_t)ob.pslot + j]; }
-    mcc -= m[0] * (ob.r[0] + m[0] / 2.0) + m[1] * (ob.r[1] + m[1] / 2.0);
+    return m[0] * (ob.r[0] + m[0] / 2.0) + m[1] * (ob.r[1] + m[1] / 2.0);
+  };
+  if (nt <= 1) {
+    for (const Obs& ob : B.obs) mcc -= mcc_one(ob);
+  } else {
+    B.scratch.resize(B.obs.size());
+    const long no = (long)B.obs.size();
+#pragma omp parallel for num_threads(nt) schedule(static)
+    for (long i = 0; i < no; i++) B.scratch[i] = mcc_one(B.obs[i]);
+    for (long i = 0; i < no; i++) mcc -= B.scratch[i];
   }
   for (const GpsRes& g : B.gps) for (int k = 0; k < 3; k++) {
     const double m = g.J[k] * B.step_c[g.cslot + 3 + k];
     mcc -= m * (g.r[k] + m / 2.0);
   }
   *model_cost_change = mcc;
+  lap("backsub + mcc");
   return true;
 }
 
@@ -705,6 +943,7 @@ ORC_API int orc_ba_solve(msfm_ba_problem* P, const msfm_ba_options* options, msf
   const auto t0 = std::chrono::steady_clock::now();
   Ba B;
   B.P = P; B.opt = *options;
+  B.threads = std::max(1, std::min(options->num_threads, 256));   // Ceres: options.num_threads (optimizer.cc:46, slam_gps.cc:683)
   ba_setup(B);
   const auto t1 = std::chrono::steady_clock::now();
   sum->num_residuals = 2 * (int)B.obs.size() + 3 * (int)B.gps.size();
@@ -1268,6 +1507,8 @@ ORC_API int orc_fundamental_ransac(int n_pairs, const int* off, const float* pt1
 template <typename Acc>
 static void knn2_impl(const float* train, int n_train, const float* query, int n_query, int dim, int* ids,
                       float* sqd) {
+  // queries are independent (the reference loops over them under OpenMP, fine_matching_graph.cc:87)
+#pragma omp parallel for num_threads(g_orc_threads) schedule(static, 16) if (g_orc_threads > 1)
   for (int q = 0; q < n_query; q++) {
     const float* b = query + (size_t)q * dim;
     Acc d0 = std::numeric_limits<Acc>::infinity(), d1 = d0;

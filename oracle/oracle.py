@@ -54,7 +54,40 @@ def lib():
             f.restype = None
         _lib.orc_angle_axis_rotate_point.argtypes = [A.c_double_p] * 3
         _lib.orc_angle_axis_rotate_point.restype = None
+        _lib.orc_set_num_threads.argtypes = [C.c_int]
+        _lib.orc_set_num_threads.restype = None
+        _lib.orc_max_threads.restype = C.c_int
     return _lib
+
+
+def set_num_threads(n):
+    """Host threads of the kNN timing leg (the BA takes `num_threads` from its options).  Results do not depend on it."""
+    lib().orc_set_num_threads(int(n))
+
+
+def host_cores():
+    """Cores this process may run on (the GPU box gives a 1-GPU job a share of the host, not all of it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for f in ("/sys/fs/cgroup/cpu.max",):          # cgroup v2 quota: "<quota> <period>" or "max <period>"
+        try:
+            q, p = open(f).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(q) // int(p)))
+        except Exception:
+            pass
+    try:                                           # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // p))
+    except Exception:
+        pass
+    if os.environ.get("MSFM_BENCH_CORES"):
+        n = max(1, int(os.environ["MSFM_BENCH_CORES"]))
+    return n
 
 
 def default_options(**kw):

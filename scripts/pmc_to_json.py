@@ -59,6 +59,14 @@ def main():
             raw[k.split("(")[0]] = dict(FETCH_SIZE=sum(fetch[k]) / len(fetch[k]), WRITE_SIZE=sum(write.get(k, [0])) / max(1, len(write.get(k, [0]))),
                                         launches=len(fetch[k]))
     res["_raw_counters_per_launch_KB"] = raw
+    # which kernels the counters belong to: bench.py attaches them to a live timing only when its own hash agrees
+    import hashlib, os
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metricsfm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    res["_kernel_source_hash"] = h.hexdigest()[:16]
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v["bytes_per_launch"] for k, v in res.items() if not k.startswith("_")}))
 

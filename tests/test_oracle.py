@@ -238,3 +238,34 @@ def test_fundamental_ransac_gates_and_determinism(oracle):
     z1 = np.ones((50, 2), np.float32)
     Fz, inz, nz, okz = O.fundamental_ransac(np.array([0, 50], np.int32), z1, z1)
     assert okz[0] == 0 and nz[0] == 0 and not Fz.any()
+
+
+def test_threaded_oracle_is_bit_identical_to_one_thread(oracle):
+    """bench.py times the oracle on one core and on all cores.  Threads only split work whose result does not
+    depend on the split - every sum keeps the single-thread order - so the trajectory and the parameters must agree
+    bit for bit, with masks, several intrinsics blocks and GPS rows in play."""
+    sc = scene.make_aerial_scene(40, 3000, seed=81, n_models=3, gps_sigma=0.5)
+    rng = np.random.default_rng(2)
+    cm = (np.arange(sc.n_cams) % 5 != 0).astype(np.uint8)
+    pm = (rng.random(sc.n_points) > 0.1).astype(np.uint8)
+    mk = lambda: A.BaArrays.from_scene(sc, cam_mutable=cm, pt_mutable=pm, gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams))
+    runs = []
+    for nt in (1, 4):
+        a = mk()
+        r = oracle.ba_solve(a, oracle.default_options(max_num_iterations=12, num_threads=nt))
+        runs.append((r, a))
+    (r1, a1), (r4, a4) = runs
+    assert r1["num_iterations"] == r4["num_iterations"] >= 5
+    for f in ("cost", "gradient_max_norm", "step_norm", "relative_decrease", "trust_region_radius"):
+        np.testing.assert_array_equal(r1["iterations"][f], r4["iterations"][f])
+    for f in ("cam_pose", "cam_model", "point"):
+        np.testing.assert_array_equal(getattr(a1, f), getattr(a4, f))
+    # kNN: queries are independent
+    d = [np.random.default_rng(s).uniform(0, 255, (300, 128)).astype(np.float32) for s in (1, 2)]
+    oracle.set_num_threads(1)
+    i1, s1 = oracle.knn2(d[0], d[1])
+    oracle.set_num_threads(4)
+    i4, s4 = oracle.knn2(d[0], d[1])
+    oracle.set_num_threads(1)
+    np.testing.assert_array_equal(i1, i4)
+    np.testing.assert_array_equal(s1, s4)
