@@ -11,9 +11,13 @@
 //   wave keeps its 32 queries as MFMA B fragments in registers for the whole sweep, train
 //   descriptors stream through an XOR-swizzled LDS tile shared by the 4 waves; the running
 //   top-2 per query lives in packed (distance << 8 | row) keys, 4 VALU ops per candidate.
-// General path (any float32 descriptors): exact binary64 brute force, sequential in k —
-//   bit-identical to the oracle's definition; slow, used only when the data is not integral.
+// General path (any float32 descriptors): one f16 MFMA product per term with a rigorous error bound, the four
+//   smallest approximate distances per half-wave lane, exact binary64 re-evaluation of the plausible candidates and a
+//   certificate that nothing outside the lists can win; the rare uncertified query is redone by exact brute force.
+//   Bit-identical to the oracle's definition for every finite input (k_knn2_f16 below).
 #include <algorithm>
+#include <climits>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -40,11 +44,14 @@ struct msfm_descset {
   //   |a-b|^2 = 2 sum (a-128)(127-b) + sum (a-127)^2 + sum (128-b)^2 - 128
   std::vector<DevBuf<signed char>*> ti8, qi8;   // [count][128]
   std::vector<DevBuf<int>*> tcin, tpar, qbeta;  // (alpha>>1)+2^21 ; alpha&1 ; beta
-  // split-bf16 forms for non-integral descriptors: v ~ hi + lo (two bf16 terms, 16 significant bits)
-  std::vector<DevBuf<unsigned short>*> shi, slo;  // [count][128]
-  std::vector<DevBuf<float>*> sn2;                // [count]  |v|^2 (binary64 sum rounded once)
-  std::vector<float> sn2max;                      // per image max |v|^2 (host copy)
-  DevBuf<unsigned> n2max_dev;
+  // f16 forms for non-integral descriptors (made at match time, once the common power-of-two scale is known):
+  // f16(s v), -2 f16(s v), fl32(s^2 |v|^2) and its per-image maximum
+  std::vector<DevBuf<unsigned short>*> th16, qh16;  // [count][128]
+  std::vector<DevBuf<float>*> n2s, rerr;            // [count]  fl32(s^2 |v|^2), |s v - f16(s v)|_2 (rounded up)
+  std::vector<float> n2s_max, rerr_max;             // per image (host copies)
+  std::vector<int> f16_exp;                         // log2 of the scale an image's f16 forms were made with (INT_MIN: none)
+  float vabs_max = 0.f;                             // largest |value| uploaded so far
+  DevBuf<unsigned> vmax_dev, n2smax_dev;            // [1], [2 n_images]: n2s maxima, then rerr maxima
   DevBuf<int> nonint;                    // OR of "not integer in [0,255]" over all uploads
   int h_nonint = 0;
   // bumped by every upload: a match result remembers the generation its device pointer tables were built at and
@@ -54,7 +61,7 @@ struct msfm_descset {
 
 // ---- prep: f32 -> bf16, squared norms, integrality flag -------------------------------
 __global__ __launch_bounds__(256) void k_desc_prep(const float* __restrict__ d, int count, unsigned short* __restrict__ out,
-                                                    float* __restrict__ norm, int* __restrict__ nonint) {
+                                                    float* __restrict__ norm, int* __restrict__ nonint, unsigned* __restrict__ vmax) {
   // one wave per row, lane handles 2 of the 128 values
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= count) return;
@@ -66,9 +73,10 @@ __global__ __launch_bounds__(256) void k_desc_prep(const float* __restrict__ d, 
   o.y = (unsigned short)(__float_as_uint(v.y) >> 16);
   reinterpret_cast<ushort2*>(out + (size_t)row * DIM)[lane] = o;
   float s = v.x * v.x + v.y * v.y;
+  float m = fmaxf(fabsf(v.x), fabsf(v.y));
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) norm[row] = s;
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); m = fmaxf(m, __shfl_xor(m, off, 64)); }
+  if (lane == 0) { norm[row] = s; atomicMax(vmax, __float_as_uint(m)); }
 }
 
 // int8 operands + the per-row integer terms (see msfm_descset).  One wave per row.
@@ -479,76 +487,104 @@ __global__ __launch_bounds__(64) void k_knn2_exact(const PairTaskF* __restrict__
   }
 }
 
-// ---- split-bf16 path for non-integral descriptors ---------------------------------------------
-// v is split into two bf16 terms (hi + lo, 16 significant bits); a.b ~ ah.bh + ah.bl + al.bh on the
-// bf16 MFMA with fp32 accumulation gives every distance to within eps (bound below).  Each query
-// keeps its 4 best approximate candidates; k_rerank evaluates those 4 exactly (binary64, k
-// sequential, the oracle's definition) and accepts the answer only if no candidate outside the
-// shortlist can beat it:  d4_approx - eps > d2_exact.  Queries that fail the test (exact duplicates,
-// near ties) are redone by the exact brute force k_exact_flagged, so the result is exact for every
-// finite input; how many took the slow road is reported in the result object.
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v) {
-  const u32 u = __float_as_uint(v);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);  // finite inputs only
-}
+// ---- certified f16 path for non-integral descriptors --------------------------------------------
+// The reference's extractors hand over non-integral floats (feature_extractor_vl_sift.cpp:202: 512.0F * x, never cast).
+// One f16 MFMA product per term gives every squared distance to within a bound E that follows from the operand
+// rounding (unit roundoff 2^-11), the fp32 accumulation and the rounding of the norms; all operands are scaled by a
+// power of two s (exact) so that the largest |value| of the descriptor set sits in [2^13, 2^14):
+//   v(row) = fl32(s^2 |a|^2) + SHIFT - 2 f16(s a) . f16(s b)          (MFMA, fp32 accumulators)
+//   s^2 |a - b|^2  is in  [v - G - E, v + G' + E],  G = SHIFT - fl32(s^2 |b|^2)
+// SHIFT (one constant per pair) keeps v positive, so the float bit patterns order like unsigned integers and a
+// candidate is the key (bits & ~255) | row-in-window.  Every half-wave lane keeps the FOUR smallest keys of its half of
+// the train rows (med3 chain: 5 VALU operations per candidate).  In the epilogue the two halves of a query exchange
+// their lists, the candidates that can still be among the two nearest are evaluated exactly (binary64, k sequential -
+// the oracle's definition) and the result is accepted only if no row outside the lists can beat it:
+//   min over halves of (4th smallest v) - G - E  >  s^2 * d_second.
+// Queries that fail the test (exact duplicates, near ties) are appended to a list and redone by exact brute force
+// (k_exact_flagged), so the result is exact for every finite input; how many took that road is reported in the
+// result object (msfm_match_result_stats).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void k_desc_prep_split(const float* __restrict__ d, int count, unsigned short* __restrict__ hi,
-                                                          unsigned short* __restrict__ lo, float* __restrict__ n2,
-                                                          unsigned* __restrict__ n2max) {
+__global__ __launch_bounds__(256) void k_desc_prep_f16(const float* __restrict__ d, int count, float scale, unsigned short* __restrict__ th,
+                                                        unsigned short* __restrict__ qh, float* __restrict__ n2s, float* __restrict__ rerr,
+                                                        unsigned* __restrict__ n2smax, unsigned* __restrict__ rerrmax) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= count) return;
   const float2 v = reinterpret_cast<const float2*>(d + (size_t)row * DIM)[lane];
-  ushort2 h, l;
-  h.x = f32_to_bf16_rne(v.x); h.y = f32_to_bf16_rne(v.y);
-  l.x = f32_to_bf16_rne(v.x - __uint_as_float((u32)h.x << 16));
-  l.y = f32_to_bf16_rne(v.y - __uint_as_float((u32)h.y << 16));
-  reinterpret_cast<ushort2*>(hi + (size_t)row * DIM)[lane] = h;
-  reinterpret_cast<ushort2*>(lo + (size_t)row * DIM)[lane] = l;
-  double s = (double)v.x * v.x + (double)v.y * v.y;
+  const float sx = v.x * scale, sy = v.y * scale;     // exact: scale is a power of two (no overflow by its choice)
+  const _Float16 hx = (_Float16)sx, hy = (_Float16)sy;  // round to nearest even
+  const _Float16 qx = (_Float16)(-2.0f * (float)hx), qy = (_Float16)(-2.0f * (float)hy);   // exact doubling (|s v| < 2^14)
+  ushort2 t, q;
+  t.x = __builtin_bit_cast(unsigned short, hx); t.y = __builtin_bit_cast(unsigned short, hy);
+  q.x = __builtin_bit_cast(unsigned short, qx); q.y = __builtin_bit_cast(unsigned short, qy);
+  reinterpret_cast<ushort2*>(th + (size_t)row * DIM)[lane] = t;
+  reinterpret_cast<ushort2*>(qh + (size_t)row * DIM)[lane] = q;
+  double s = (double)sx * sx + (double)sy * sy;
+  // the rounding error this row really carries into the MFMA, |s v - f16(s v)| per element - or |s v| where the matrix
+  // pipe may flush a subnormal f16 operand to zero, whichever is larger
+  auto elem_err = [](float x, _Float16 hx) {
+    const double e = fabs((double)x - (double)(float)hx);
+    return fabsf((float)hx) < 6.103515625e-5f ? fmax(e, fabs((double)x)) : e;
+  };
+  const double ex = elem_err(sx, hx), ey = elem_err(sy, hy);
+  double r2 = ex * ex + ey * ey;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); r2 += __shfl_xor(r2, off, 64); }
   if (lane == 0) {
     const float f = (float)s;
-    n2[row] = f;
-    atomicMax(n2max, __float_as_uint(f));  // non-negative floats order like their bit patterns
+    n2s[row] = f;
+    atomicMax(n2smax, __float_as_uint(f));  // non-negative floats order like their bit patterns
+    const float rr = (float)(sqrt(r2) * 1.000001) + 1e-30f;   // rounded up
+    rerr[row] = rr;
+    atomicMax(rerrmax, __float_as_uint(rr));
   }
 }
 
-struct PairTaskS {
-  const unsigned short *thi, *tlo, *qhi, *qlo;
-  const float *tn2, *qn2;
-  const float *tf32, *qf32;
-  float tn2max;
+struct PairTaskH {
+  const unsigned short* th;   // f16(s a)      [n_train][128]
+  const unsigned short* qh;   // -2 f16(s b)   [n_query][128]
+  const float* tn2s;          // fl32(s^2 |a|^2)
+  const float* qn2s;
+  const float* qre;           // |s b - f16(s b)|_2 of every query row (rounded up)
+  const float* tf32;          // the descriptors as uploaded, for the exact evaluations
+  const float* qf32;
+  float a2max_s;              // max of tn2s over the train image
+  float remax_a;              // max rounding-error norm over the train image
+  float shift;                // SHIFT
+  float s2;                   // s^2
   int n_train, n_query, out_off;
+  int group, group_off;       // pairs with the same train image form a group; its flagged queries share one list
 };
 
-#define QPS 128  // queries per workgroup in the split kernel (4 waves x 32)
+// Error bound E (scaled units) of one approximate distance v against the exact s^2 |a - b|^2 (derivation: DESIGN.md §4):
+//   operands: |sum (f16(s a) f16(s b) - s^2 a b)| <= r_a |f16(s b)| + |s a| r_b <= r_a (|s b| + r_b) + |s a| r_b by
+//   Cauchy-Schwarz, with r the 2-norm of a row's ACTUAL rounding-error vector (computed at preparation time; for an
+//   unlisted train row only the image maximum is known); twice that in the distance;
+//   accumulation: fp32 sums of <= 137 terms, counted twice: 1.7e-5 (2.02 |s a||s b| + |C|), C the accumulator start;
+//   the roundings of the two norms, of C and of the key truncation's upper end: 1.2e-7 (...); 2 % slack on top.
+__host__ __device__ __forceinline__ double f16_error_bound(double a2max, double ramax, double b2, double rb, double shift) {
+  const double na = sqrt(a2max), nb = sqrt(b2);
+  const double dot = ramax * (nb + rb) + na * rb;
+  return 1.02 * (2.0 * dot + 1.7e-5 * (2.02 * na * nb + a2max + shift) + 1.2e-7 * (a2max + b2 + shift)) + 1e-5;
+}
 
-__device__ __forceinline__ void load_query_frags_split(const unsigned short* qp, int h, bf16x8* bq) {
-#pragma unroll
-  for (int ks = 0; ks < 8; ks++) {
-    const uint4 raw = *reinterpret_cast<const uint4*>(qp + ks * 16 + h * 8);
-    u32 w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      // bf16 x -> -2x: exponent + 1, sign flipped; zero / subnormal -> 0
-      u32 a = w[j] & 0xffffu, b = w[j] >> 16;
-      a = (a & 0x7F80u) ? (((a + 0x0080u) ^ 0x8000u) & 0xffffu) : 0u;
-      b = (b & 0x7F80u) ? (((b + 0x0080u) ^ 0x8000u) & 0xffffu) : 0u;
-      w[j] = a | (b << 16);
-    }
-    bq[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+// exact distance, the oracle's definition: binary64, k sequential, one fma per term
+__device__ __forceinline__ double exact_sqdist(const float* __restrict__ a, const float* __restrict__ b) {
+  double s = 0.0;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll 4
+  for (int k = 0; k < DIM / 4; k++) {
+    const float4 x = a4[k], y = b4[k];
+    double d = (double)x.x - (double)y.x; s = fma(d, d, s);
+    d = (double)x.y - (double)y.y; s = fma(d, d, s);
+    d = (double)x.z - (double)y.z; s = fma(d, d, s);
+    d = (double)x.w - (double)y.w; s = fma(d, d, s);
   }
+  return s;
 }
 
-// sorted insert of key x into k0 <= k1 <= k2 <= k3
-__device__ __forceinline__ void top4_insert(u32& k0, u32& k1, u32& k2, u32& k3, u32 x) {
-  u32 t = max(k0, x); k0 = min(k0, x);
-  u32 t2 = max(k1, t); k1 = min(k1, t);
-  u32 t3 = max(k2, t2); k2 = min(k2, t2);
-  k3 = min(k3, t3);
-}
-// (value bits, index) lists, 4 entries, ordered by (value, index)
+// sorted insert of (value bits, index) into a 4-entry list ordered by (value, index)
 __device__ __forceinline__ void list4_insert(u32 (&v)[4], int (&id)[4], u32 x, int xi) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -561,208 +597,348 @@ __device__ __forceinline__ void list4_insert(u32 (&v)[4], int (&id)[4], u32 x, i
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_knn2_split(const PairTaskS* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
-                                                        int* __restrict__ cand /*[q][4]*/, float* __restrict__ d4a /*[q]*/) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds_hi[2 * TT * 256];
-  __shared__ __attribute__((aligned(16))) unsigned char lds_lo[2 * TT * 256];
-  __shared__ __attribute__((aligned(16))) float lds_n[2 * TT];
-  int lo_ = 0, hi_ = n_pairs - 1;
-  const int bid = blockIdx.x;
-  while (lo_ < hi_) {
-    const int mid = (lo_ + hi_ + 1) >> 1;
-    if (tile_first[mid] <= bid) lo_ = mid; else hi_ = mid - 1;
+// merge (e0, j0) <= (e1, j1) into (d0, i0) <= (d1, i1); ties -> lower index
+__device__ __forceinline__ void merge_top2(double& d0, int& i0, double& d1, int& i1, double e0, int j0, double e1, int j1) {
+  if (e0 < d0 || (e0 == d0 && j0 < i0)) {
+    const bool second_is_mine = d0 < e1 || (d0 == e1 && i0 < j1);
+    d1 = second_is_mine ? d0 : e1; i1 = second_is_mine ? i0 : j1;
+    d0 = e0; i0 = j0;
+  } else if (e0 < d1 || (e0 == d1 && j0 < i1)) {
+    d1 = e0; i1 = j0;
   }
-  const int pair = lo_;
-  const PairTaskS T = tasks[pair];
-  const int q0 = (bid - tile_first[pair]) * QPS;
+}
+
+// The four smallest keys of a finished 256-row window (sorted, rows base + (key & 255)) merged into the lane's sorted list
+// over all rows so far: one bitonic step (min of g[i], w[3-i]) leaves the four smallest of the eight, four
+// compare-exchanges sort them.  Entries carry their window base beside the key; equal keys of different windows may land
+// in either order (their values agree to the key's resolution, which is all the certificate uses).
+__device__ __forceinline__ void merge_window4(u32 (&g)[4], int (&gb)[4], u32 w0, u32 w1, u32 w2, u32 w3, int wb) {
+  const u32 w[4] = {w3, w2, w1, w0};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const bool t = w[i] < g[i];
+    g[i] = t ? w[i] : g[i];
+    gb[i] = t ? wb : gb[i];
+  }
+#define MSFM_CE(a, b) { const bool t = g[b] < g[a]; const u32 ka = g[a], kb = g[b]; const int ba = gb[a], bb = gb[b]; \
+                        g[a] = t ? kb : ka; g[b] = t ? ka : kb; gb[a] = t ? bb : ba; gb[b] = t ? ba : bb; }
+  MSFM_CE(0, 2) MSFM_CE(1, 3) MSFM_CE(0, 1) MSFM_CE(2, 3)
+#undef MSFM_CE
+}
+
+// Epilogue of one query (two lanes: r, r + 32, each with the list of its half of the train rows).
+__device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, int q, bool qvalid, int h, const u32 (&gk)[4], const int (&gbase)[4],
+                                                 float ratio_good, float ratio_all, int32_t* __restrict__ code, int* __restrict__ ids,
+                                                 float* __restrict__ sqd, int* __restrict__ n_all, int* __restrict__ n_good,
+                                                 int* __restrict__ flagged, int* __restrict__ nf_group, int* __restrict__ n_flagged) {
+  u32 gv[4], ov[4];
+  int gi[4], oi[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {   // key -> (value bits, train row); an empty slot stays out of range
+    gv[j] = gk[j] & 0xffffff00u;
+    gi[j] = gk[j] == 0xffffffffu ? 0x7fffffff : gbase[j] + (int)(gk[j] & 255u);
+    ov[j] = __shfl_xor(gv[j], 32, 64);
+    oi[j] = __shfl_xor(gi[j], 32, 64);
+  }
+  const double inf = __builtin_inf();
+  const double b2 = (double)T.qn2s[qvalid ? q : 0], shift = (double)T.shift;
+  const double E = f16_error_bound((double)T.a2max_s, (double)T.remax_a, b2, (double)T.qre[qvalid ? q : 0], shift);
+  const double G = shift - b2;
+  // scaled-distance interval of a listed row: [val - G - E, val (1 + 2^-15) - G + E]  (val = key with its low byte cleared)
+  double h1 = inf, h2 = inf;  // the two smallest upper bounds over both lists
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u32 kv = j < 4 ? gv[j] : ov[j - 4];
+    const int ki = j < 4 ? gi[j] : oi[j - 4];
+    if (ki < T.n_train) {
+      const double hi = (double)__uint_as_float(kv) * (1.0 + 3.0517578125e-5) - G + E;
+      if (hi < h1) { h2 = h1; h1 = hi; } else if (hi < h2) h2 = hi;
+    }
+  }
+  const float* qv = T.qf32 + (size_t)(qvalid ? q : 0) * DIM;
+  double d0 = inf, d1 = inf;
+  int i0 = 0x7fffffff, i1 = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const bool eval = qvalid && gi[j] < T.n_train && ((double)__uint_as_float(gv[j]) - G - E) <= h2;
+    if (eval) {
+      const double s = exact_sqdist(T.tf32 + (size_t)gi[j] * DIM, qv);
+      merge_top2(d0, i0, d1, i1, s, gi[j], inf, 0x7fffffff);
+    }
+  }
+  {
+    const double e0 = __shfl_xor(d0, 32, 64), e1 = __shfl_xor(d1, 32, 64);
+    const int j0 = __shfl_xor(i0, 32, 64), j1 = __shfl_xor(i1, 32, 64);
+    merge_top2(d0, i0, d1, i1, e0, j0, e1, j1);
+  }
+  if (h != 0 || !qvalid) return;
+  // rows outside the two lists: v >= the 4th key of their half
+  const double b_mine = gi[3] < T.n_train ? (double)__uint_as_float(gv[3]) : inf;
+  const double b_other = oi[3] < T.n_train ? (double)__uint_as_float(ov[3]) : inf;
+  const double bound = fmin(b_mine, b_other) - G - E;
+  const size_t o = (size_t)T.out_off + q;
+  if (!(bound > d1 * (double)T.s2 * (1.0 + 1e-12))) {   // cannot certify: exact brute force later, filed under the train image's group
+    flagged[T.group_off + atomicAdd(&nf_group[T.group], 1)] = (int)o;
+    atomicAdd(n_flagged, 1);
+    return;
+  }
+  const float f0 = (float)d0, f1 = (float)d1;
+  if (ids) { ids[2 * o] = i0; ids[2 * o + 1] = i1; sqd[2 * o] = f0; sqd[2 * o + 1] = f1; }
+  code[o] = ratio_code(f0, f1, i0, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
+}
+
+// 1 workgroup = 4 waves = 256 queries of one pair (two query sets of 32 per wave, every A fragment feeds two MFMAs);
+// train tiles of 64 rows double-buffered through XOR-swizzled LDS, as the integer kernels.
+__global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+                                                      float ratio_good, float ratio_all, int32_t* __restrict__ code, int* __restrict__ ids,
+                                                      float* __restrict__ sqd, int* __restrict__ n_all, int* __restrict__ n_good,
+                                                      int* __restrict__ flagged, int* __restrict__ nf_group, int* __restrict__ n_flagged,
+                                                      int debug_mode) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[2][TT * 256];
+  __shared__ __attribute__((aligned(16))) float lds_n[2][TT];
+  int lo = 0, hi = n_pairs - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_first[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const int pair = lo;
+  const PairTaskH T = tasks[pair];
+  const int q0 = (bid - tile_first[pair]) * QPB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int q = q0 + wave * 32 + r;
-  const bool qvalid = q < T.n_query;
-  bf16x8 bh[8], bl[8];
-  load_query_frags_split(T.qhi + (size_t)(qvalid ? q : 0) * DIM, h, bh);
-  load_query_frags_split(T.qlo + (size_t)(qvalid ? q : 0) * DIM, h, bl);
-  const float b2 = T.qn2[qvalid ? q : 0];
-  // every approximate distance is within eps of the exact one; shifting by 2 eps keeps them positive
-  const float eps = 2.44140625e-4f * sqrtf(T.tn2max * b2) + 4.76837158e-7f * (T.tn2max + b2) + 1e-30f;
-  const float shift = b2 + 2.0f * eps;
-  u32 k0 = 0xffffffffu, k1 = 0xffffffffu, k2 = 0xffffffffu, k3 = 0xffffffffu;
-  u32 gv[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-  int gi[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  const int qa = q0 + wave * 64 + r, qb = qa + 32;
+  const bool va = qa < T.n_query, vb = qb < T.n_query;
+  f16x8 bqa[8], bqb[8];
+  {
+    const unsigned short* pa = T.qh + (size_t)(va ? qa : 0) * DIM;
+    const unsigned short* pb = T.qh + (size_t)(vb ? qb : 0) * DIM;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      bqa[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(pa + ks * 16 + h * 8));
+      bqb[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(pb + ks * 16 + h * 8));
+    }
+  }
+  // window keys (4 smallest of the current 256-row window) and the lane's lists over all rows so far
+  u32 a0 = 0xffffffffu, a1 = 0xffffffffu, a2 = 0xffffffffu, a3 = 0xffffffffu;
+  u32 b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu, b3 = 0xffffffffu;
+  u32 gva[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, gvb[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  int gia[4] = {0, 0, 0, 0}, gib[4] = {0, 0, 0, 0};   // window bases of the list entries
   const int n_tiles = (T.n_train + TT - 1) / TT;
-  uint4 sh[4], sl[4];
+  uint4 stage[4];
   float stage_n = 0.f;
   auto fetch = [&](int tile) {
     const int t0 = tile * TT;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      sh[i] = make_uint4(0, 0, 0, 0); sl[i] = make_uint4(0, 0, 0, 0);
-      if (t0 + row < T.n_train) {
-        sh[i] = *reinterpret_cast<const uint4*>(T.thi + (size_t)(t0 + row) * DIM + ch * 8);
-        sl[i] = *reinterpret_cast<const uint4*>(T.tlo + (size_t)(t0 + row) * DIM + ch * 8);
-      }
+      stage[i] = make_uint4(0, 0, 0, 0);
+      if (t0 + row < T.n_train) stage[i] = *reinterpret_cast<const uint4*>(T.th + (size_t)(t0 + row) * DIM + ch * 8);
     }
-    if (tid < TT) stage_n = (t0 + tid < T.n_train) ? T.tn2[t0 + tid] : 3.0e38f;  // padding rows lose every comparison
+    if (tid < TT) stage_n = (t0 + tid < T.n_train) ? T.tn2s[t0 + tid] + T.shift : 3.0e38f;  // padding rows lose every comparison
   };
   auto commit = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      const int off = buf * TT * 256 + row * 256 + ((ch ^ (row & 15)) << 4);
-      *reinterpret_cast<uint4*>(lds_hi + off) = sh[i];
-      *reinterpret_cast<uint4*>(lds_lo + off) = sl[i];
+      *reinterpret_cast<uint4*>(&lds_a[buf][row * 256 + ((ch ^ (row & 15)) << 4)]) = stage[i];
     }
-    if (tid < TT) lds_n[buf * TT + tid] = stage_n;
+    if (tid < TT) lds_n[buf][tid] = stage_n;
   };
+  u32 keymask;
+  asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keymask));
   fetch(0);
   commit(0);
   __syncthreads();
   int cur = 0;
   for (int tile = 0; tile < n_tiles; tile++) {
     if (tile + 1 < n_tiles) fetch(tile + 1);
+    const unsigned char* la = lds_a[cur];
+    const float* ln = lds_n[cur];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-      f32x16 acc;
+      f32x16 acca, accb;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        const f32x4 nv = *reinterpret_cast<const f32x4*>(&lds_n[cur * TT + st * 32 + 8 * g + 4 * h]);
-        acc[4 * g + 0] = nv.x; acc[4 * g + 1] = nv.y; acc[4 * g + 2] = nv.z; acc[4 * g + 3] = nv.w;
+        const f32x4 nv = *reinterpret_cast<const f32x4*>(&ln[st * 32 + 8 * g + 4 * h]);
+        acca[4 * g + 0] = nv.x; acca[4 * g + 1] = nv.y; acca[4 * g + 2] = nv.z; acca[4 * g + 3] = nv.w;
       }
+      accb = acca;
       const int row = st * 32 + r;
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         const int ch = 2 * ks + h;
-        const int off = cur * TT * 256 + row * 256 + ((ch ^ (row & 15)) << 4);
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(lds_hi + off);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(lds_lo + off);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
+        const f16x8 a = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(la + row * 256 + ((ch ^ (row & 15)) << 4)));
+        acca = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqa[ks], acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqb[ks], accb, 0, 0, 0);
       }
       const int wbase = ((tile & 3) * 2 + st) * 32;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
-        const float v = fmaxf(acc[reg] + shift, 0.0f);  // > 0 whenever eps is a valid bound; the clamp only guards NaN-free ordering
-        const u32 key = (__float_as_uint(v) & 0xffffff00u) | (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
-        top4_insert(k0, k1, k2, k3, key);
+        const u32 idx = (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
+        // one v_and_or_b32 per key: the mask sits in a VGPR (a VOP3 takes one scalar / literal operand only).  The
+        // accumulators must be read by an instruction the compiler sees: it places the MFMA -> VALU wait states
+        const u32 ka = (__float_as_uint(acca[reg]) & keymask) | idx;
+        const u32 kb = (__float_as_uint(accb[reg]) & keymask) | idx;
+        a3 = umed3(a2, a3, ka); a2 = umed3(a1, a2, ka); a1 = umed3(a0, a1, ka); a0 = min(a0, ka);
+        b3 = umed3(b2, b3, kb); b2 = umed3(b1, b2, kb); b1 = umed3(b0, b1, kb); b0 = min(b0, kb);
       }
     }
     if ((tile & 3) == 3 || tile == n_tiles - 1) {
       const int base = (tile & ~3) * TT + 4 * h;
-      const u32 ks4[4] = {k0, k1, k2, k3};
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (ks4[j] != 0xffffffffu) list4_insert(gv, gi, ks4[j] & 0xffffff00u, base + (int)(ks4[j] & 255u));
-      k0 = k1 = k2 = k3 = 0xffffffffu;
+      merge_window4(gva, gia, a0, a1, a2, a3, base);
+      merge_window4(gvb, gib, b0, b1, b2, b3, base);
+      a0 = a1 = a2 = a3 = 0xffffffffu;
+      b0 = b1 = b2 = b3 = 0xffffffffu;
     }
     if (tile + 1 < n_tiles) commit(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
-  // merge the two lane halves of each query
-  {
-    u32 pv[4]; int pi[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { pv[j] = __shfl_xor(gv[j], 32, 64); pi[j] = __shfl_xor(gi[j], 32, 64); }
-#pragma unroll
-    for (int j = 0; j < 4; j++) list4_insert(gv, gi, pv[j], pi[j]);
+  if (debug_mode == 1) {   // timing experiment: main loop only
+    if (va && h == 0) code[(size_t)T.out_off + qa] = (int)gva[0] + gia[1];
+    if (vb && h == 0) code[(size_t)T.out_off + qb] = (int)gvb[0] + gib[1];
+    return;
   }
-  if (h == 0 && qvalid) {
-    const size_t o = (size_t)T.out_off + q;
-#pragma unroll
-    for (int j = 0; j < 4; j++) cand[4 * o + j] = (gv[j] == 0xffffffffu || gi[j] >= T.n_train) ? -1 : gi[j];  // padding rows are not candidates
-    // approximate distance of the 4th candidate (lower end of its truncation bucket), un-shifted
-    d4a[o] = (gv[3] == 0xffffffffu) ? 3.0e38f : __uint_as_float(gv[3]) - 2.0f * eps;  // key value = approx distance + 2 eps
-  }
+  finish_query_f16(T, pair, qa, va, h, gva, gia, ratio_good, ratio_all, code, ids, sqd, n_all, n_good, flagged, nf_group, n_flagged);
+  finish_query_f16(T, pair, qb, vb, h, gvb, gib, ratio_good, ratio_all, code, ids, sqd, n_all, n_good, flagged, nf_group, n_flagged);
 }
 
-// exact distance, the oracle's definition: binary64, k sequential, one fma per term
-__device__ __forceinline__ double exact_sqdist(const float* __restrict__ a, const float* __restrict__ b) {
-  double s = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < DIM; k++) {
-    const double d = (double)a[k] - (double)b[k];
-    s = fma(d, d, s);
-  }
-  return s;
-}
-
-__global__ __launch_bounds__(256) void k_rerank(const PairTaskS* __restrict__ tasks, const int* __restrict__ qpair /*[total_q]*/,
-                                                 long total_q, const int* __restrict__ cand, const float* __restrict__ d4a,
-                                                 int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ flagged,
-                                                 int* __restrict__ n_flagged) {
-  const long o = (long)blockIdx.x * 256 + threadIdx.x;
-  if (o >= total_q) return;
-  const int pair = qpair[o];
-  const PairTaskS T = tasks[pair];
-  const int q = (int)(o - T.out_off);
-  const float* qv = T.qf32 + (size_t)q * DIM;
-  double d0 = __builtin_inf(), d1 = __builtin_inf();
-  int i0 = -1, i1 = -1;
-  for (int j = 0; j < 4; j++) {
-    const int t = cand[4 * o + j];
-    if (t < 0) continue;
-    const double s = exact_sqdist(T.tf32 + (size_t)t * DIM, qv);
-    if (s < d0 || (s == d0 && t < i0)) { d1 = d0; i1 = i0; d0 = s; i0 = t; }
-    else if (s < d1 || (s == d1 && t < i1)) { d1 = s; i1 = t; }
-  }
-  ids[2 * o] = i0; ids[2 * o + 1] = i1;
-  sqd[2 * o] = (float)d0; sqd[2 * o + 1] = (float)d1;
-  if (T.n_train > 4) {
-    // can a row outside the shortlist beat the second best?  Its exact distance is at least
-    // d4_approx - eps (eps: split-bf16 products dropped, fp32 accumulation, key truncation).
-    const float b2 = T.qn2[q];
-    const double eps = 2.44140625e-4 * sqrt((double)T.tn2max * b2) + 4.76837158e-7 * ((double)T.tn2max + b2) + 1e-30;
-    const double d4 = (double)d4a[o];
-    // (d4a is the lower end of the 4th key's truncation bucket, so the dropped mantissa bits are already on the safe side;
-    //  the 2^-22 |d4| term covers the fp32 rounding of the shift itself)
-    const double bound = d4 - eps - 2.4e-7 * fabs(d4);
-    if (!(bound > d1)) flagged[atomicAdd(n_flagged, 1)] = (int)o;
-  }
-}
-
-// exact brute force for the queries the shortlist could not certify: one wave per flagged query
-__global__ __launch_bounds__(64) void k_exact_flagged(const PairTaskS* __restrict__ tasks, const int* __restrict__ qpair,
-                                                       const int* __restrict__ flagged, const int* __restrict__ n_flagged,
-                                                       int* __restrict__ ids, float* __restrict__ sqd) {
-  const int nf = *n_flagged, lane = threadIdx.x;
-  for (int f = blockIdx.x; f < nf; f += gridDim.x) {
-    const long o = flagged[f];
-    const PairTaskS T = tasks[qpair[o]];
-    const int q = (int)(o - T.out_off);
-    const float* qv = T.qf32 + (size_t)q * DIM;
-    double d0 = __builtin_inf(), d1 = __builtin_inf();
-    int i0 = 0x7fffffff, i1 = 0x7fffffff;
-    for (int t = lane; t < T.n_train; t += 64) {
-      const double s = exact_sqdist(T.tf32 + (size_t)t * DIM, qv);
-      if (s < d0) { d1 = d0; i1 = i0; d0 = s; i0 = t; }
-      else if (s < d1) { d1 = s; i1 = t; }
+// Exact brute force for the queries the lists could not certify.  The f16 kernel files every such query under the group
+// of its train image (consecutive pairs with the same idx1 - the reference's loop order, fine_matching_graph.cc:58,87 -
+// share one list), so one workgroup per group takes them SIXTEEN at a time against each staged block of train rows: the
+// 2 MB train image is read once per batch, not once per query.
+// Phase 1 sweeps all train rows in binary32 (64 rows at a time, transposed through LDS: coalesced global reads, every
+// lane walks its own row against four queries of its wave, whose values arrive through the scalar cache): d32 is within
+// a relative 1.6e-5 of the exact value (130 roundings of 2^-24 on a sum of squares); each lane keeps its four smallest
+// per query.  Phase 2 (one wave = four queries): with g1 the second smallest d32 of the whole image, only rows with
+// d32 <= g1 (1 + 3.3e-5) can be among the two nearest; those few are evaluated by the oracle's definition (binary64, k
+// sequential).  A query for which some lane's four slots all qualify (many duplicates) goes through the plain binary64
+// sweep instead.  Writes the final (ids, sqdists), code and counts of the flagged queries.
+#define XROW 132   // LDS row stride in floats: 16-byte aligned rows, conflict-free b128 reads across 16 lanes
+#define XQ 16      // flagged queries per batch (4 per wave)
+__global__ __launch_bounds__(256) void k_exact_flagged(const PairTaskH* __restrict__ tasks, const int* __restrict__ group_first /*[n_groups+1]*/,
+                                                        const int* __restrict__ pair_off /*[n_pairs+1]*/, const int* __restrict__ flagged,
+                                                        const int* __restrict__ nf_group, float ratio_good, float ratio_all,
+                                                        int32_t* __restrict__ code, int* __restrict__ ids, float* __restrict__ sqd,
+                                                        int* __restrict__ n_all, int* __restrict__ n_good) {
+  __shared__ __attribute__((aligned(16))) float rows[64 * XROW];
+  // gridDim.y workgroups share a group: workgroup y takes batches y, y + gridDim.y, ...
+  const int group = blockIdx.x;
+  const int nf = nf_group[group];
+  if ((int)blockIdx.y * XQ >= nf) return;
+  const int p_first = group_first[group], p_last = group_first[group + 1] - 1;
+  const PairTaskH T = tasks[p_first];   // train side (tf32, n_train) and group_off are the same for every pair of the group
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double inf = __builtin_inf();
+  for (int f0 = (int)blockIdx.y * XQ; f0 < nf; f0 += (int)gridDim.y * XQ) {
+    const int nq = min(XQ, nf - f0);
+    // the four queries of this wave: wave-uniform row pointers, so their values arrive through the scalar cache and feed
+    // the vector instructions as SGPR operands (staging them in LDS made the kernel LDS-bandwidth bound)
+    const float* qp[4];
+    int qo[4], qpair[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int slot = min(4 * wave + j, nq - 1);
+      const int oq = __builtin_amdgcn_readfirstlane(flagged[T.group_off + f0 + slot]);
+      int lo = p_first, hi = p_last;   // pair of flat query offset oq
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pair_off[mid] <= oq) lo = mid; else hi = mid - 1;
+      }
+      lo = __builtin_amdgcn_readfirstlane(lo);
+      qo[j] = oq;
+      qpair[j] = lo;
+      qp[j] = tasks[lo].qf32 + (size_t)(oq - pair_off[lo]) * DIM;
     }
+    u32 lv[4][4];
+    int li[4][4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double e0 = __shfl_xor(d0, off, 64), e1 = __shfl_xor(d1, off, 64);
-      const int j0 = __shfl_xor(i0, off, 64), j1 = __shfl_xor(i1, off, 64);
-      // merge two sorted pairs, ties -> lower index
-      if (e0 < d0 || (e0 == d0 && j0 < i0)) {
-        const bool second_is_mine = d0 < e1 || (d0 == e1 && i0 < j1);
-        d1 = second_is_mine ? d0 : e1; i1 = second_is_mine ? i0 : j1;
-        d0 = e0; i0 = j0;
-      } else if (e0 < d1 || (e0 == d1 && j0 < i1)) {
-        d1 = e0; i1 = j0;
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) { lv[j][k] = 0xffffffffu; li[j][k] = 0x7fffffff; }
+    for (int t0 = 0; t0 < T.n_train; t0 += 64) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int e = tid + 256 * i, row = e >> 5, c4 = e & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 + row < T.n_train) v = *reinterpret_cast<const float4*>(T.tf32 + (size_t)(t0 + row) * DIM + 4 * c4);
+        *reinterpret_cast<float4*>(&rows[row * XROW + 4 * c4]) = v;
+      }
+      __syncthreads();
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < DIM / 4; k++) {
+        const float4 x = *reinterpret_cast<const float4*>(&rows[lane * XROW + 4 * k]);
+        // constant address space + wave-uniform address = s_load_dwordx4 (the descriptors are never written by this kernel)
+        typedef const f32x4 __attribute__((address_space(4)))* cf4p;
+        const f32x4 y0 = ((cf4p)(uintptr_t)qp[0])[k];
+        const f32x4 y1 = ((cf4p)(uintptr_t)qp[1])[k];
+        const f32x4 y2 = ((cf4p)(uintptr_t)qp[2])[k];
+        const f32x4 y3 = ((cf4p)(uintptr_t)qp[3])[k];
+        float d;
+        d = x.x - y0.x; s0 = fmaf(d, d, s0); d = x.y - y0.y; s0 = fmaf(d, d, s0); d = x.z - y0.z; s0 = fmaf(d, d, s0); d = x.w - y0.w; s0 = fmaf(d, d, s0);
+        d = x.x - y1.x; s1 = fmaf(d, d, s1); d = x.y - y1.y; s1 = fmaf(d, d, s1); d = x.z - y1.z; s1 = fmaf(d, d, s1); d = x.w - y1.w; s1 = fmaf(d, d, s1);
+        d = x.x - y2.x; s2 = fmaf(d, d, s2); d = x.y - y2.y; s2 = fmaf(d, d, s2); d = x.z - y2.z; s2 = fmaf(d, d, s2); d = x.w - y2.w; s2 = fmaf(d, d, s2);
+        d = x.x - y3.x; s3 = fmaf(d, d, s3); d = x.y - y3.y; s3 = fmaf(d, d, s3); d = x.z - y3.z; s3 = fmaf(d, d, s3); d = x.w - y3.w; s3 = fmaf(d, d, s3);
+      }
+      if (t0 + lane < T.n_train) {
+        const float sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const u32 sb = (sv[j] == sv[j]) ? __float_as_uint(sv[j]) : 0u;   // a NaN (inf - inf) qualifies for the exact evaluation
+          if (sb < lv[j][3] || (sb == lv[j][3] && t0 + lane < li[j][3])) list4_insert(lv[j], li[j], sb, t0 + lane);
+        }
       }
     }
-    if (lane == 0) { ids[2 * o] = i0; ids[2 * o + 1] = i1; sqd[2 * o] = (float)d0; sqd[2 * o + 1] = (float)d1; }
+    // phase 2: wave w finishes queries 4w .. 4w+3 of the batch
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int slot = 4 * wave + j;
+      if (slot >= nq) break;   // wave-uniform
+      const int o = qo[j], pair = qpair[j];
+      const float* qv = qp[j];
+      float g0 = __uint_as_float(lv[j][0] == 0xffffffffu ? 0x7f800000u : lv[j][0]);
+      float g1 = __uint_as_float(lv[j][1] == 0xffffffffu ? 0x7f800000u : lv[j][1]);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float e0 = __shfl_xor(g0, off, 64), e1 = __shfl_xor(g1, off, 64);
+        const float n0 = fminf(g0, e0);
+        g1 = fminf(fmaxf(g0, e0), fminf(g1, e1));
+        g0 = n0;
+      }
+      const float tau = g1 * 1.000033f + 1e-37f;   // inf stays inf; the absolute term covers sums in the subnormal range
+      const bool overflow = li[j][3] < T.n_train && __uint_as_float(lv[j][3]) <= tau;
+      double d0 = inf, d1 = inf;
+      int i0 = 0x7fffffff, i1 = 0x7fffffff;
+      if (__any(overflow)) {
+        for (int t = lane; t < T.n_train; t += 64) {   // plain binary64 sweep (many rows tie within the binary32 resolution)
+          const double sx = exact_sqdist(T.tf32 + (size_t)t * DIM, qv);
+          merge_top2(d0, i0, d1, i1, sx, t, inf, 0x7fffffff);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          if (li[j][c] < T.n_train && __uint_as_float(lv[j][c]) <= tau) {
+            const double sx = exact_sqdist(T.tf32 + (size_t)li[j][c] * DIM, qv);
+            merge_top2(d0, i0, d1, i1, sx, li[j][c], inf, 0x7fffffff);
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double e0 = __shfl_xor(d0, off, 64), e1 = __shfl_xor(d1, off, 64);
+        const int j0 = __shfl_xor(i0, off, 64), j1 = __shfl_xor(i1, off, 64);
+        merge_top2(d0, i0, d1, i1, e0, j0, e1, j1);
+      }
+      if (lane == 0) {
+        const float f0v = (float)d0, f1v = (float)d1;
+        if (ids) { ids[2 * (size_t)o] = i0; ids[2 * (size_t)o + 1] = i1; sqd[2 * (size_t)o] = f0v; sqd[2 * (size_t)o + 1] = f1v; }
+        code[o] = ratio_code(f0v, f1v, i0, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
+      }
+    }
   }
-}
-
-// ratio tests on final (ids, sqd): fine_matching_graph.cc:116-133
-__global__ __launch_bounds__(256) void k_codes(const int* __restrict__ qpair, long total_q, const int* __restrict__ ids,
-                                                const float* __restrict__ sqd, float ratio_good, float ratio_all,
-                                                int32_t* __restrict__ code, int* __restrict__ n_all, int* __restrict__ n_good) {
-  const long o = (long)blockIdx.x * 256 + threadIdx.x;
-  if (o >= total_q) return;
-  code[o] = ratio_code(sqd[2 * o], sqd[2 * o + 1], ids[2 * o], ratio_good, ratio_all, &n_all[qpair[o]], &n_good[qpair[o]]);
 }
 
 // ---- host ---------------------------------------------------------------------------------
@@ -775,9 +951,12 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
   ctx->children++;
   s->count.assign(n_images, 0);
   s->f32.assign(n_images, nullptr); s->bf16.assign(n_images, nullptr); s->norm.assign(n_images, nullptr);
-  s->shi.assign(n_images, nullptr); s->slo.assign(n_images, nullptr); s->sn2.assign(n_images, nullptr); s->sn2max.assign(n_images, 0.f);
+  s->th16.assign(n_images, nullptr); s->qh16.assign(n_images, nullptr); s->n2s.assign(n_images, nullptr); s->n2s_max.assign(n_images, 0.f);
+  s->rerr.assign(n_images, nullptr); s->rerr_max.assign(n_images, 0.f);
+  s->f16_exp.assign(n_images, INT_MIN);
   s->ti8.assign(n_images, nullptr); s->qi8.assign(n_images, nullptr); s->tcin.assign(n_images, nullptr); s->tpar.assign(n_images, nullptr); s->qbeta.assign(n_images, nullptr);
-  if (s->n2max_dev.alloc(1) != hipSuccess || s->nonint.alloc(1) != hipSuccess || hipMemsetAsync(s->nonint.p, 0, sizeof(int), ctx->stream) != hipSuccess) {
+  if (s->vmax_dev.alloc(1) != hipSuccess || s->n2smax_dev.alloc(2 * (size_t)n_images) != hipSuccess || s->nonint.alloc(1) != hipSuccess ||
+      hipMemsetAsync(s->nonint.p, 0, sizeof(int), ctx->stream) != hipSuccess || hipMemsetAsync(s->vmax_dev.p, 0, sizeof(unsigned), ctx->stream) != hipSuccess) {
     delete s;
     return msfm_set_error(ctx, MSFM_E_NOMEM, "descset alloc");
   }
@@ -793,9 +972,10 @@ MSFM_API void msfm_descset_destroy(msfm_descset* s) {
   for (auto p : s->f32) delete p;
   for (auto p : s->bf16) delete p;
   for (auto p : s->norm) delete p;
-  for (auto p : s->shi) delete p;
-  for (auto p : s->slo) delete p;
-  for (auto p : s->sn2) delete p;
+  for (auto p : s->th16) delete p;
+  for (auto p : s->qh16) delete p;
+  for (auto p : s->n2s) delete p;
+  for (auto p : s->rerr) delete p;
   for (auto p : s->ti8) delete p;
   for (auto p : s->qi8) delete p;
   for (auto p : s->tcin) delete p;
@@ -820,9 +1000,11 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
   HIP_TRY(ctx, hipStreamSynchronize(st));
   s->generation++;
   delete s->f32[image]; delete s->bf16[image]; delete s->norm[image];
-  delete s->shi[image]; delete s->slo[image]; delete s->sn2[image];
-  s->shi[image] = new DevBuf<unsigned short>(); s->slo[image] = new DevBuf<unsigned short>(); s->sn2[image] = new DevBuf<float>();
-  s->sn2max[image] = 0.f;
+  delete s->th16[image]; delete s->qh16[image]; delete s->n2s[image]; delete s->rerr[image];
+  s->th16[image] = new DevBuf<unsigned short>(); s->qh16[image] = new DevBuf<unsigned short>(); s->n2s[image] = new DevBuf<float>();
+  s->rerr[image] = new DevBuf<float>();
+  s->n2s_max[image] = 0.f;
+  s->f16_exp[image] = INT_MIN;
   delete s->ti8[image]; delete s->qi8[image]; delete s->tcin[image]; delete s->tpar[image]; delete s->qbeta[image];
   s->f32[image] = new DevBuf<float>(); s->bf16[image] = new DevBuf<unsigned short>(); s->norm[image] = new DevBuf<float>();
   s->ti8[image] = new DevBuf<signed char>(); s->qi8[image] = new DevBuf<signed char>();
@@ -836,20 +1018,54 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
   HIP_TRY(ctx, s->tcin[image]->alloc(count)); HIP_TRY(ctx, s->tpar[image]->alloc(count)); HIP_TRY(ctx, s->qbeta[image]->alloc(count));
   HIP_TRY(ctx, s->f32[image]->upload(desc, (size_t)count * DIM, st));
   hipLaunchKernelGGL(k_desc_prep, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->bf16[image]->p,
-                     s->norm[image]->p, s->nonint.p);
+                     s->norm[image]->p, s->nonint.p, s->vmax_dev.p);
   hipLaunchKernelGGL(k_desc_prep_i8, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->ti8[image]->p,
                      s->qi8[image]->p, s->tcin[image]->p, s->tpar[image]->p, s->qbeta[image]->p);
-  HIP_TRY(ctx, s->shi[image]->alloc((size_t)count * DIM)); HIP_TRY(ctx, s->slo[image]->alloc((size_t)count * DIM));
-  HIP_TRY(ctx, s->sn2[image]->alloc(count));
-  HIP_TRY(ctx, hipMemsetAsync(s->n2max_dev.p, 0, sizeof(unsigned), st));
-  hipLaunchKernelGGL(k_desc_prep_split, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[image]->p, count, s->shi[image]->p,
-                     s->slo[image]->p, s->sn2[image]->p, s->n2max_dev.p);
   HIP_TRY(ctx, hipGetLastError());
-  unsigned n2bits = 0;
+  unsigned vbits = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&s->h_nonint, s->nonint.p, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipMemcpyAsync(&n2bits, s->n2max_dev.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipMemcpyAsync(&vbits, s->vmax_dev.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
-  memcpy(&s->sn2max[image], &n2bits, sizeof(float));
+  memcpy(&s->vabs_max, &vbits, sizeof(float));   // running maximum over every upload so far (never reset)
+  return MSFM_OK;
+}
+
+// f16 forms of every image at the common power-of-two scale (largest |value| of the set in [2^13, 2^14)); images whose
+// forms were made at another scale (or never) are redone from their resident float32 copy.
+static int ensure_f16_forms(msfm_descset* s) {
+  msfm_ctx* ctx = s->ctx;
+  hipStream_t st = ctx->stream;
+  int e = 0;
+  if (s->vabs_max > 0.f && std::isfinite(s->vabs_max)) {
+    int ex = 0;
+    (void)frexpf(s->vabs_max, &ex);   // vabs_max = m 2^ex, m in [0.5, 1)  ->  vabs_max * 2^(14 - ex) in [2^13, 2^14)
+    e = 14 - ex;
+  }
+  e = std::max(-100, std::min(100, e));
+  const float scale = ldexpf(1.0f, e);
+  bool any = false;
+  for (int i = 0; i < s->n_images; i++) {
+    if (s->count[i] == 0 || s->f16_exp[i] == e) continue;
+    const int count = s->count[i];
+    if (!any) HIP_TRY(ctx, hipMemsetAsync(s->n2smax_dev.p, 0, sizeof(unsigned) * 2 * s->n_images, st));
+    any = true;
+    if (s->th16[i]->n != (size_t)count * DIM) {
+      HIP_TRY(ctx, s->th16[i]->alloc((size_t)count * DIM)); HIP_TRY(ctx, s->qh16[i]->alloc((size_t)count * DIM));
+      HIP_TRY(ctx, s->n2s[i]->alloc(count)); HIP_TRY(ctx, s->rerr[i]->alloc(count));
+    }
+    hipLaunchKernelGGL(k_desc_prep_f16, dim3(cdiv(count, 4)), dim3(256), 0, st, s->f32[i]->p, count, scale, s->th16[i]->p, s->qh16[i]->p,
+                       s->n2s[i]->p, s->rerr[i]->p, s->n2smax_dev.p + i, s->n2smax_dev.p + s->n_images + i);
+    s->f16_exp[i] = e;
+    s->n2s_max[i] = -1.f;   // to be read back
+  }
+  if (any) {
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<unsigned> bits(2 * (size_t)s->n_images);
+    HIP_TRY(ctx, hipMemcpyAsync(bits.data(), s->n2smax_dev.p, sizeof(unsigned) * bits.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int i = 0; i < s->n_images; i++)
+      if (s->n2s_max[i] < 0.f) { memcpy(&s->n2s_max[i], &bits[i], sizeof(float)); memcpy(&s->rerr_max[i], &bits[s->n_images + i], sizeof(float)); }
+  }
   return MSFM_OK;
 }
 
@@ -867,11 +1083,10 @@ struct msfm_match_result {
   DevBuf<PairTask> tasks;
   DevBuf<PairTask8> tasks8;
   DevBuf<PairTaskF> tasksf;
-  DevBuf<PairTaskS> taskss;
-  DevBuf<int> qpair, cand, flagged, n_flagged;
-  DevBuf<float> d4a;
-  int n_tiles_split = 0;
-  bool use_exact = false;  // MSFM_KNN_EXACT=1: brute-force FP64 kernel for non-integral data instead of split-bf16 + re-rank
+  DevBuf<PairTaskH> tasksh;
+  DevBuf<int> flagged, n_flagged, pair_off, group_first, nf_group;
+  int n_groups = 0;
+  bool use_exact = false;  // MSFM_KNN_EXACT=1: brute-force FP64 kernel for non-integral data instead of the certified f16 path
   bool use_bf16 = false;  // MSFM_KNN_BF16=1 selects the bf16 MFMA kernel instead of the int8 one
   int n_tiles = 0;
   bool exact_path = false;
@@ -903,20 +1118,19 @@ static int launch_match(msfm_match_result* R) {
                        R->n_all.p, R->n_good.p);
   } else if (!R->use_exact) {
     {
-      KTimer t(ctx, "knn2_split_bf16_mfma");
-      hipLaunchKernelGGL(k_knn2_split, dim3(R->n_tiles_split), dim3(256), 0, st, R->taskss.p, R->tile_first.p, R->n_pairs,
-                         R->cand.p, R->d4a.p);
+      KTimer t(ctx, "knn2_f16_mfma");
+      HIP_TRY(ctx, hipMemsetAsync(R->n_flagged.p, 0, sizeof(int), st));
+      HIP_TRY(ctx, hipMemsetAsync(R->nf_group.p, 0, sizeof(int) * std::max(1, R->n_groups), st));   // per-group flagged counters
+      hipLaunchKernelGGL(k_knn2_f16, dim3(R->n_tiles), dim3(256), 0, st, R->tasksh.p, R->tile_first.p, R->n_pairs, R->ratio_good, R->ratio_all,
+                         R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr, R->n_all.p, R->n_good.p,
+                         R->flagged.p, R->nf_group.p, R->n_flagged.p, getenv("MSFM_KNN_DEBUG") ? atoi(getenv("MSFM_KNN_DEBUG")) : 0);
     }
     {
-      KTimer t(ctx, "knn2_rerank_f64");
-      HIP_TRY(ctx, hipMemsetAsync(R->n_flagged.p, 0, sizeof(int), st));
-      const int nb = cdiv(R->total_q, 256);
-      hipLaunchKernelGGL(k_rerank, dim3(nb), dim3(256), 0, st, R->taskss.p, R->qpair.p, R->total_q, R->cand.p, R->d4a.p, R->ids.p,
-                         R->sqd.p, R->flagged.p, R->n_flagged.p);
-      hipLaunchKernelGGL(k_exact_flagged, dim3((int)std::min<long>(R->total_q, 4096)), dim3(64), 0, st, R->taskss.p, R->qpair.p,
-                         R->flagged.p, R->n_flagged.p, R->ids.p, R->sqd.p);
-      hipLaunchKernelGGL(k_codes, dim3(nb), dim3(256), 0, st, R->qpair.p, R->total_q, R->ids.p, R->sqd.p, R->ratio_good, R->ratio_all,
-                         R->code.p, R->n_all.p, R->n_good.p);
+      KTimer t(ctx, "knn2_exact_flagged_f64");
+      if (R->n_groups)
+        hipLaunchKernelGGL(k_exact_flagged, dim3(R->n_groups, std::max(1, std::min(64, cdiv(2048, R->n_groups)))), dim3(256), 0, st, R->tasksh.p, R->group_first.p, R->pair_off.p, R->flagged.p, R->nf_group.p, R->ratio_good,
+                           R->ratio_all, R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr, R->n_all.p,
+                           R->n_good.p);
     }
   } else {
     KTimer t(ctx, "knn2_exact_f64");
@@ -949,10 +1163,11 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
   R->exact_path = s->h_nonint != 0;
   { const char* e = getenv("MSFM_KNN_BF16"); R->use_bf16 = e && e[0] == '1'; }
   { const char* e = getenv("MSFM_KNN_EXACT"); R->use_exact = e && e[0] == '1'; }
-  const bool split = R->exact_path && !R->use_exact;
-  const int qpb = split ? QPS : (R->exact_path ? 64 : QPB);
-  std::vector<PairTaskS> taskss(n_pairs);
-  std::vector<int> qpair;
+  const bool certified = R->exact_path && !R->use_exact;
+  if (certified) MSFM_TRY(ensure_f16_forms(s));
+  const int qpb = (R->exact_path && !certified) ? 64 : QPB;
+  std::vector<PairTaskH> tasksh(certified ? n_pairs : 0);
+  std::vector<int> pair_off(n_pairs + 1, 0), group_first;
   std::vector<int> tile_first(n_pairs + 1, 0);
   std::vector<PairTask> tasks(n_pairs);
   std::vector<PairTaskF> tasksf(n_pairs);
@@ -968,9 +1183,20 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
     tasks[p] = PairTask{s->bf16[a]->p, nq ? s->bf16[b]->p : nullptr, s->norm[a]->p, nq ? s->norm[b]->p : nullptr, s->count[a], nq, (int)off};
     tasks8[p] = PairTask8{s->ti8[a]->p, nq ? s->qi8[b]->p : nullptr, s->tcin[a]->p, s->tpar[a]->p, nq ? s->qbeta[b]->p : nullptr, s->count[a], nq, (int)off};
     tasksf[p] = PairTaskF{s->f32[a]->p, nq ? s->f32[b]->p : nullptr, s->count[a], nq, (int)off};
-    taskss[p] = PairTaskS{s->shi[a]->p, s->slo[a]->p, nq ? s->shi[b]->p : nullptr, nq ? s->slo[b]->p : nullptr, s->sn2[a]->p,
-                          nq ? s->sn2[b]->p : nullptr, s->f32[a]->p, nq ? s->f32[b]->p : nullptr, s->sn2max[a], s->count[a], nq, (int)off};
-    if (split) qpair.insert(qpair.end(), (size_t)nq, p);
+    pair_off[p] = (int)off;
+    if (certified) {
+      const float ex = (float)s->f16_exp[a];
+      const double a2max = s->n2s_max[a], b2max = nq ? s->n2s_max[b] : 0.0;
+      // SHIFT >= max |b|^2 + 2 E keeps every accumulator positive; E itself depends (weakly) on SHIFT: two sweeps settle it
+      double shift = b2max;
+      for (int it = 0; it < 3; it++) shift = b2max + 2.0 * f16_error_bound(a2max, s->rerr_max[a], b2max, nq ? s->rerr_max[b] : 0.0, shift * 1.001);
+      float shift_f = (float)(shift * 1.001);
+      shift_f = nextafterf(shift_f, INFINITY);
+      if (p == 0 || pairs[2 * (p - 1)] != a) group_first.push_back(p);   // a new train image starts a new group
+      tasksh[p] = PairTaskH{s->th16[a]->p, nq ? s->qh16[b]->p : nullptr, s->n2s[a]->p, nq ? s->n2s[b]->p : nullptr, nq ? s->rerr[b]->p : nullptr,
+                            s->f32[a]->p, nq ? s->f32[b]->p : nullptr, (float)a2max, s->rerr_max[a], shift_f, ldexpf(1.0f, 2 * (int)ex), s->count[a], nq,
+                            (int)off, (int)group_first.size() - 1, pair_off[group_first.back()]};
+    }
     off += nq;
     tiles += cdiv(nq, qpb);
     if (off > 0x7fffffffL || tiles > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_INVAL, "too many queries in one call; split the pair list");
@@ -978,15 +1204,18 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
   tile_first[n_pairs] = (int)tiles;
   R->total_q = off;
   R->n_tiles = (int)tiles;
-  R->n_tiles_split = split ? (int)tiles : 0;
+  pair_off[n_pairs] = (int)off;
   hipStream_t st = ctx->stream;
   HIP_TRY(ctx, R->code.alloc(std::max<long>(1, off)));
-  if (split) {
-    R->keep_knn = true;  // the re-rank stage produces (ids, sqd) anyway
-    HIP_TRY(ctx, R->qpair.from(qpair.empty() ? std::vector<int>(1, 0) : qpair, st));
-    HIP_TRY(ctx, R->cand.alloc(std::max<long>(1, 4 * off))); HIP_TRY(ctx, R->d4a.alloc(std::max<long>(1, off)));
+  if (certified) {
     HIP_TRY(ctx, R->flagged.alloc(std::max<long>(1, off))); HIP_TRY(ctx, R->n_flagged.alloc(1));
-    if (n_pairs) HIP_TRY(ctx, R->taskss.from(taskss, st));
+    HIP_TRY(ctx, hipMemsetAsync(R->n_flagged.p, 0, sizeof(int), st));
+    group_first.push_back(n_pairs);
+    R->n_groups = (int)group_first.size() - 1;
+    HIP_TRY(ctx, R->pair_off.from(pair_off, st));
+    HIP_TRY(ctx, R->group_first.from(group_first, st));
+    HIP_TRY(ctx, R->nf_group.alloc(std::max(1, R->n_groups)));   // per-group counters of flagged queries
+    if (n_pairs) HIP_TRY(ctx, R->tasksh.from(tasksh, st));
   }
   if (R->keep_knn) { HIP_TRY(ctx, R->ids.alloc(std::max<long>(1, 2 * off))); HIP_TRY(ctx, R->sqd.alloc(std::max<long>(1, 2 * off))); }
   HIP_TRY(ctx, R->n_all.alloc(std::max(1, n_pairs))); HIP_TRY(ctx, R->n_good.alloc(std::max(1, n_pairs)));

@@ -13,7 +13,7 @@ from metricsfm_amd import _abi as A, capi, scene  # noqa: E402
 
 ctx = capi.Context(0)
 out = {}
-# ---- general float descriptors (VLFeat 512*x floats): exact FP64 path ----
+# ---- general float descriptors (VLFeat 512*x floats): certified f16 path ----
 rng = np.random.default_rng(0)
 n_float_images = 24   # 552 ordered pairs: enough workgroups to fill the chip (12 pairs leave it two thirds idle)
 d = [(rng.gamma(0.6, 1.0, (4096, 128)) * 40).astype(np.float32) for _ in range(n_float_images)]

@@ -69,9 +69,9 @@ def test_knn2_general_floats(ctx, oracle):
 
 
 def test_knn2_general_floats_hard_cases(ctx, oracle):
-    """The split-bf16 + re-rank path must stay exact where its shortlist cannot certify the answer:
-    many exact duplicates (more than the shortlist holds), near ties below the bf16x2 resolution,
-    tiny and huge magnitudes, fewer train rows than the shortlist."""
+    """The certified f16 path must stay exact where its lists cannot certify the answer:
+    many exact duplicates (more than the lists hold), near ties far below the f16 resolution,
+    tiny and huge magnitudes (the power-of-two scale), fewer train rows than the lists hold."""
     rng = np.random.default_rng(12)
     base = (rng.gamma(0.6, 1.0, (500, 128)) * 40).astype(np.float32)
     tr = base.copy()
@@ -99,7 +99,7 @@ def test_knn2_general_floats_hard_cases(ctx, oracle):
     np.testing.assert_array_equal(d_g, d_r)
 
 
-def test_split_path_certifies_almost_everything(ctx, oracle):
+def test_float_path_certifies_almost_everything(ctx, oracle):
     """Random non-integral data: the shortlist is certified for (nearly) every query; exact
     duplicates force the exact fallback for the affected queries only.  Integer data: no slow path."""
     rng = np.random.default_rng(3)
@@ -231,3 +231,53 @@ def test_context_outlives_its_children(oracle):
     ds.close()                      # the set goes before its result
     res.close()
     ba.close()                      # last child: the context is released here
+
+
+def test_float_path_on_clustered_descriptors(ctx, oracle):
+    """Adversarial for the certificate: descriptors in tight clusters (dozens of rows within the f16 error bound of each
+    other), so most queries cannot be certified and go through the exact brute force - results still bit-identical."""
+    rng = np.random.default_rng(21)
+    centres = (rng.gamma(0.6, 1.0, (12, 128)) * 40).astype(np.float32)
+    tr = (centres[rng.integers(0, 12, 700)] + rng.normal(0, 0.02, (700, 128))).astype(np.float32)
+    qu = (centres[rng.integers(0, 12, 260)] + rng.normal(0, 0.02, (260, 128))).astype(np.float32)
+    ds = ctx.descset([tr, qu])
+    res = ds.match_pairs(np.array([[0, 1], [1, 0]], np.int32), keep_knn=True)
+    assert res.stats()["slow_path"] > 200
+    for p, (i, j) in enumerate([(0, 1), (1, 0)]):
+        d = [tr, qu]
+        code, ids, dist = res.fetch(p)
+        ids_r, d_r = oracle.knn2(d[i], d[j])
+        np.testing.assert_array_equal(ids, ids_r)
+        np.testing.assert_array_equal(dist, d_r)
+        code_r, na_r, ng_r = oracle.ratio_codes(ids_r, d_r, 0.6, 0.85)
+        np.testing.assert_array_equal(code, code_r)
+    na, ng = res.counts()
+    assert na.sum() >= ng.sum()
+
+
+def test_float_path_vlfeat_scale_full_tiles(ctx, oracle):
+    """512 * unit-norm descriptors (feature_extractor_vl_sift.cpp:202) at the size of a real image pair: several
+    256-row key windows, both query sets of every wave, ragged last tile."""
+    sc = scene.add_features(scene.make_aerial_scene(12, 1200, seed=33), 1500, images=range(3))
+    d = [(512.0 * x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32) for x in sc.desc[:3]]
+    d[1] = d[1][:1333]
+    ds = ctx.descset(d)
+    pairs = np.array([[0, 1], [1, 2], [2, 0], [1, 0]], np.int32)
+    res = ds.match_pairs(pairs, keep_knn=True)
+    st = res.stats()
+    assert st["slow_path"] < 0.05 * st["queries"]
+    ng_total = 0
+    for p, (i, j) in enumerate(pairs):
+        code, ids, dist = res.fetch(p)
+        ids_r, d_r = oracle.knn2(d[i], d[j])
+        np.testing.assert_array_equal(ids, ids_r)
+        np.testing.assert_array_equal(dist, d_r)
+        code_r, _, ng_r = oracle.ratio_codes(ids_r, d_r, 0.6, 0.85)
+        np.testing.assert_array_equal(code, code_r)
+        ng_total += ng_r
+    assert ng_total > 100
+    # without keep_knn only the codes and counts exist; they must not change
+    res2 = ds.match_pairs(pairs, keep_knn=False)
+    for p in range(len(pairs)):
+        np.testing.assert_array_equal(res2.fetch(p)[0], res.fetch(p)[0])
+    np.testing.assert_array_equal(res2.counts()[0], res.counts()[0])
