@@ -112,8 +112,15 @@ def main():
         torch.cuda.set_device(local_rank)
 
     ctx = capi.Context(local_rank)
+    collective = "none (1 rank)"
     if world > 1:
-        ctx.set_allreduce(shard.make_allreduce(dist, local_rank, ctx), rank, world)
+        if dist.get_backend() == "nccl":
+            # the library's own RCCL communicator: ncclAllReduce from C++ on the library's stream, no Python in the LM loop
+            shard.init_native_rccl(ctx, dist, rank, world)
+            collective = "RCCL ncclAllReduce inside libmsfm (msfm_ctx_init_rccl)"
+        else:   # rehearsal on CPU-staged gloo (several ranks sharing one GPU)
+            ctx.set_allreduce(shard.make_allreduce(dist, local_rank, ctx), rank, world)
+            collective = "torch.distributed %s through the hook (host staged)" % dist.get_backend()
 
     def barrier():
         ctx.synchronize()
@@ -269,7 +276,7 @@ def main():
                warmup=args.warmup, ms_per_step=1e3 * ba_s / args.steps, higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=workload, reduced_system_order=n_red,
-                           parallelism="points sharded over %d rank(s), camera block all-reduced" % world,
+                           parallelism="points sharded over %d rank(s), camera block all-reduced" % world, collective=collective,
                            successful_steps=res["num_successful_steps"], unsuccessful_steps=res["num_unsuccessful_steps"],
                            setup_ms=res["setup_ms"], scene_gen_s=gen_s),
                roofline=roofline, roofline_whole_step=whole, kernel_rooflines=rooflines, ba_kernels=kernels,

@@ -266,6 +266,20 @@ typedef int (*msfm_allreduce_fn)(void* user, double* buf_dev, size_t count, int 
 int msfm_ctx_set_allreduce(msfm_ctx* ctx, msfm_allreduce_fn fn, void* user, int rank,
                            int world_size);
 
+/* The same collective supplied by the library itself: RCCL all-reduce over xGMI, one process per GPU (the
+ * multi-GPU context owns the communicator).  librccl is loaded at run time by these two calls only, so a single-GPU
+ * host has no RCCL dependency.  Rank 0 obtains an id, the host hands the 128 bytes to the other ranks by whatever it has
+ * (MPI_Bcast, a file, torch.distributed.broadcast_object_list), then EVERY rank calls msfm_ctx_init_rccl - a collective
+ * call - which creates the communicator on the context's device and installs ncclAllReduce (ncclDouble, sum / max,
+ * in place, on the context's stream) as the reduction hook.  msfm_ctx_destroy releases the communicator. */
+#define MSFM_RCCL_ID_BYTES 128
+int msfm_rccl_get_unique_id(msfm_ctx* ctx, unsigned char id[MSFM_RCCL_ID_BYTES]);
+int msfm_ctx_init_rccl(msfm_ctx* ctx, const unsigned char id[MSFM_RCCL_ID_BYTES], int rank, int world_size);
+/* Runs the installed collective (host hook or the native RCCL one) on `count` doubles at `buf_dev`, in place, ordered on
+ * the context's stream - what the solver does internally; exposed so that a host can reduce its own per-rank results
+ * (the N x N match-count matrix of fine_matching_graph.cc:275-292, timing maxima) through the same communicator. */
+int msfm_ctx_allreduce(msfm_ctx* ctx, double* buf_dev, size_t count, int op);
+
 /* ==================================================================================== *
  *  Triangulation / reprojection  
  * ==================================================================================== */

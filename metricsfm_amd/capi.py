@@ -24,7 +24,7 @@ SYMBOLS = [
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
     "msfm_epipolar_filter_batch", "msfm_tracks_build", "msfm_track_set_size", "msfm_track_set_fetch", "msfm_track_set_destroy",
-    "msfm_epnp_ransac_batch", "msfm_relpose_5pt_batch",
+    "msfm_epnp_ransac_batch", "msfm_relpose_5pt_batch", "msfm_rccl_get_unique_id", "msfm_ctx_init_rccl", "msfm_ctx_allreduce",
 ]
 
 
@@ -92,6 +92,9 @@ def lib():
                                          A.c_double_p, A.c_double_p, A.c_double_p, A.c_int_p]
     L.msfm_relpose_5pt_batch.argtypes = [vp, i, A.c_int_p, A.c_double_p, A.c_double_p, A.c_double_p, A.c_double_p, i, C.c_uint64,
                                          A.c_double_p, A.c_double_p, A.c_double_p, A.c_u8_p, A.c_int_p]
+    L.msfm_rccl_get_unique_id.argtypes = [vp, C.POINTER(C.c_ubyte)]
+    L.msfm_ctx_init_rccl.argtypes = [vp, C.POINTER(C.c_ubyte), i, i]
+    L.msfm_ctx_allreduce.argtypes = [vp, vp, C.c_size_t, i]
     L.msfm_tracks_build.argtypes = [i, A.c_int_p, i, A.c_int_p, A.c_int_p, A.c_int_p, C.POINTER(vp)]
     L.msfm_track_set_size.argtypes = [vp, A.c_int_p, A.c_int_p]
     L.msfm_track_set_fetch.argtypes = [vp, A.c_int_p, A.c_int_p, A.c_int_p]
@@ -217,6 +220,22 @@ class Context:
                     return -1
             self._cb = ALLREDUCE_FN(tramp)
         self.check(lib().msfm_ctx_set_allreduce(self._h, self._cb, None, rank, world_size))
+
+    def rccl_unique_id(self):
+        """128 opaque bytes (ncclUniqueId) from rank 0, to be handed to every rank's init_rccl."""
+        buf = (C.c_ubyte * 128)()
+        self.check(lib().msfm_rccl_get_unique_id(self._h, buf))
+        return bytes(buf)
+
+    def init_rccl(self, unique_id, rank, world_size):
+        """Collective: the library creates its own RCCL communicator and reduces with ncclAllReduce on its stream -
+        no Python in the LM loop (msfm_ctx_init_rccl)."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        self.check(lib().msfm_ctx_init_rccl(self._h, buf, rank, world_size))
+
+    def allreduce(self, dev_ptr, count, op=0):
+        """msfm_ctx_allreduce on a device buffer of doubles (op 0 = sum, 1 = max), ordered on the context's stream."""
+        self.check(lib().msfm_ctx_allreduce(self._h, dev_ptr, count, op))
 
     # -- matching --
     def knn2(self, train, query):

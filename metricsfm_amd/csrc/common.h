@@ -40,6 +40,12 @@ struct msfm_ctx {
   // msfm_ctx_destroy refuses while there are any, and the last child of an orphaned context destroys it
   int children = 0;
   bool orphaned = false;
+  // native collective (msfm_ctx_init_rccl): librccl handle, communicator and the entry points resolved from it
+  void* rccl_lib = nullptr;
+  void* rccl_comm = nullptr;
+  void* rccl_allreduce = nullptr;
+  void* rccl_comm_destroy = nullptr;
+  void* rccl_error_string = nullptr;
 };
 void msfm_ctx_child_released(msfm_ctx* ctx);
 

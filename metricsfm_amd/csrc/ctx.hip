@@ -163,6 +163,10 @@ MSFM_API void msfm_ctx_destroy(msfm_ctx* ctx) {
   }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->rccl_comm && ctx->rccl_comm_destroy) {
+    (void)reinterpret_cast<int (*)(void*)>(ctx->rccl_comm_destroy)(ctx->rccl_comm);
+    ctx->rccl_comm = nullptr;
+  }
   msfm_pool_trim(ctx->device);
   if (ctx->ba_scratch && ctx->ba_scratch_free) ctx->ba_scratch_free(ctx->ba_scratch);
   for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -193,6 +197,80 @@ MSFM_API int msfm_ctx_set_allreduce(msfm_ctx* ctx, msfm_allreduce_fn fn, void* u
   ctx->allreduce_user = user;
   ctx->rank = rank;
   ctx->world = world_size;
+  return MSFM_OK;
+}
+
+// ---- native RCCL collective ------------------------------------------------------------
+// rccl.h is not included on purpose (the library must build and load where RCCL is absent); the few types used:
+#include <dlfcn.h>
+namespace {
+struct RcclId { char internal[MSFM_RCCL_ID_BYTES]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
+typedef int (*rccl_get_unique_id_t)(RcclId*);
+typedef int (*rccl_comm_init_rank_t)(void** comm, int nranks, RcclId id, int rank);
+typedef int (*rccl_all_reduce_t)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream);
+typedef int (*rccl_comm_destroy_t)(void* comm);
+typedef const char* (*rccl_error_string_t)(int);
+enum { RCCL_SUM = 0, RCCL_MAX = 2, RCCL_FLOAT64 = 8 };   // ncclRedOp_t / ncclDataType_t values of rccl.h
+
+void* rccl_open(msfm_ctx* ctx) {
+  if (ctx->rccl_lib) return ctx->rccl_lib;
+  // a copy already mapped into the process (torch ships one) is found first by its soname
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    ctx->rccl_lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (ctx->rccl_lib) break;
+  }
+  return ctx->rccl_lib;
+}
+
+int rccl_hook(void* user, double* buf, size_t count, int op, void* stream) {
+  msfm_ctx* ctx = static_cast<msfm_ctx*>(user);
+  const int rc = reinterpret_cast<rccl_all_reduce_t>(ctx->rccl_allreduce)(buf, buf, count, RCCL_FLOAT64, op == MSFM_REDUCE_MAX ? RCCL_MAX : RCCL_SUM,
+                                                                           ctx->rccl_comm, (hipStream_t)stream);
+  return rc;   // ncclSuccess = 0
+}
+}  // namespace
+
+MSFM_API int msfm_rccl_get_unique_id(msfm_ctx* ctx, unsigned char id[MSFM_RCCL_ID_BYTES]) {
+  if (!ctx || !id) return MSFM_E_INVAL;
+  if (!rccl_open(ctx)) return msfm_set_error(ctx, MSFM_E_DEVICE, "librccl not found: %s", dlerror());
+  auto fn = reinterpret_cast<rccl_get_unique_id_t>(dlsym(ctx->rccl_lib, "ncclGetUniqueId"));
+  if (!fn) return msfm_set_error(ctx, MSFM_E_DEVICE, "ncclGetUniqueId not found in librccl");
+  RcclId u;
+  const int rc = fn(&u);
+  if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "ncclGetUniqueId failed: %d", rc);
+  memcpy(id, u.internal, MSFM_RCCL_ID_BYTES);
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_ctx_init_rccl(msfm_ctx* ctx, const unsigned char id[MSFM_RCCL_ID_BYTES], int rank, int world_size) {
+  if (!ctx || !id || world_size < 1 || rank < 0 || rank >= world_size) return MSFM_E_INVAL;
+  if (ctx->rccl_comm) return msfm_set_error(ctx, MSFM_E_INVAL, "this context already owns a communicator");
+  if (!rccl_open(ctx)) return msfm_set_error(ctx, MSFM_E_DEVICE, "librccl not found: %s", dlerror());
+  auto init = reinterpret_cast<rccl_comm_init_rank_t>(dlsym(ctx->rccl_lib, "ncclCommInitRank"));
+  ctx->rccl_allreduce = dlsym(ctx->rccl_lib, "ncclAllReduce");
+  ctx->rccl_comm_destroy = dlsym(ctx->rccl_lib, "ncclCommDestroy");
+  ctx->rccl_error_string = dlsym(ctx->rccl_lib, "ncclGetErrorString");
+  if (!init || !ctx->rccl_allreduce || !ctx->rccl_comm_destroy) return msfm_set_error(ctx, MSFM_E_DEVICE, "librccl lacks an entry point");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RcclId u;
+  memcpy(u.internal, id, MSFM_RCCL_ID_BYTES);
+  void* comm = nullptr;
+  const int rc = init(&comm, world_size, u, rank);
+  if (rc != 0) {
+    const char* txt = ctx->rccl_error_string ? reinterpret_cast<rccl_error_string_t>(ctx->rccl_error_string)(rc) : "";
+    return msfm_set_error(ctx, MSFM_E_DEVICE, "ncclCommInitRank failed: %d %s", rc, txt);
+  }
+  ctx->rccl_comm = comm;
+  return msfm_ctx_set_allreduce(ctx, rccl_hook, ctx, rank, world_size);
+}
+
+MSFM_API int msfm_ctx_allreduce(msfm_ctx* ctx, double* buf_dev, size_t count, int op) {
+  if (!ctx || (count > 0 && !buf_dev) || (op != MSFM_REDUCE_SUM && op != MSFM_REDUCE_MAX)) return MSFM_E_INVAL;
+  if (!ctx->allreduce) return ctx->world <= 1 ? MSFM_OK : msfm_set_error(ctx, MSFM_E_INVAL, "no collective installed");
+  if (count == 0) return MSFM_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int rc = ctx->allreduce(ctx->allreduce_user, buf_dev, count, op, (void*)ctx->stream);
+  if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce failed: %d", rc);
   return MSFM_OK;
 }
 

@@ -116,3 +116,12 @@ class TorchAllReduce:
 def make_allreduce(dist, device_index, ctx=None, group=None):
     """The collective the library's hook calls (msfm_ctx_set_allreduce): torch.distributed on the library's stream."""
     return TorchAllReduce(dist, device_index, group)
+
+
+def init_native_rccl(ctx, dist, rank, world, group=None):
+    """The library's own RCCL communicator (msfm_ctx_init_rccl): rank 0 creates the id, torch.distributed carries the
+    128 bytes to the other ranks, every rank joins.  After this the LM loop reduces with ncclAllReduce from C++ -
+    no Python callback, no torch tensor wrapping per call."""
+    box = [ctx.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ctx.init_rccl(box[0], rank, world)

@@ -91,3 +91,168 @@ class DenseLM:
                 reuse = True
                 traj.append(ccost)
         return x, traj
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A second, stronger pin at the size of BASELINE config 1 (10 cameras / 2000 points): sparse Jacobian by COMPLEX-STEP
+# differentiation of an independent numpy projection (exact to rounding, no finite-difference noise), normal equations
+# solved WITHOUT a Schur complement by a sparse LU (scipy SuperLU), the full Ceres 1.13 trust-region control flow
+# (rejected steps reuse the LM diagonal and divide the radius by 2, 4, ...), frozen cameras / points / intrinsics,
+# absolute GPS rows (gps_error_pose_absolute.h:31-44) and the Huber corrector with active outliers.
+def _project_cs(pose, model, X):
+    """Reprojection of reprojection_error_pose_cam_xyz.h:41-63 on complex inputs: angle-axis rotation by the Rodrigues
+    point formula (no branches, every operation analytic), +z forward, radial distortion k1, k2."""
+    a, t = pose[:, :3], pose[:, 3:]
+    th2 = (a * a).sum(1)
+    th = np.sqrt(th2)
+    w = a / th[:, None]
+    c, s = np.cos(th), np.sin(th)
+    wxX = np.stack([w[:, 1] * X[:, 2] - w[:, 2] * X[:, 1], w[:, 2] * X[:, 0] - w[:, 0] * X[:, 2], w[:, 0] * X[:, 1] - w[:, 1] * X[:, 0]], 1)
+    p = X * c[:, None] + wxX * s[:, None] + w * ((w * X).sum(1) * (1 - c))[:, None] + t
+    xp, yp = p[:, 0] / p[:, 2], p[:, 1] / p[:, 2]
+    r2 = xp * xp + yp * yp
+    d = 1.0 + r2 * (model[:, 1] + model[:, 2] * r2)
+    return np.stack([model[:, 0] * d * xp, model[:, 0] * d * yp], 1)
+
+
+class SparseLM:
+    """msfm_ba_problem semantics (include/msfm.h): masks select the functor per observation, bad points are simply absent."""
+
+    def __init__(self, arr, huber=1.0):
+        import scipy.sparse as sp
+        self.sp = sp
+        self.a = arr
+        self.huber = huber
+        a = arr
+        Nc, Nm, Np = len(a.cam_pose), len(a.cam_model), len(a.point)
+        cm = np.ones(Nc, bool) if a.cam_mutable is None else a.cam_mutable != 0
+        mm = np.ones(Nm, bool) if a.model_mutable is None else a.model_mutable != 0
+        pm = np.ones(Np, bool) if a.pt_mutable is None else a.pt_mutable != 0
+        oc, op = a.obs_cam, a.obs_pt
+        om = a.cam_model_of_cam[oc]
+        self.active = cm[oc] | pm[op]                       # both frozen: no residual block (optimizer.cc:86-125)
+        self.oc, self.op, self.om = oc[self.active], op[self.active], om[self.active]
+        self.xy = a.obs_xy[self.active]
+        self.w = a.pt_weight[self.op]
+        self.c_free, self.p_free = cm[self.oc], pm[self.op]
+        self.m_free = self.c_free & mm[self.om]             # intrinsics move only with a free camera (functor choice)
+        self.has_gps = a.gps_xyz is not None
+        # a block is a parameter iff some residual uses it
+        cu = np.zeros(Nc, bool); cu[self.oc[self.c_free]] = True
+        if self.has_gps:
+            cu |= cm
+        mu = np.zeros(Nm, bool); mu[self.om[self.m_free]] = True
+        pu = np.zeros(Np, bool); pu[self.op[self.p_free]] = True
+        self.cu, self.mu, self.pu = cu, mu, pu
+        self.col_c = np.full(Nc, -1); self.col_c[cu] = 6 * np.arange(cu.sum())
+        off = 6 * int(cu.sum())
+        self.col_m = np.full(Nm, -1); self.col_m[mu] = off + 3 * np.arange(mu.sum())
+        off += 3 * int(mu.sum())
+        self.col_p = np.full(Np, -1); self.col_p[pu] = off + 3 * np.arange(pu.sum())
+        self.n = off + 3 * int(pu.sum())
+        self.gps_cams = np.nonzero(cu & cm)[0] if self.has_gps else np.zeros(0, int)
+        self.gw = np.array([a.struct.gps_weight, a.struct.gps_weight, a.struct.gps_weight / 5.0])
+
+    # -- residuals and Jacobian at (pose, model, point)
+    def _res(self, pose, model, point):
+        uv = _project_cs(pose[self.oc], model[self.om], point[self.op])
+        r = (self.w[:, None] * (uv - self.xy))
+        g = None
+        if self.has_gps:
+            d = pose[self.gps_cams, 3:] - self.a.gps_xyz[self.gps_cams]
+            g = self.gw[None, :] * np.abs(d)
+        return r, g
+
+    def cost(self, pose, model, point):
+        r, g = self._res(pose, model, point)
+        c = 0.5 * huber_rho((r * r).sum(1), self.huber)[0].sum()
+        if g is not None:
+            c += 0.5 * huber_rho((g * g).sum(1), self.huber)[0].sum()
+        return c
+
+    def linearise(self, pose, model, point):
+        sp = self.sp
+        No = len(self.oc)
+        P, M, X = pose[self.oc].astype(complex), model[self.om].astype(complex), point[self.op].astype(complex)
+        h = 1e-30
+        Jo = np.zeros((No, 2, 12))
+        for j in range(12):
+            Pj, Mj, Xj = P.copy(), M.copy(), X.copy()
+            (Pj if j < 6 else Mj if j < 9 else Xj)[:, j if j < 6 else j - 6 if j < 9 else j - 9] += 1j * h
+            Jo[:, :, j] = (self.w[:, None] * _project_cs(Pj, Mj, Xj)).imag / h
+        r, g = self._res(pose, model, point)
+        _, rho1 = huber_rho((r * r).sum(1), self.huber)
+        sq = np.sqrt(rho1)
+        r = r * sq[:, None]
+        Jo = Jo * sq[:, None, None]
+        rows, cols, vals = [], [], []
+        ridx = 2 * np.arange(No)
+        for blk, free, base, lo, dim in ((0, self.c_free, self.col_c[self.oc], 0, 6), (1, self.m_free, self.col_m[self.om], 6, 3),
+                                         (2, self.p_free, self.col_p[self.op], 9, 3)):
+            sel = np.nonzero(free)[0]
+            for k in range(2):
+                for d in range(dim):
+                    rows.append(ridx[sel] + k); cols.append(base[sel] + d); vals.append(Jo[sel, k, lo + d])
+        rvec = [r.reshape(-1)]
+        nrows = 2 * No
+        if g is not None:
+            d = pose[self.gps_cams, 3:] - self.a.gps_xyz[self.gps_cams]
+            _, rho1g = huber_rho((g * g).sum(1), self.huber)
+            sg = np.sqrt(rho1g)
+            Jg = self.gw[None, :] * np.where(d < 0, -1.0, 1.0) * sg[:, None]      # d|x|/dx as the Jets see it
+            for k in range(3):
+                rows.append(nrows + 3 * np.arange(len(self.gps_cams)) + k); cols.append(self.col_c[self.gps_cams] + 3 + k); vals.append(Jg[:, k])
+            rvec.append((g * sg[:, None]).reshape(-1))
+            nrows += 3 * len(self.gps_cams)
+        J = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nrows, self.n))
+        return np.concatenate(rvec), J
+
+    def pack(self, pose, model, point):
+        return np.concatenate([pose[self.cu].ravel(), model[self.mu].ravel(), point[self.pu].ravel()])
+
+    def apply(self, pose, model, point, delta):
+        pose, model, point = pose.copy(), model.copy(), point.copy()
+        a, b = 6 * int(self.cu.sum()), 6 * int(self.cu.sum()) + 3 * int(self.mu.sum())
+        pose[self.cu] += delta[:a].reshape(-1, 6); model[self.mu] += delta[a:b].reshape(-1, 3); point[self.pu] += delta[b:].reshape(-1, 3)
+        return pose, model, point
+
+    def run(self, iters, radius=1e4, min_relative_decrease=1e-3):
+        """TrustRegionMinimizer (Ceres 1.13) with LevenbergMarquardtStrategy, monotonic steps; returns the parameters and
+        one record per iteration: cost after it, accepted?, |gradient|_max, |step|."""
+        import scipy.sparse.linalg as spl
+        sp = self.sp
+        a = self.a
+        pose, model, point = a.cam_pose.copy(), a.cam_model.copy(), a.point.copy()
+        cost = self.cost(pose, model, point)
+        r, J = self.linearise(pose, model, point)
+        scale = 1.0 / (1.0 + np.sqrt(np.asarray(J.multiply(J).sum(0)).ravel()))
+        J = J @ sp.diags(scale)
+        rec = [dict(cost=cost, ok=1, gmax=np.abs(J.T @ r / scale).max() if self.n else 0.0, step=0.0)]
+        dec, reuse, diag = 2.0, False, None
+        for _ in range(iters):
+            if not reuse:
+                diag = np.clip(np.asarray(J.multiply(J).sum(0)).ravel(), 1e-6, 1e32)
+            H = (J.T @ J + sp.diags(np.sqrt(diag / radius) ** 2)).tocsc()
+            y = spl.splu(H).solve(J.T @ r)
+            step = -y
+            m = J @ step
+            mcc = -m @ (r + m / 2)
+            delta = step * scale
+            cp, cm_, cx = self.apply(pose, model, point, delta)
+            ccost = self.cost(cp, cm_, cx)
+            x_old = self.pack(pose, model, point)
+            snorm = np.linalg.norm(self.pack(cp, cm_, cx) - x_old)
+            rho = (cost - ccost) / mcc
+            if mcc > 0 and rho > min_relative_decrease:
+                pose, model, point, cost = cp, cm_, cx, ccost
+                r, J = self.linearise(pose, model, point)
+                J = J @ sp.diags(scale)
+                radius = min(1e16, radius / max(1 / 3, 1 - (2 * rho - 1) ** 3))
+                dec, reuse = 2.0, False
+                rec.append(dict(cost=cost, ok=1, gmax=np.abs(J.T @ r / scale).max(), step=snorm))
+            else:
+                radius /= dec
+                dec *= 2
+                reuse = True
+                rec.append(dict(cost=ccost, ok=0, gmax=rec[-1]["gmax"], step=snorm))
+        return (pose, model, point), rec

@@ -55,3 +55,38 @@ print("ok")
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_native_rccl_collective_world1(tmp_path):
+    """msfm_ctx_init_rccl: the library loads librccl itself, creates a communicator (one rank) and reduces device buffers
+    with ncclAllReduce on its own stream - the C++ path of the N-GPU bench, minus the peers.  A bundle adjustment on the
+    same context afterwards is unaffected."""
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from metricsfm_amd import _abi as A, capi, scene
+torch.cuda.set_device(0)
+ctx = capi.Context(0)
+uid = ctx.rccl_unique_id()
+assert len(uid) == 128 and any(uid)
+ctx.init_rccl(uid, 0, 1)
+buf = torch.arange(5000, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+for op in (0, 1, 0):
+    ctx.allreduce(buf.data_ptr(), buf.numel(), op)
+ctx.synchronize()
+assert (buf.cpu().numpy() == np.arange(5000)).all()
+sc = scene.make_ring_scene(5, 300, seed=4)
+r = ctx.ba_solve(A.BaArrays.from_scene(sc), capi.default_options(max_num_iterations=5))
+assert r["num_iterations"] >= 3
+try:
+    ctx.init_rccl(uid, 0, 1)
+    raise SystemExit("a second communicator on one context must be refused")
+except capi.MsfmError as e:
+    assert e.code == A.MSFM_E_INVAL
+ctx.close()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
