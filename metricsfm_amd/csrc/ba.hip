@@ -20,6 +20,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#include <rocprim/rocprim.hpp>
 
 #include "ba_device.h"
 #include "common.h"
@@ -1130,21 +1134,655 @@ static BaScratch& ba_scratch(msfm_ctx* ctx) {
   return *static_cast<BaScratch*>(ctx->ba_scratch);
 }
 
-MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** out) {
-  if (!ctx || !P || !out) return MSFM_E_INVAL;
-  *out = nullptr;
-  struct ExitLap {   // declared first, destroyed last: the time to the very end of the call, host vectors released
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    bool on = getenv("MSFM_VERBOSE") != nullptr;
-    ~ExitLap() { if (on) fprintf(stderr, "msfm: create returned after          %7.2f ms (from entry)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); }
-  } exit_lap;
-  if (P->n_cams <= 0 || P->n_models <= 0 || P->n_points < 0 || P->n_obs < 0 || !P->cam_pose || !P->cam_model ||
-      !P->cam_model_of_cam || (P->n_points > 0 && !P->point) ||
-      (P->n_obs > 0 && (!P->obs_cam || !P->obs_pt || !P->obs_xy)))
-    return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_ba_create: null or empty problem arrays");
-  for (int c = 0; c < P->n_cams; c++)
-    if (P->cam_model_of_cam[c] < 0 || P->cam_model_of_cam[c] >= P->n_models)
-      return msfm_set_error(ctx, MSFM_E_INVAL, "cam_model_of_cam[%d] out of range", c);
+// =======================================================================================
+// Index structures of a problem built ON THE DEVICE (default).  The reference hands over host arrays at every bundle
+// adjustment of its incremental loop and the structure changes each time (sfm_incremental.cc:917-1014), so this set-up
+// sits on the hot path of msfm_ba_solve: only the caller's own arrays cross PCIe (24 bytes per observation); block
+// usage, the point order, point-major rows, camera-major positions, the (point, intrinsics) entries and the three
+// block-pair lists are produced by scans, stable radix sorts (rocPRIM) and small kernels that write exactly what the
+// host code below writes (create_structures_host, kept for MSFM_CREATE_HOST=1 and compared bit for bit in the tests).
+// The host keeps what is O(cameras): slot numbering and the camera-graph bisection.
+// =======================================================================================
+namespace devsetup {
+
+template <class T>
+static hipError_t excl_scan(const T* in, T* out, size_t n, hipStream_t s, DevBuf<char>& tmp) {
+  if (n == 0) return hipSuccess;
+  size_t bytes = 0;
+  hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), s);
+  if (e != hipSuccess) return e;
+  if (tmp.n < bytes) { e = tmp.alloc(bytes); if (e != hipSuccess) return e; }
+  return rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), s);
+}
+template <class K>
+static hipError_t sort_pairs(const K* kin, K* kout, const int* vin, int* vout, size_t n, int bits, hipStream_t s, DevBuf<char>& tmp) {
+  if (n == 0) return hipSuccess;
+  size_t bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, s);
+  if (e != hipSuccess) return e;
+  if (tmp.n < bytes) { e = tmp.alloc(bytes); if (e != hipSuccess) return e; }
+  return rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0, bits, s);   // stable
+}
+static int bits_for(long n) { int b = 1; while ((1L << b) < n) b++; return b; }
+
+__device__ __forceinline__ bool dmut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
+
+// validation + block usage + observations per point.  err[0] = first out-of-range observation, err[1] = first order break
+__global__ __launch_bounds__(256) void k_scan_obs(int No, int Nc, int Np, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+                                                   const int* __restrict__ model_of_cam, const uint8_t* __restrict__ cam_mut,
+                                                   const uint8_t* __restrict__ model_mut, const uint8_t* __restrict__ pt_mut,
+                                                   uint8_t* __restrict__ cu, uint8_t* __restrict__ mu, uint8_t* __restrict__ pu,
+                                                   int* __restrict__ cnt, int* __restrict__ err) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= No) return;
+  const int c = obs_cam[o], p = obs_pt[o];
+  if (c < 0 || c >= Nc || p < 0 || p >= Np) { atomicMin(&err[0], o); return; }
+  if (o > 0 && p < obs_pt[o - 1]) atomicMin(&err[1], o);
+  atomicAdd(&cnt[p], 1);
+  const bool cm = dmut(cam_mut, c), pm = dmut(pt_mut, p);
+  if (!cm && !pm) return;
+  if (pm) pu[p] = 1;
+  if (cm) {
+    cu[c] = 1;
+    const int m = model_of_cam[c];
+    if (dmut(model_mut, m)) mu[m] = 1;
+  }
+}
+
+// cameras that share an eliminated point (0/1 matrix over the graph nodes)
+__global__ __launch_bounds__(256) void k_adjacency(int Np, const int* __restrict__ run_first, const int* __restrict__ obs_cam,
+                                                    const uint8_t* __restrict__ pt_mut, const int* __restrict__ gnode, int ng,
+                                                    uint8_t* __restrict__ adjb) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Np || !dmut(pt_mut, p)) return;
+  const int f = run_first[p], l = run_first[p + 1];
+  for (int e1 = f; e1 < l; e1++) {
+    const int a = gnode[obs_cam[e1]];
+    if (a < 0) continue;
+    for (int e2 = f; e2 < l; e2++) {
+      const int b = gnode[obs_cam[e2]];
+      if (b >= 0 && b != a) adjb[(size_t)a * ng + b] = 1;
+    }
+  }
+}
+
+// sort key of an eliminated point: its smallest camera blocks (4 x 16 bits, or 3 x 21 bits past 65535 blocks)
+__global__ __launch_bounds__(256) void k_point_keys(int Np, const uint8_t* __restrict__ pu, const int* __restrict__ pu_pos,
+                                                     const int* __restrict__ run_first, const int* __restrict__ obs_cam,
+                                                     const int* __restrict__ cam_slot, int wide, unsigned long long* __restrict__ keys,
+                                                     int* __restrict__ vals) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Np || !pu[p]) return;
+  const int nk = wide ? 3 : 4, bits = wide ? 21 : 16;
+  const int none = (1 << bits) - 1;
+  int best[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  for (int e = run_first[p]; e < run_first[p + 1]; e++) {
+    int v = cam_slot[obs_cam[e]];
+    if (v < 0) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {   // sorted insert (duplicates kept, as the host's sorted list keeps them)
+      const int lo = min(best[j], v);
+      v = max(best[j], v);
+      best[j] = lo;
+    }
+  }
+  unsigned long long k = 0;
+  for (int q = 0; q < nk; q++) k = (k << bits) | (unsigned long long)(best[q] == 0x7fffffff ? none : best[q]);
+  keys[pu_pos[p]] = k;
+  vals[pu_pos[p]] = p;
+}
+
+__global__ __launch_bounds__(256) void k_compact_used(int Np, const uint8_t* __restrict__ pu, const int* __restrict__ pu_pos, int* __restrict__ vals) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < Np && pu[p]) vals[pu_pos[p]] = p;
+}
+__global__ __launch_bounds__(256) void k_u8_to_int(int n, const uint8_t* __restrict__ a, int* __restrict__ b) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = a[i] ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_point_lengths(int npb, const int* __restrict__ pb_pt, const int* __restrict__ cnt, int* __restrict__ len,
+                                                        int* __restrict__ pt_slot) {
+  const int pb = blockIdx.x * 256 + threadIdx.x;
+  if (pb >= npb) return;
+  const int p = pb_pt[pb];
+  len[pb] = cnt[p];
+  pt_slot[p] = pb;
+}
+
+struct RowOut { int *o_cam, *o_model, *o_pt, *o_cb, *o_mb, *o_pb; double *o_x, *o_y, *o_w; };
+
+// point-major rows of the eliminated points: row i of block pb is observation run_first[p] + (i - pt_first[pb])
+__global__ __launch_bounds__(256) void k_fill_rows(int AE, int npb, const int* __restrict__ pt_first, const int* __restrict__ pb_pt,
+                                                    const int* __restrict__ run_first, const int* __restrict__ obs_cam,
+                                                    const double* __restrict__ obs_xy, const double* __restrict__ ptw,
+                                                    const int* __restrict__ model_of_cam, const uint8_t* __restrict__ cam_mut,
+                                                    const uint8_t* __restrict__ model_mut, const int* __restrict__ cam_slot,
+                                                    const int* __restrict__ model_slot, RowOut R, int* __restrict__ cam_hist) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= AE) return;
+  int lo = 0, hi = npb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pt_first[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  const int pb = lo, p = pb_pt[pb], o = run_first[p] + (i - pt_first[pb]);
+  const int c = obs_cam[o], m = model_of_cam[c];
+  const bool cm = dmut(cam_mut, c);
+  const int cb = cm ? cam_slot[c] : -1;
+  R.o_cam[i] = c; R.o_model[i] = m; R.o_pt[i] = p;
+  R.o_cb[i] = cb;
+  R.o_mb[i] = (cm && dmut(model_mut, m)) ? model_slot[m] : -1;
+  R.o_pb[i] = pb;
+  R.o_x[i] = obs_xy[2 * (size_t)o]; R.o_y[i] = obs_xy[2 * (size_t)o + 1];
+  R.o_w[i] = ptw ? ptw[p] : 1.0;
+  if (cb >= 0) atomicAdd(&cam_hist[cb], 1);
+}
+
+// observations of frozen points by free cameras, in input order (only with a point mask)
+__global__ __launch_bounds__(256) void k_flag_frozen(int No, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+                                                      const uint8_t* __restrict__ cam_mut, const uint8_t* __restrict__ pt_mut, int* __restrict__ flag) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o < No) flag[o] = (!dmut(pt_mut, obs_pt[o]) && dmut(cam_mut, obs_cam[o])) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_fill_frozen(int No, int AE, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                      const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+                                                      const double* __restrict__ obs_xy, const double* __restrict__ ptw,
+                                                      const int* __restrict__ model_of_cam, const uint8_t* __restrict__ model_mut,
+                                                      const int* __restrict__ cam_slot, const int* __restrict__ model_slot, RowOut R,
+                                                      int* __restrict__ cam_hist) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= No || !flag[o]) return;
+  const int i = AE + pos[o];
+  const int c = obs_cam[o], p = obs_pt[o], m = model_of_cam[c];
+  R.o_cam[i] = c; R.o_model[i] = m; R.o_pt[i] = p;
+  R.o_cb[i] = cam_slot[c];
+  R.o_mb[i] = dmut(model_mut, m) ? model_slot[m] : -1;
+  R.o_pb[i] = -1;
+  R.o_x[i] = obs_xy[2 * (size_t)o]; R.o_y[i] = obs_xy[2 * (size_t)o + 1];
+  R.o_w[i] = ptw ? ptw[p] : 1.0;
+  if (cam_slot[c] >= 0) atomicAdd(&cam_hist[cam_slot[c]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_row_keys(int A, int ncb, const int* __restrict__ o_cb, int* __restrict__ keys, int* __restrict__ vals) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A) return;
+  keys[i] = o_cb[i] >= 0 ? o_cb[i] : ncb;   // rows without a camera block sort behind every camera
+  vals[i] = i;
+}
+__global__ __launch_bounds__(256) void k_assign_positions(int NCR, const int* __restrict__ sorted_key, const int* __restrict__ sorted_row,
+                                                           const int* __restrict__ o_pb, int* __restrict__ o_cpos, int* __restrict__ cpos_pb) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos >= NCR) return;
+  (void)sorted_key;
+  const int i = sorted_row[pos];
+  o_cpos[i] = pos;
+  cpos_pb[pos] = o_pb[i];
+}
+__global__ __launch_bounds__(256) void k_fill_int(int n, int v, int* __restrict__ p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// the sorted distinct intrinsics blocks of a point's rows: pass 0 counts, pass 1 writes pm_mb and o_pm
+__global__ __launch_bounds__(256) void k_pm_entries(int npb, const int* __restrict__ pt_first, const int* __restrict__ o_mb, int pass,
+                                                     int* __restrict__ pm_count, const int* __restrict__ pm_first, int* __restrict__ pm_mb,
+                                                     int* __restrict__ o_pm, int* __restrict__ err) {
+  const int pb = blockIdx.x * 256 + threadIdx.x;
+  if (pb >= npb) return;
+  int tmp[64];
+  int nt = 0;
+  for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++) {
+    const int mb = o_mb[i];
+    if (mb < 0) continue;
+    bool seen = false;
+    for (int k = 0; k < nt; k++) seen |= tmp[k] == mb;
+    if (!seen) {
+      if (nt == 64) { atomicMin(err, pb); nt = -1; break; }
+      tmp[nt++] = mb;
+    }
+  }
+  if (pass == 0) { pm_count[pb] = nt < 0 ? 0 : nt; return; }
+  if (nt < 0) return;
+  for (int a = 1; a < nt; a++) {   // insertion sort
+    const int v = tmp[a];
+    int b = a - 1;
+    while (b >= 0 && tmp[b] > v) { tmp[b + 1] = tmp[b]; b--; }
+    tmp[b + 1] = v;
+  }
+  const int base = pm_first[pb];
+  for (int k = 0; k < nt; k++) pm_mb[base + k] = tmp[k];
+  for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++)
+    if (o_mb[i] >= 0)
+      for (int k = 0; k < nt; k++) if (tmp[k] == o_mb[i]) o_pm[i] = base + k;
+}
+
+// ---- block-pair lists ------------------------------------------------------------------------
+// kind 0: camera x camera (row block >= column block), 1: intrinsics x camera, 2: intrinsics x intrinsics (row >= column);
+// a point's entries in the order of the host loops (i outer, j inner), points in block order.
+template <int KIND, bool EMIT>
+__global__ __launch_bounds__(256) void k_pairs_of_points(int npb, const int* __restrict__ pt_first, const int* __restrict__ o_cb,
+                                                          const int* __restrict__ o_cpos, const int* __restrict__ pm_first,
+                                                          const int* __restrict__ pm_mb, long ncol, int* __restrict__ count,
+                                                          const int* __restrict__ offset, int* __restrict__ key, int* __restrict__ pa,
+                                                          int* __restrict__ pbv) {
+  const int pb = blockIdx.x * 256 + threadIdx.x;
+  if (pb >= npb) return;
+  const int f = pt_first[pb], l = pt_first[pb + 1];
+  int n = 0;
+  const int base = EMIT ? offset[pb] : 0;
+  auto emit = [&](int r, int c, int a, int b) {
+    if (EMIT) {
+      const int k = (int)((long)r * ncol + c);
+      key[base + n] = k; pa[base + n] = a; pbv[base + n] = b;
+    }
+    n++;
+  };
+  if (KIND == 0) {
+    for (int i = f; i < l; i++) {
+      if (o_cpos[i] < 0) continue;
+      for (int j = f; j < l; j++) {
+        if (o_cpos[j] < 0) continue;
+        if (o_cb[i] >= o_cb[j]) emit(o_cb[i], o_cb[j], o_cpos[i], o_cpos[j]);
+      }
+    }
+  } else if (KIND == 1) {
+    for (int e = pm_first[pb]; e < pm_first[pb + 1]; e++)
+      for (int j = f; j < l; j++) if (o_cpos[j] >= 0) emit(pm_mb[e], o_cb[j], e, o_cpos[j]);
+  } else {
+    for (int e = pm_first[pb]; e < pm_first[pb + 1]; e++)
+      for (int g = pm_first[pb]; g <= e; g++) emit(pm_mb[e], pm_mb[g], e, g);
+  }
+  if (!EMIT) count[pb] = n;
+}
+// first entry of every key in the sorted key array (lower bound), and from that the entries per key: no atomics, so a
+// list whose entries all share one key (one intrinsics block: 200k entries) costs the same as any other
+__global__ __launch_bounds__(256) void k_key_first(long nkey, int total, const int* __restrict__ key_sorted, int* __restrict__ key_first) {
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  if (k > nkey) return;
+  int lo = 0, hi = total;   // first position with key_sorted[pos] >= k
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (key_sorted[mid] < (int)k) lo = mid + 1; else hi = mid;
+  }
+  key_first[k] = lo;
+}
+__global__ __launch_bounds__(256) void k_key_hist(long nkey, const int* __restrict__ key_first, int* __restrict__ key_hist) {
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  if (k <= nkey) key_hist[k] = k < nkey ? key_first[k + 1] - key_first[k] : 0;
+}
+__global__ __launch_bounds__(256) void k_iota(int n, int* __restrict__ p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+__global__ __launch_bounds__(256) void k_gather2(int n, const int* __restrict__ perm, const int* __restrict__ a, const int* __restrict__ b,
+                                                  int* __restrict__ a2, int* __restrict__ b2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { a2[i] = a[perm[i]]; b2[i] = b[perm[i]]; }
+}
+// a block exists if it has entries or must be assembled from the F^T F terms alone
+__global__ __launch_bounds__(256) void k_block_flags(long nkey, long ncol, int kind, const int* __restrict__ key_hist, const int* __restrict__ cb_mb,
+                                                      int* __restrict__ flag, int* __restrict__ nchunk) {
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nkey) return;
+  const long r = k / ncol, c = k % ncol;
+  const bool force = kind == 1 ? (cb_mb[c] == r) : (r == c);
+  const int n = key_hist[k];
+  flag[k] = (n > 0 || force) ? 1 : 0;
+  nchunk[k] = (n + CHUNK - 1) / CHUNK;
+}
+__global__ __launch_bounds__(256) void k_block_lists(long nkey, long ncol, const int* __restrict__ flag, const int* __restrict__ blk_of_key,
+                                                      const int* __restrict__ key_first, const int* __restrict__ key_hist,
+                                                      const int* __restrict__ chunk_first_of_key, int* __restrict__ blk_row, int* __restrict__ blk_col,
+                                                      int* __restrict__ blk_chunk_first, int* __restrict__ ch_start, int* __restrict__ ch_end) {
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nkey || !flag[k]) return;
+  const int b = blk_of_key[k];
+  blk_row[b] = (int)(k / ncol);
+  blk_col[b] = (int)(k % ncol);
+  const int cf = chunk_first_of_key[k];
+  blk_chunk_first[b] = cf;
+  const int e0 = key_first[k], n = key_hist[k];
+  for (int q = 0, e = e0; e < e0 + n; e += CHUNK, q++) { ch_start[cf + q] = e; ch_end[cf + q] = min(e + CHUNK, e0 + n); }
+}
+
+}  // namespace devsetup
+
+#define DTRY(expr) HIP_TRY(ctx, (expr))
+template <int KIND>
+static int build_pairs_device(msfm_ctx* ctx, msfm_ba* ba, PairJobs& J, int nout, const int* d_pt_first, const int* d_pm_first, const int* d_pm_mb,
+                              DevBuf<char>& tmp, bool want_host_blocks) {
+  using namespace devsetup;
+  hipStream_t s = ctx->stream;
+  const int npb = ba->npb, ncb = ba->ncb, nmb = ba->nmb;
+  const long nrow = KIND == 0 ? ncb : nmb, ncol = KIND == 2 ? nmb : ncb;
+  const long nkey = nrow * ncol;
+  J.n_pairs = J.n_chunks = J.n_blocks = 0;
+  J.h_row.clear(); J.h_col.clear();
+  if (nkey == 0) {
+    DTRY(J.pa.alloc(1)); DTRY(J.pb.alloc(1)); DTRY(J.ch_start.alloc(1)); DTRY(J.ch_end.alloc(1)); DTRY(J.blk_row.alloc(1)); DTRY(J.blk_col.alloc(1));
+    DTRY(J.blk_chunk_first.alloc(1)); DTRY(hipMemsetAsync(J.blk_chunk_first.p, 0, sizeof(int), s)); DTRY(J.partial.alloc(nout));
+    return MSFM_OK;
+  }
+  if (nkey > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_NOMEM, "block key space too large");
+  DevBuf<int> count, offset, key, pa, pbv, key_hist, key_sorted, perm, perm_sorted, key_first, flag, nchunk, blk_of_key, chunk_first;
+  const int nb_p = cdiv(std::max(1, npb), 256);
+  DTRY(count.alloc((size_t)npb + 1)); DTRY(offset.alloc((size_t)npb + 1));
+  DTRY(hipMemsetAsync(count.p, 0, sizeof(int) * ((size_t)npb + 1), s));
+  if (npb) hipLaunchKernelGGL((k_pairs_of_points<KIND, false>), dim3(nb_p), dim3(256), 0, s, npb, d_pt_first, ba->o_cb.p, ba->o_cpos.p, d_pm_first, d_pm_mb,
+                              ncol, count.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+  DTRY(excl_scan(count.p, offset.p, (size_t)npb + 1, s, tmp));
+  int total = 0;
+  DTRY(hipMemcpyAsync(&total, offset.p + npb, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  if (total < 0) return msfm_set_error(ctx, MSFM_E_NOMEM, "pair list too long");
+  const size_t nt = (size_t)std::max(1, total);
+  DTRY(key.alloc(nt)); DTRY(pa.alloc(nt)); DTRY(pbv.alloc(nt)); DTRY(key_hist.alloc((size_t)nkey + 1)); DTRY(key_first.alloc((size_t)nkey + 1));
+  if (npb && total) hipLaunchKernelGGL((k_pairs_of_points<KIND, true>), dim3(nb_p), dim3(256), 0, s, npb, d_pt_first, ba->o_cb.p, ba->o_cpos.p, d_pm_first,
+                                       d_pm_mb, ncol, (int*)nullptr, offset.p, key.p, pa.p, pbv.p);
+  // entries sorted by block key, point order kept inside a block (stable)
+  DTRY(J.pa.alloc(nt)); DTRY(J.pb.alloc(nt)); DTRY(key_sorted.alloc(nt));
+  if (total) {
+    DTRY(perm.alloc(nt)); DTRY(perm_sorted.alloc(nt));
+    hipLaunchKernelGGL(k_iota, dim3(cdiv(total, 256)), dim3(256), 0, s, total, perm.p);
+    DTRY(sort_pairs(key.p, key_sorted.p, perm.p, perm_sorted.p, (size_t)total, bits_for(nkey), s, tmp));
+    hipLaunchKernelGGL(k_gather2, dim3(cdiv(total, 256)), dim3(256), 0, s, total, perm_sorted.p, pa.p, pbv.p, J.pa.p, J.pb.p);
+  }
+  hipLaunchKernelGGL(k_key_first, dim3(cdiv(nkey + 1, 256)), dim3(256), 0, s, nkey, total, key_sorted.p, key_first.p);
+  hipLaunchKernelGGL(k_key_hist, dim3(cdiv(nkey + 1, 256)), dim3(256), 0, s, nkey, key_first.p, key_hist.p);
+  // blocks and chunks
+  DTRY(flag.alloc((size_t)nkey + 1)); DTRY(nchunk.alloc((size_t)nkey + 1)); DTRY(blk_of_key.alloc((size_t)nkey + 1)); DTRY(chunk_first.alloc((size_t)nkey + 1));
+  DTRY(hipMemsetAsync(flag.p + nkey, 0, sizeof(int), s)); DTRY(hipMemsetAsync(nchunk.p + nkey, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_block_flags, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, KIND, key_hist.p, ba->cb_mb.p, flag.p, nchunk.p);
+  DTRY(excl_scan(flag.p, blk_of_key.p, (size_t)nkey + 1, s, tmp));
+  DTRY(excl_scan(nchunk.p, chunk_first.p, (size_t)nkey + 1, s, tmp));
+  int nbc[2] = {0, 0};
+  DTRY(hipMemcpyAsync(&nbc[0], blk_of_key.p + nkey, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipMemcpyAsync(&nbc[1], chunk_first.p + nkey, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  J.n_pairs = total; J.n_blocks = nbc[0]; J.n_chunks = nbc[1];
+  DTRY(J.blk_row.alloc((size_t)std::max(1, J.n_blocks))); DTRY(J.blk_col.alloc((size_t)std::max(1, J.n_blocks)));
+  DTRY(J.blk_chunk_first.alloc((size_t)J.n_blocks + 1));
+  DTRY(J.ch_start.alloc((size_t)std::max(1, J.n_chunks))); DTRY(J.ch_end.alloc((size_t)std::max(1, J.n_chunks)));
+  hipLaunchKernelGGL(k_block_lists, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, flag.p, blk_of_key.p, key_first.p, key_hist.p, chunk_first.p,
+                     J.blk_row.p, J.blk_col.p, J.blk_chunk_first.p, J.ch_start.p, J.ch_end.p);
+  DTRY(hipMemcpyAsync(J.blk_chunk_first.p + J.n_blocks, &J.n_chunks, sizeof(int), hipMemcpyHostToDevice, s));
+  DTRY(J.partial.alloc((size_t)std::max(1, J.n_chunks) * nout));
+  if (want_host_blocks && J.n_blocks) {
+    J.h_row.resize(J.n_blocks); J.h_col.resize(J.n_blocks);
+    DTRY(hipMemcpyAsync(J.h_row.data(), J.blk_row.p, sizeof(int) * J.n_blocks, hipMemcpyDeviceToHost, s));
+    DTRY(hipMemcpyAsync(J.h_col.data(), J.blk_col.p, sizeof(int) * J.n_blocks, hipMemcpyDeviceToHost, s));
+  }
+  DTRY(hipGetLastError());
+  DTRY(hipStreamSynchronize(s));   // the host copy of n_chunks and the temporaries go out of scope
+  return MSFM_OK;
+}
+
+// Everything msfm_ba_create needs between the caller's arrays and the allocation of the work buffers, on the device.
+static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba* ba, const std::function<void(const char*)>& lap) {
+  using namespace devsetup;
+  hipStream_t s = ctx->stream;
+  const int Nc = ba->Nc = P->n_cams, Nm = ba->Nm = P->n_models, Np = ba->Np = P->n_points, No = P->n_obs;
+  DevBuf<char> tmp;
+  // ---- the caller's arrays (the only bulk PCIe traffic of the set-up) ----
+  DevBuf<int> d_obs_cam, d_obs_pt, d_model_of_cam;
+  DevBuf<double> d_obs_xy, d_ptw;
+  DevBuf<uint8_t> d_cam_mut, d_model_mut, d_pt_mut;
+  DTRY(d_obs_cam.alloc((size_t)std::max(1, No))); DTRY(d_obs_pt.alloc((size_t)std::max(1, No))); DTRY(d_obs_xy.alloc(2 * (size_t)std::max(1, No)));
+  DTRY(d_model_of_cam.alloc(Nc));
+  if (No) {
+    DTRY(d_obs_cam.upload(P->obs_cam, No, s)); DTRY(d_obs_pt.upload(P->obs_pt, No, s)); DTRY(d_obs_xy.upload(P->obs_xy, 2 * (size_t)No, s));
+  }
+  DTRY(d_model_of_cam.upload(P->cam_model_of_cam, Nc, s));
+  if (P->pt_weight && Np) { DTRY(d_ptw.alloc(Np)); DTRY(d_ptw.upload(P->pt_weight, Np, s)); }
+  if (P->cam_mutable) { DTRY(d_cam_mut.alloc(Nc)); DTRY(d_cam_mut.upload(P->cam_mutable, Nc, s)); }
+  if (P->model_mutable) { DTRY(d_model_mut.alloc(Nm)); DTRY(d_model_mut.upload(P->model_mutable, Nm, s)); }
+  if (P->pt_mutable && Np) { DTRY(d_pt_mut.alloc(Np)); DTRY(d_pt_mut.upload(P->pt_mutable, Np, s)); }
+  // ---- validation, block usage, observations per point ----
+  DevBuf<uint8_t> d_cu, d_mu, d_pu;
+  DevBuf<int> d_cnt, d_run_first, d_err;
+  DTRY(d_cu.alloc(Nc)); DTRY(d_mu.alloc(Nm)); DTRY(d_pu.alloc((size_t)std::max(1, Np)));
+  DTRY(d_cnt.alloc((size_t)Np + 1)); DTRY(d_run_first.alloc((size_t)Np + 1)); DTRY(d_err.alloc(4));
+  DTRY(hipMemsetAsync(d_cu.p, 0, Nc, s)); DTRY(hipMemsetAsync(d_mu.p, 0, Nm, s)); DTRY(hipMemsetAsync(d_pu.p, 0, (size_t)std::max(1, Np), s));
+  DTRY(hipMemsetAsync(d_cnt.p, 0, sizeof(int) * ((size_t)Np + 1), s));
+  DTRY(hipMemsetAsync(d_err.p, 0x7f, sizeof(int) * 4, s));
+  if (No) hipLaunchKernelGGL(k_scan_obs, dim3(cdiv(No, 256)), dim3(256), 0, s, No, Nc, Np, d_obs_cam.p, d_obs_pt.p, d_model_of_cam.p, d_cam_mut.p,
+                             d_model_mut.p, d_pt_mut.p, d_cu.p, d_mu.p, d_pu.p, d_cnt.p, d_err.p);
+  DTRY(excl_scan(d_cnt.p, d_run_first.p, (size_t)Np + 1, s, tmp));
+  std::vector<uint8_t> cu(Nc), mu(Nm);
+  int err[4];
+  DTRY(hipMemcpyAsync(cu.data(), d_cu.p, Nc, hipMemcpyDeviceToHost, s));
+  DTRY(hipMemcpyAsync(mu.data(), d_mu.p, Nm, hipMemcpyDeviceToHost, s));
+  DTRY(hipMemcpyAsync(err, d_err.p, sizeof err, hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  if (err[0] < 0x7f7f7f7f && (err[1] == 0x7f7f7f7f || err[0] <= err[1])) return msfm_set_error(ctx, MSFM_E_INVAL, "observation %d: index out of range", err[0]);
+  if (err[1] < 0x7f7f7f7f) return msfm_set_error(ctx, MSFM_E_INVAL, "obs_pt must be non-decreasing (gather order, optimizer.cc:62)");
+  lap("uploaded + scanned");
+  // ---- slots of the camera / intrinsics blocks (host: O(cameras)) ----
+  if (P->gps_xyz) for (int c = 0; c < Nc; c++) if (is_mut(P->cam_mutable, c)) cu[c] = 1;
+  if (ctx->world > 1)
+    for (int c = 0; c < Nc; c++) if (is_mut(P->cam_mutable, c)) { cu[c] = 1; if (is_mut(P->model_mutable, P->cam_model_of_cam[c])) mu[P->cam_model_of_cam[c]] = 1; }
+  std::vector<int> cam_slot(Nc, -1), model_slot(Nm, -1);
+  for (int m = 0; m < Nm; m++) if (mu[m]) { model_slot[m] = ba->nmb++; ba->h_mb_model.push_back(m); }
+  std::vector<int> gnode(Nc, -1), gcam;
+  for (int c = 0; c < Nc; c++) if (cu[c]) { gnode[c] = (int)gcam.size(); gcam.push_back(c); }
+  const int ng = (int)gcam.size();
+  std::vector<int> label(ng, 0);
+  int K = 1;
+  const char* env = getenv("MSFM_CHOL_DOMAINS");
+  const int force = env ? atoi(env) : -1;
+  if (ng >= 128 && ng <= 4096 && force != 0) {
+    DevBuf<int> d_gnode;
+    DevBuf<uint8_t> d_adj;
+    DTRY(d_gnode.from(gnode, s));
+    DTRY(d_adj.alloc((size_t)ng * ng));
+    DTRY(hipMemsetAsync(d_adj.p, 0, (size_t)ng * ng, s));
+    if (Np) hipLaunchKernelGGL(k_adjacency, dim3(cdiv(Np, 256)), dim3(256), 0, s, Np, d_run_first.p, d_obs_cam.p, d_pt_mut.p, d_gnode.p, ng, d_adj.p);
+    std::vector<uint8_t> adjb((size_t)ng * ng);
+    DTRY(hipMemcpyAsync(adjb.data(), d_adj.p, adjb.size(), hipMemcpyDeviceToHost, s));
+    DTRY(hipStreamSynchronize(s));
+    if (ctx->world > 1) {   // the graph must be the same on every rank: max-reduce over the ranks' shards
+      std::vector<double> adjm(adjb.size());
+      for (size_t k = 0; k < adjm.size(); k++) adjm[k] = adjb[k] ? 1.0 : 0.0;
+      DevBuf<double> dadj;
+      DTRY(dadj.from(adjm, s));
+      DTRY(hipStreamSynchronize(s));
+      const int rc = ctx->allreduce(ctx->allreduce_user, dadj.p, adjm.size(), MSFM_REDUCE_MAX, (void*)s);
+      if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce hook failed: %d", rc);
+      DTRY(hipMemcpyAsync(adjm.data(), dadj.p, sizeof(double) * adjm.size(), hipMemcpyDeviceToHost, s));
+      DTRY(hipStreamSynchronize(s));
+      for (size_t k = 0; k < adjm.size(); k++) adjb[k] = adjm[k] != 0.0;
+    }
+    CamGraph G;
+    G.n = ng;
+    G.adj.resize(ng);
+    for (int a = 0; a < ng; a++)
+      for (int b = 0; b < ng; b++) if (adjb[(size_t)a * ng + b]) G.adj[a].push_back(b);
+    K = partition_cameras(G, 3 * ba->nmb + 1, force, label);
+    if (getenv("MSFM_VERBOSE") && ctx->rank == 0) {
+      std::vector<int> cntk(K + 1, 0);
+      for (int g = 0; g < ng; g++) cntk[label[g] < 0 ? K : label[g]]++;
+      fprintf(stderr, "msfm: camera graph %d nodes -> %d domain(s):", ng, K);
+      for (int k = 0; k < K; k++) fprintf(stderr, " %d", cntk[k]);
+      fprintf(stderr, "  separator %d\n", K > 1 ? cntk[K] : 0);
+    }
+  }
+  std::vector<int> cb_off_h, padcol_h;
+  int col = 0;
+  for (int k = 0; k < (K > 1 ? K : 1); k++) {
+    const int begin = col;
+    for (int g = 0; g < ng; g++)
+      if (K <= 1 || label[g] == k) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
+    if (K > 1) {
+      while (col % 64) padcol_h.push_back(col++);
+      ba->plan.dom_begin[k] = begin;
+      ba->plan.dom_end[k] = col;
+    }
+  }
+  if (K > 1) {
+    ba->plan.K = K;
+    ba->plan.sep_begin = col;
+    for (int g = 0; g < ng; g++)
+      if (label[g] < 0) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
+  }
+  ba->mo = col;
+  ba->nsys = col + 3 * ba->nmb;
+  ba->n_padcol = (int)padcol_h.size();
+  const int ncb = ba->ncb, nmb = ba->nmb;
+  ba->nred = 6 * ncb + 3 * nmb;
+  ba->npad = 64 * cdiv(ba->nsys + 1, 64);
+  if (ba->plan.K > 1) {
+    ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.sep_begin, 64);
+    DTRY(ba->corners.alloc((size_t)ba->plan.K * ba->plan.ldc * ba->plan.ldc));
+    ba->plan.corners = ba->corners.p;
+  }
+  ba->gps_weight = P->gps_weight;
+  DTRY(ba->cb_off.from(cb_off_h.empty() ? std::vector<int>(1, 0) : cb_off_h, s));
+  DTRY(ba->padcol.from(padcol_h.empty() ? std::vector<int>(1, 0) : padcol_h, s));
+  DevBuf<int> d_cam_slot, d_model_slot;
+  DTRY(d_cam_slot.from(cam_slot, s)); DTRY(d_model_slot.from(model_slot, s));
+  // cameras of each intrinsics block (host, O(cameras))
+  std::vector<int> cb_mb(std::max(1, ncb), -1), mcam_first(nmb + 1, 0), mcam;
+  for (int cb = 0; cb < ncb; cb++) {
+    const int m = P->cam_model_of_cam[ba->h_cb_cam[cb]];
+    cb_mb[cb] = is_mut(P->model_mutable, m) ? model_slot[m] : -1;
+  }
+  for (int mb = 0; mb < nmb; mb++) {
+    mcam_first[mb] = (int)mcam.size();
+    for (int cb = 0; cb < ncb; cb++) if (cb_mb[cb] == mb) mcam.push_back(cb);
+  }
+  mcam_first[nmb] = (int)mcam.size();
+  DTRY(ba->cb_cam.from(ba->h_cb_cam.empty() ? std::vector<int>(1, 0) : ba->h_cb_cam, s));
+  DTRY(ba->mb_model.from(ba->h_mb_model.empty() ? std::vector<int>(1, 0) : ba->h_mb_model, s));
+  DTRY(ba->cb_mb.from(cb_mb, s)); DTRY(ba->mcam_first.from(mcam_first, s));
+  if (!mcam.empty()) DTRY(ba->mcam.from(mcam, s));
+  std::vector<double> gps_cb;
+  ba->has_gps = P->gps_xyz != nullptr;
+  if (ba->has_gps) {
+    gps_cb.resize(3 * (size_t)std::max(1, ncb));
+    for (int cb = 0; cb < ncb; cb++) for (int k = 0; k < 3; k++) gps_cb[3 * (size_t)cb + k] = P->gps_xyz[3 * (size_t)ba->h_cb_cam[cb] + k];
+    DTRY(ba->gps.from(gps_cb, s));
+  }
+  lap("camera order");
+  // ---- order of the eliminated points: by their smallest camera blocks, ties by the caller's index (stable sort) ----
+  DevBuf<int> d_pu_int, d_pu_pos, d_vals, d_vals_sorted, d_pt_slot, d_len;
+  DevBuf<unsigned long long> d_keys, d_keys_sorted;
+  DTRY(d_pu_int.alloc((size_t)Np + 1)); DTRY(d_pu_pos.alloc((size_t)Np + 1));
+  DTRY(hipMemsetAsync(d_pu_int.p + Np, 0, sizeof(int), s));
+  if (Np) hipLaunchKernelGGL(k_u8_to_int, dim3(cdiv(Np, 256)), dim3(256), 0, s, Np, d_pu.p, d_pu_int.p);
+  DTRY(excl_scan(d_pu_int.p, d_pu_pos.p, (size_t)Np + 1, s, tmp));
+  int npb = 0;
+  DTRY(hipMemcpyAsync(&npb, d_pu_pos.p + Np, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  ba->npb = npb;
+  DTRY(ba->pb_pt.alloc((size_t)std::max(1, npb)));
+  const bool order_points = !getenv("MSFM_POINT_ORDER") || atoi(getenv("MSFM_POINT_ORDER")) != 0;
+  if (npb) {
+    if (order_points) {
+      DTRY(d_keys.alloc(npb)); DTRY(d_keys_sorted.alloc(npb)); DTRY(d_vals.alloc(npb));
+      hipLaunchKernelGGL(k_point_keys, dim3(cdiv(Np, 256)), dim3(256), 0, s, Np, d_pu.p, d_pu_pos.p, d_run_first.p, d_obs_cam.p, d_cam_slot.p,
+                         ncb >= 0xFFFF ? 1 : 0, d_keys.p, d_vals.p);
+      DTRY(sort_pairs(d_keys.p, d_keys_sorted.p, d_vals.p, ba->pb_pt.p, (size_t)npb, 64, s, tmp));
+    } else {
+      hipLaunchKernelGGL(k_compact_used, dim3(cdiv(Np, 256)), dim3(256), 0, s, Np, d_pu.p, d_pu_pos.p, ba->pb_pt.p);
+    }
+  }
+  DTRY(d_pt_slot.alloc((size_t)std::max(1, Np))); DTRY(d_len.alloc((size_t)npb + 1)); DTRY(ba->pt_first.alloc((size_t)npb + 1));
+  DTRY(hipMemsetAsync(d_len.p + npb, 0, sizeof(int), s));
+  if (npb) hipLaunchKernelGGL(k_point_lengths, dim3(cdiv(npb, 256)), dim3(256), 0, s, npb, ba->pb_pt.p, d_cnt.p, d_len.p, d_pt_slot.p);
+  DTRY(excl_scan(d_len.p, ba->pt_first.p, (size_t)npb + 1, s, tmp));
+  // frozen points seen by free cameras: flags and their ranks
+  DevBuf<int> d_fflag, d_fpos;
+  int n_frozen_rows = 0;
+  if (P->pt_mutable && No) {
+    DTRY(d_fflag.alloc((size_t)No + 1)); DTRY(d_fpos.alloc((size_t)No + 1));
+    DTRY(hipMemsetAsync(d_fflag.p + No, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_flag_frozen, dim3(cdiv(No, 256)), dim3(256), 0, s, No, d_obs_cam.p, d_obs_pt.p, d_cam_mut.p, d_pt_mut.p, d_fflag.p);
+    DTRY(excl_scan(d_fflag.p, d_fpos.p, (size_t)No + 1, s, tmp));
+    DTRY(hipMemcpyAsync(&n_frozen_rows, d_fpos.p + No, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
+  int AE = 0;
+  DTRY(hipMemcpyAsync(&AE, ba->pt_first.p + npb, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  ba->AE = AE;
+  const int A = ba->A = AE + n_frozen_rows;
+  ba->n_residuals = 2 * A + (ba->has_gps ? 3 * ncb : 0);
+  lap("point order");
+  // ---- rows ----
+  const size_t As = (size_t)std::max(1, A);
+  DTRY(ba->o_cam.alloc(As)); DTRY(ba->o_model.alloc(As)); DTRY(ba->o_pt.alloc(As)); DTRY(ba->o_cb.alloc(As)); DTRY(ba->o_mb.alloc(As));
+  DTRY(ba->o_pb.alloc(As)); DTRY(ba->o_cpos.alloc(As)); DTRY(ba->o_pm.alloc(As)); DTRY(ba->o_x.alloc(As)); DTRY(ba->o_y.alloc(As)); DTRY(ba->o_w.alloc(As));
+  DevBuf<int> d_cam_hist, d_cam_first;
+  DTRY(d_cam_hist.alloc((size_t)ncb + 1)); DTRY(d_cam_first.alloc((size_t)ncb + 1));
+  DTRY(hipMemsetAsync(d_cam_hist.p, 0, sizeof(int) * ((size_t)ncb + 1), s));
+  RowOut R{ba->o_cam.p, ba->o_model.p, ba->o_pt.p, ba->o_cb.p, ba->o_mb.p, ba->o_pb.p, ba->o_x.p, ba->o_y.p, ba->o_w.p};
+  if (AE) hipLaunchKernelGGL(k_fill_rows, dim3(cdiv(AE, 256)), dim3(256), 0, s, AE, npb, ba->pt_first.p, ba->pb_pt.p, d_run_first.p, d_obs_cam.p, d_obs_xy.p,
+                             d_ptw.p, d_model_of_cam.p, d_cam_mut.p, d_model_mut.p, d_cam_slot.p, d_model_slot.p, R, d_cam_hist.p);
+  if (n_frozen_rows) hipLaunchKernelGGL(k_fill_frozen, dim3(cdiv(No, 256)), dim3(256), 0, s, No, AE, d_fflag.p, d_fpos.p, d_obs_cam.p, d_obs_pt.p, d_obs_xy.p,
+                                        d_ptw.p, d_model_of_cam.p, d_model_mut.p, d_cam_slot.p, d_model_slot.p, R, d_cam_hist.p);
+  // ---- camera-major positions: stable sort of the rows by camera block ----
+  DTRY(excl_scan(d_cam_hist.p, d_cam_first.p, (size_t)ncb + 1, s, tmp));
+  std::vector<int> cam_first(ncb + 1, 0);
+  DTRY(hipMemcpyAsync(cam_first.data(), d_cam_first.p, sizeof(int) * ((size_t)ncb + 1), hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  const int NCR = ba->NCR = cam_first[ncb];
+  DTRY(ba->cpos_pb.alloc((size_t)std::max(1, NCR)));
+  hipLaunchKernelGGL(k_fill_int, dim3(cdiv(As, 256)), dim3(256), 0, s, (int)As, -1, ba->o_cpos.p);
+  hipLaunchKernelGGL(k_fill_int, dim3(cdiv(As, 256)), dim3(256), 0, s, (int)As, -1, ba->o_pm.p);
+  hipLaunchKernelGGL(k_fill_int, dim3(cdiv(std::max(1, NCR), 256)), dim3(256), 0, s, std::max(1, NCR), -1, ba->cpos_pb.p);
+  if (A && NCR) {
+    DevBuf<int> rk, rv, rks, rvs;
+    DTRY(rk.alloc(A)); DTRY(rv.alloc(A)); DTRY(rks.alloc(A)); DTRY(rvs.alloc(A));
+    hipLaunchKernelGGL(k_row_keys, dim3(cdiv(A, 256)), dim3(256), 0, s, A, ncb, ba->o_cb.p, rk.p, rv.p);
+    DTRY(sort_pairs(rk.p, rks.p, rv.p, rvs.p, (size_t)A, bits_for((long)ncb + 1), s, tmp));
+    hipLaunchKernelGGL(k_assign_positions, dim3(cdiv(NCR, 256)), dim3(256), 0, s, NCR, rks.p, rvs.p, ba->o_pb.p, ba->o_cpos.p, ba->cpos_pb.p);
+    DTRY(hipStreamSynchronize(s));   // the sort buffers go out of scope
+  }
+  lap("rows + camera positions");
+  // ---- (point, intrinsics block) entries ----
+  DevBuf<int> d_pm_count;
+  DTRY(d_pm_count.alloc((size_t)npb + 1)); DTRY(ba->pm_first.alloc((size_t)npb + 1));
+  DTRY(hipMemsetAsync(d_pm_count.p, 0, sizeof(int) * ((size_t)npb + 1), s));
+  DTRY(hipMemsetAsync(d_err.p, 0x7f, sizeof(int) * 4, s));
+  if (npb) hipLaunchKernelGGL(k_pm_entries, dim3(cdiv(npb, 256)), dim3(256), 0, s, npb, ba->pt_first.p, ba->o_mb.p, 0, d_pm_count.p, (const int*)nullptr,
+                              (int*)nullptr, (int*)nullptr, d_err.p);
+  DTRY(excl_scan(d_pm_count.p, ba->pm_first.p, (size_t)npb + 1, s, tmp));
+  int NPM = 0;
+  DTRY(hipMemcpyAsync(&NPM, ba->pm_first.p + npb, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipMemcpyAsync(err, d_err.p, sizeof err, hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  if (err[0] < 0x7f7f7f7f) return msfm_set_error(ctx, MSFM_E_INVAL, "a point touches more than 64 intrinsics blocks");
+  ba->NPM = NPM;
+  DTRY(ba->pm_mb.alloc((size_t)std::max(1, NPM)));
+  if (npb && NPM) hipLaunchKernelGGL(k_pm_entries, dim3(cdiv(npb, 256)), dim3(256), 0, s, npb, ba->pt_first.p, ba->o_mb.p, 1, d_pm_count.p, ba->pm_first.p,
+                                     ba->pm_mb.p, ba->o_pm.p, d_err.p);
+  // ---- FTF chunks (host: O(cameras + rows / 1024)) ----
+  std::vector<int> f_start, f_end, cam_chunk_first(ncb + 1, 0);
+  for (int c = 0; c < ncb; c++) {
+    cam_chunk_first[c] = (int)f_start.size();
+    for (int e = cam_first[c]; e < cam_first[c + 1]; e += CHUNK) { f_start.push_back(e); f_end.push_back(std::min(e + CHUNK, cam_first[c + 1])); }
+  }
+  cam_chunk_first[ncb] = (int)f_start.size();
+  ba->n_fchunks = (int)f_start.size();
+  DTRY(ba->f_start.from(f_start.empty() ? std::vector<int>(1, 0) : f_start, s));
+  DTRY(ba->f_end.from(f_end.empty() ? std::vector<int>(1, 0) : f_end, s));
+  DTRY(ba->cam_chunk_first.from(cam_chunk_first, s));
+  DTRY(hipStreamSynchronize(s));
+  lap("entries + chunks");
+  // ---- block-pair lists ----
+  const bool want_blocks = ctx->world > 1;
+  MSFM_TRY((build_pairs_device<0>(ctx, ba, ba->cc, 36, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, want_blocks)));
+  lap("pairs cc");
+  MSFM_TRY((build_pairs_device<1>(ctx, ba, ba->mc, 18, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, false)));
+  MSFM_TRY((build_pairs_device<2>(ctx, ba, ba->mm, 12, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, false)));
+  lap("pairs mc mm");
+  return MSFM_OK;
+}
+#undef DTRY
+
+// The same structures built by host threads (MSFM_CREATE_HOST=1): the first implementation, kept as the reference the
+// device build is compared with bit for bit (tests/test_gpu_ba.py).
+static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba* ba, const std::function<void(const char*)>& lap) {
+  hipStream_t s = ctx->stream;
   {
     const int nt = host_threads();
     std::vector<long> bad_range(nt, -1), bad_order(nt, -1);
@@ -1160,20 +1798,6 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
       if (bad_order[t] >= 0) return msfm_set_error(ctx, MSFM_E_INVAL, "obs_pt must be non-decreasing (gather order, optimizer.cc:62)");
     }
   }
-  const auto t0 = std::chrono::steady_clock::now();
-  const bool verbose = getenv("MSFM_VERBOSE") != nullptr;
-  if (verbose) fprintf(stderr, "msfm: create input checked after     %7.2f ms (from entry)\n", std::chrono::duration<double, std::milli>(t0 - exit_lap.t).count());
-  auto lap = [&](const char* what) {
-    if (verbose && ctx->rank == 0)
-      fprintf(stderr, "msfm: create %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-  };
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  msfm_ba* ba = new msfm_ba();
-  struct Guard { msfm_ba* p; ~Guard() { if (p) msfm_ba_destroy(p); } } guard{ba};
-  ba->ctx = ctx;
-  ctx->children++;
-  ba->world_at_create = ctx->world;
   const int Nc = ba->Nc = P->n_cams, Nm = ba->Nm = P->n_models, Np = ba->Np = P->n_points, No = P->n_obs;
   // ---- which parameter blocks exist (a block exists iff some residual uses it) ----
   BaScratch& H = ba_scratch(ctx);
@@ -1582,6 +2206,44 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   MSFM_TRY(build_pairs(1, ba->mc, 18));
   MSFM_TRY(build_pairs(2, ba->mm, 12));
   lap("pairs mc mm");
+  return MSFM_OK;
+}
+
+MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** out) {
+  if (!ctx || !P || !out) return MSFM_E_INVAL;
+  *out = nullptr;
+  struct ExitLap {   // declared first, destroyed last: the time to the very end of the call, host vectors released
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    bool on = getenv("MSFM_VERBOSE") != nullptr;
+    ~ExitLap() { if (on) fprintf(stderr, "msfm: create returned after          %7.2f ms (from entry)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); }
+  } exit_lap;
+  if (P->n_cams <= 0 || P->n_models <= 0 || P->n_points < 0 || P->n_obs < 0 || !P->cam_pose || !P->cam_model ||
+      !P->cam_model_of_cam || (P->n_points > 0 && !P->point) ||
+      (P->n_obs > 0 && (!P->obs_cam || !P->obs_pt || !P->obs_xy)))
+    return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_ba_create: null or empty problem arrays");
+  for (int c = 0; c < P->n_cams; c++)
+    if (P->cam_model_of_cam[c] < 0 || P->cam_model_of_cam[c] >= P->n_models)
+      return msfm_set_error(ctx, MSFM_E_INVAL, "cam_model_of_cam[%d] out of range", c);
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool verbose = getenv("MSFM_VERBOSE") != nullptr;
+  if (verbose) fprintf(stderr, "msfm: create input checked after     %7.2f ms (from entry)\n", std::chrono::duration<double, std::milli>(t0 - exit_lap.t).count());
+  auto lap = [&](const char* what) {
+    if (verbose && ctx->rank == 0)
+      fprintf(stderr, "msfm: create %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  };
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  msfm_ba* ba = new msfm_ba();
+  struct Guard { msfm_ba* p; ~Guard() { if (p) msfm_ba_destroy(p); } } guard{ba};
+  ba->ctx = ctx;
+  ctx->children++;
+  ba->world_at_create = ctx->world;
+  {
+    const char* e = getenv("MSFM_CREATE_HOST");
+    const bool on_host = e && atoi(e) != 0;
+    MSFM_TRY(on_host ? create_structures_host(ctx, P, ba, lap) : create_structures_device(ctx, P, ba, lap));
+  }
+  const int Nc = ba->Nc, Nm = ba->Nm, Np = ba->Np, ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb, A = ba->A, NCR = ba->NCR, NPM = ba->NPM;
   if (ctx->world > 1 && ncb > 0 && ncb <= 4096) {
     // union over ranks of the camera-camera block structure: a 0/1 matrix, max-reduced once
     std::vector<double> ind((size_t)ncb * ncb, 0.0);

@@ -330,3 +330,34 @@ def test_ba_config5_window_full_size(ctx):
     new = sc.obs_cam == idx
     uvn, _ = scene.project(arr.cam_pose[sc.obs_cam[new]], arr.cam_model[sc.cam_model_of_cam[sc.obs_cam[new]]], arr.point[sc.obs_pt[new]])
     assert np.median(np.linalg.norm(uvn - sc.obs_xy[new], axis=1)) < 0.7
+
+
+def test_device_built_structures_match_the_host_build():
+    """msfm_ba_create builds its index structures on the device (scans, stable radix sorts, small kernels); MSFM_CREATE_HOST=1
+    keeps the first, host-threaded implementation.  Both must produce the same structures, hence bitwise the same solve:
+    a domain-ordered problem, window masks + several intrinsics blocks + GPS, and a tiny degenerate one."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from metricsfm_amd import _abi as A, capi, scene, window\n"
+            "ctx = capi.Context(0)\n"
+            "out = []\n"
+            "sc = scene.make_aerial_scene(140, 6000, seed=11)\n"
+            "a = A.BaArrays.from_scene(sc); r = ctx.ba_solve(a, capi.default_options(max_num_iterations=8))\n"
+            "out.append((repr(r['final_cost']), r['num_iterations'], repr(float(a.cam_pose.sum())), repr(float(a.point.sum())), r['num_residuals'], r['num_reduced_params']))\n"
+            "sc = scene.make_aerial_scene(40, 4000, seed=51, n_models=7, gps_sigma=0.5)\n"
+            "rng = np.random.default_rng(2); cm = (np.arange(40) %% 5 != 0).astype(np.uint8); pm = (rng.random(4000) > 0.2).astype(np.uint8); mm = (np.arange(7) %% 3 != 1).astype(np.uint8)\n"
+            "a = A.BaArrays.from_scene(sc, cam_mutable=cm, pt_mutable=pm, model_mutable=mm, gps_xyz=sc.gps_xyz, gps_weight=60.0); r = ctx.ba_solve(a, capi.default_options(max_num_iterations=8))\n"
+            "out.append((repr(r['final_cost']), r['num_iterations'], repr(float(a.cam_pose.sum())), repr(float(a.point.sum())), repr(float(a.cam_model.sum())), r['num_residuals'], r['num_reduced_params']))\n"
+            "arr, _ = window.partial_bundle_adjustment_problem(sc, 39, gps=True); r = ctx.ba_solve(arr, capi.default_options(max_num_iterations=6))\n"
+            "out.append((repr(r['final_cost']), r['num_iterations'], repr(float(arr.cam_pose.sum())), repr(float(arr.point.sum())), r['num_residuals']))\n"
+            "sc = scene.make_ring_scene(3, 7, seed=2)\n"
+            "a = A.BaArrays.from_scene(sc); r = ctx.ba_solve(a, capi.default_options(max_num_iterations=4))\n"
+            "out.append((repr(r['final_cost']), r['num_iterations'], repr(float(a.cam_pose.sum()))))\n"
+            "print(out)\n") % ROOT
+    outs = []
+    for host in ("0", "1"):
+        env = dict(os.environ, MSFM_CREATE_HOST=host, MSFM_CHOL_DOMAINS="1")
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600))
+        assert outs[-1].returncode == 0, outs[-1].stderr[-3000:]
+    assert outs[0].stdout == outs[1].stdout and outs[0].stdout.strip()
