@@ -246,8 +246,14 @@ typedef struct msfm_ba_layout {
   int system_order;       /* order of the factored matrix: reduced_order + identity padding of the domains */
   int n_domains;          /* mutually uncoupled camera domains whose panel chains share launches */
   int domain_cols[8];     /* columns of each domain (multiples of 64) */
-  int separator_cols;     /* separator cameras + intrinsics */
+  int separator_cols;     /* every separator + intrinsics (everything behind the leaf domains) */
   int panel_launches;     /* panel launches per factorisation */
+  /* the elimination tree behind it: level 0 = the leaf domains above, level 1.. = separators from the deepest cut to
+   * the shallowest (nodes of one level are mutually uncoupled and share launches), then the root chain */
+  int n_levels;
+  int level_nodes[3];
+  int level_begin[3];     /* first column of each level */
+  int root_cols;          /* root separator + intrinsics: the final dense chain */
 } msfm_ba_layout;
 int msfm_ba_get_layout(const msfm_ba* ba, msfm_ba_layout* out);
 

@@ -30,7 +30,8 @@ class BaProblem(C.Structure):
 class BaLayout(C.Structure):
     """msfm_ba_layout (include/msfm.h)."""
     _fields_ = [("reduced_order", C.c_int), ("system_order", C.c_int), ("n_domains", C.c_int), ("domain_cols", C.c_int * 8),
-                ("separator_cols", C.c_int), ("panel_launches", C.c_int)]
+                ("separator_cols", C.c_int), ("panel_launches", C.c_int), ("n_levels", C.c_int), ("level_nodes", C.c_int * 3),
+                ("level_begin", C.c_int * 3), ("root_cols", C.c_int)]
 
 
 class FransacOptions(C.Structure):

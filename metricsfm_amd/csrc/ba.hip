@@ -1019,44 +1019,127 @@ static bool graph_bisect(const CamGraph& G, const std::vector<char>& in, std::ve
   return best >= 0;
 }
 
-static void graph_split(const CamGraph& G, const std::vector<char>& in, int depth, std::vector<std::vector<char>>& doms, std::vector<char>& sep) {
+// Nested dissection of the camera graph to a given depth.  Leaves and separators are collected in tree order (the "a"
+// side of a cut before the "b" side), the separators per depth; every node remembers the interval of leaf indices under it.
+struct NdNode { std::vector<int> cams; int leaf_lo, leaf_hi; };
+struct NdTree {
+  std::vector<NdNode> leaves;
+  std::vector<std::vector<NdNode>> seps;   // seps[d]: separators cut at depth d (seps[0][0] = root separator)
+};
+static void nd_split(const CamGraph& G, const std::vector<char>& in, int depth_left, int d, NdTree& T) {
   std::vector<char> a, b, s;
-  if (depth == 0 || !graph_bisect(G, in, a, b, s)) { doms.push_back(in); return; }
-  for (int i = 0; i < G.n; i++) if (s[i]) sep[i] = 1;
-  graph_split(G, a, depth - 1, doms, sep);
-  graph_split(G, b, depth - 1, doms, sep);
+  auto members = [&](const std::vector<char>& m) { std::vector<int> v; for (int i = 0; i < G.n; i++) if (m[i]) v.push_back(i); return v; };
+  if (depth_left == 0 || !graph_bisect(G, in, a, b, s)) {
+    const int id = (int)T.leaves.size();
+    T.leaves.push_back(NdNode{members(in), id, id});
+    return;
+  }
+  if ((int)T.seps.size() <= d) T.seps.resize(d + 1);
+  const size_t me = T.seps[d].size();
+  T.seps[d].push_back(NdNode{members(s), (int)T.leaves.size(), -1});
+  nd_split(G, a, depth_left - 1, d + 1, T);
+  nd_split(G, b, depth_left - 1, d + 1, T);
+  T.seps[d][me].leaf_hi = (int)T.leaves.size() - 1;
 }
 
-// label[i]: domain 0..K-1 or -1 (separator).  Chooses the depth (0..3) with the shortest estimated chain of
-// 64-column panels, max_k ceil(6 |D_k| / 64) + ceil((6 |S| + tail) / 64); K = 1 means "keep the dense order".
-static int partition_cameras(const CamGraph& G, int tail_cols, int force_depth, std::vector<int>& label) {
+// Chooses the dissection depth (1..3) with the shortest estimated chain of 64-column panel launches: per level the
+// longest node chain plus three launch-equivalents for the level's deferred corner update (one SYRK over all its panels +
+// the merge: measured at config 3, depth 3 has one launch fewer than depth 2 and is 5 % slower), then the root separator
+// with the intrinsics.  Returns false ("keep the dense order") unless a depth is at least 20 % shorter than the dense
+// chain (or one is forced).
+static bool choose_dissection(const CamGraph& G, int tail_cols, int force_depth, NdTree& best_tree) {
   const int n = G.n;
-  label.assign(n, 0);
-  int bestK = 1;
-  long best = cdiv(6L * n + tail_cols, 64);
-  const long dense = best;
+  const long dense = cdiv(6L * n + tail_cols, 64);
+  long best = dense;
+  bool found = false;
   for (int depth = 1; depth <= 3; depth++) {
     if (force_depth >= 0 && depth != force_depth) continue;
-    std::vector<std::vector<char>> doms;
-    std::vector<char> sep(n, 0), all(n, 1);
-    graph_split(G, all, depth, doms, sep);
-    if (doms.size() < 2 || doms.size() > 8) continue;
-    long maxp = 0, nsep = 0;
-    for (auto& d : doms) { long c = 0; for (int i = 0; i < n; i++) c += d[i]; maxp = std::max<long>(maxp, cdiv(6 * c, 64)); }
-    for (int i = 0; i < n; i++) nsep += sep[i];
-    const long chain = maxp + 1 + cdiv(6 * nsep + tail_cols, 64);
-    if (force_depth >= 0 || (chain < best && chain * 10 <= dense * 8)) {  // worth it only if clearly shorter
+    NdTree T;
+    std::vector<char> all(n, 1);
+    nd_split(G, all, depth, 0, T);
+    if (T.leaves.size() < 2 || T.leaves.size() > 8 || T.seps.empty()) continue;
+    bool ok = true;
+    for (size_t d = 1; d < T.seps.size(); d++) ok = ok && T.seps[d].size() <= 8;
+    if (!ok) continue;
+    long chain = 0, maxp = 0;
+    for (auto& l : T.leaves) maxp = std::max<long>(maxp, cdiv(6 * (long)l.cams.size(), 64));
+    chain += maxp + 3;
+    for (size_t d = T.seps.size() - 1; d >= 1; d--) {
+      long mp = 0;
+      for (auto& q : T.seps[d]) mp = std::max<long>(mp, cdiv(6 * (long)q.cams.size(), 64));
+      if (mp) chain += mp + 3;
+    }
+    chain += cdiv(6 * (long)T.seps[0][0].cams.size() + tail_cols, 64);
+    if (force_depth >= 0 || (chain < best && chain * 10 <= dense * 8)) {
       best = chain;
-      bestK = (int)doms.size();
-      for (int i = 0; i < n; i++) label[i] = -1;
-      for (int k = 0; k < bestK; k++)
-        for (int i = 0; i < n; i++) if (doms[k][i]) label[i] = k;
+      best_tree = T;
+      found = true;
     }
   }
-  return bestK;
+  return found;
 }
 
 static bool is_mut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
+
+// Numbers the camera blocks in elimination order and lays the reduced system out: leaves, then the separators from the
+// deepest cut to the shallowest (every node padded with identity columns to a multiple of 64), the root separator and the
+// intrinsics last.  adjb: ng x ng 0/1 adjacency of the graph nodes (cameras sharing an eliminated point), empty = no
+// dissection.  Fills cam_slot, ba->h_cb_cam, ncb, mo, nsys, n_padcol, plan (levels) and the two column lists.
+static void order_camera_blocks(msfm_ctx* ctx, msfm_ba* ba, const std::vector<int>& gcam, const std::vector<uint8_t>& adjb, int force,
+                                std::vector<int>& cam_slot, std::vector<int>& cb_off_h, std::vector<int>& padcol_h) {
+  const int ng = (int)gcam.size();
+  NdTree T;
+  bool dissect = false;
+  if (!adjb.empty()) {
+    CamGraph G;
+    G.n = ng;
+    G.adj.resize(ng);
+    for (int a = 0; a < ng; a++)
+      for (int b = 0; b < ng; b++) if (adjb[(size_t)a * ng + b]) G.adj[a].push_back(b);
+    dissect = choose_dissection(G, 3 * ba->nmb + 1, force, T);
+  }
+  int col = 0;
+  auto place = [&](int g) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; };
+  ba->plan = msfm_chol_plan();
+  if (!dissect) {
+    for (int g = 0; g < ng; g++) place(g);
+  } else {
+    // levels: 0 = leaves, then the separators of depth D-1, ..., 1; depth 0 is the root chain
+    std::vector<std::vector<NdNode>*> levels;
+    levels.push_back(&T.leaves);
+    for (int d = (int)T.seps.size() - 1; d >= 1; d--) if (!T.seps[d].empty()) levels.push_back(&T.seps[d]);
+    int nl = 0;
+    for (auto* lv : levels) {
+      msfm_chol_level& L = ba->plan.level[nl];
+      L.K = 0;
+      L.begin = col;
+      for (auto& node : *lv) {
+        if (node.cams.empty()) continue;   // a cut without separator nodes (disconnected parts)
+        const int begin = col;
+        for (int g : node.cams) place(g);
+        while (col % 64) padcol_h.push_back(col++);
+        L.node[L.K++] = msfm_chol_node{begin, col, node.leaf_lo, node.leaf_hi};
+      }
+      L.b0 = col;
+      if (L.K > 0) nl++;
+    }
+    ba->plan.n_levels = nl;
+    for (int g : T.seps[0][0].cams) place(g);
+    if (getenv("MSFM_VERBOSE") && ctx->rank == 0) {
+      fprintf(stderr, "msfm: camera graph %d nodes ->", ng);
+      for (int l = 0; l < nl; l++) {
+        fprintf(stderr, " level %d:", l);
+        for (int k = 0; k < ba->plan.level[l].K; k++) fprintf(stderr, " %d", (ba->plan.level[l].node[k].end - ba->plan.level[l].node[k].begin) / 6);
+        fprintf(stderr, " |");
+      }
+      fprintf(stderr, " root separator %zu cameras\n", T.seps[0][0].cams.size());
+    }
+  }
+  ba->mo = col;
+  ba->nsys = col + 3 * ba->nmb;
+  ba->n_padcol = (int)padcol_h.size();
+}
+
 
 // Build chunk / block lists from pair entries already sorted by block key.
 static int finish_jobs(msfm_ba* ba, PairJobs& J, const std::vector<int>& pa, const std::vector<int>& pb,
@@ -1566,10 +1649,9 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
   std::vector<int> gnode(Nc, -1), gcam;
   for (int c = 0; c < Nc; c++) if (cu[c]) { gnode[c] = (int)gcam.size(); gcam.push_back(c); }
   const int ng = (int)gcam.size();
-  std::vector<int> label(ng, 0);
-  int K = 1;
   const char* env = getenv("MSFM_CHOL_DOMAINS");
   const int force = env ? atoi(env) : -1;
+  std::vector<uint8_t> adjb;
   if (ng >= 128 && ng <= 4096 && force != 0) {
     DevBuf<int> d_gnode;
     DevBuf<uint8_t> d_adj;
@@ -1577,7 +1659,7 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
     DTRY(d_adj.alloc((size_t)ng * ng));
     DTRY(hipMemsetAsync(d_adj.p, 0, (size_t)ng * ng, s));
     if (Np) hipLaunchKernelGGL(k_adjacency, dim3(cdiv(Np, 256)), dim3(256), 0, s, Np, d_run_first.p, d_obs_cam.p, d_pt_mut.p, d_gnode.p, ng, d_adj.p);
-    std::vector<uint8_t> adjb((size_t)ng * ng);
+    adjb.resize((size_t)ng * ng);
     DTRY(hipMemcpyAsync(adjb.data(), d_adj.p, adjb.size(), hipMemcpyDeviceToHost, s));
     DTRY(hipStreamSynchronize(s));
     if (ctx->world > 1) {   // the graph must be the same on every rank: max-reduce over the ranks' shards
@@ -1592,47 +1674,15 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
       DTRY(hipStreamSynchronize(s));
       for (size_t k = 0; k < adjm.size(); k++) adjb[k] = adjm[k] != 0.0;
     }
-    CamGraph G;
-    G.n = ng;
-    G.adj.resize(ng);
-    for (int a = 0; a < ng; a++)
-      for (int b = 0; b < ng; b++) if (adjb[(size_t)a * ng + b]) G.adj[a].push_back(b);
-    K = partition_cameras(G, 3 * ba->nmb + 1, force, label);
-    if (getenv("MSFM_VERBOSE") && ctx->rank == 0) {
-      std::vector<int> cntk(K + 1, 0);
-      for (int g = 0; g < ng; g++) cntk[label[g] < 0 ? K : label[g]]++;
-      fprintf(stderr, "msfm: camera graph %d nodes -> %d domain(s):", ng, K);
-      for (int k = 0; k < K; k++) fprintf(stderr, " %d", cntk[k]);
-      fprintf(stderr, "  separator %d\n", K > 1 ? cntk[K] : 0);
-    }
   }
   std::vector<int> cb_off_h, padcol_h;
-  int col = 0;
-  for (int k = 0; k < (K > 1 ? K : 1); k++) {
-    const int begin = col;
-    for (int g = 0; g < ng; g++)
-      if (K <= 1 || label[g] == k) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
-    if (K > 1) {
-      while (col % 64) padcol_h.push_back(col++);
-      ba->plan.dom_begin[k] = begin;
-      ba->plan.dom_end[k] = col;
-    }
-  }
-  if (K > 1) {
-    ba->plan.K = K;
-    ba->plan.sep_begin = col;
-    for (int g = 0; g < ng; g++)
-      if (label[g] < 0) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
-  }
-  ba->mo = col;
-  ba->nsys = col + 3 * ba->nmb;
-  ba->n_padcol = (int)padcol_h.size();
+  order_camera_blocks(ctx, ba, gcam, adjb, force, cam_slot, cb_off_h, padcol_h);
   const int ncb = ba->ncb, nmb = ba->nmb;
   ba->nred = 6 * ncb + 3 * nmb;
   ba->npad = 64 * cdiv(ba->nsys + 1, 64);
-  if (ba->plan.K > 1) {
-    ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.sep_begin, 64);
-    DTRY(ba->corners.alloc((size_t)ba->plan.K * ba->plan.ldc * ba->plan.ldc));
+  if (ba->plan.n_levels > 0) {
+    ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.level[0].b0, 64);
+    DTRY(ba->corners.alloc((size_t)4 * ba->plan.ldc * ba->plan.ldc));   // up to four K-splits of the corner update
     ba->plan.corners = ba->corners.p;
   }
   ba->gps_weight = P->gps_weight;
@@ -1834,10 +1884,9 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
     std::vector<int> gnode(Nc, -1), gcam;
     for (int c = 0; c < Nc; c++) if (cu[c]) { gnode[c] = (int)gcam.size(); gcam.push_back(c); }
     const int ng = (int)gcam.size();
-    std::vector<int> label(ng, 0);
-    int K = 1;
     const char* env = getenv("MSFM_CHOL_DOMAINS");  // "0": dense order, "1".."3": force that bisection depth
     const int force = env ? atoi(env) : -1;
+    std::vector<uint8_t> adjb8;
     if (ng >= 128 && ng <= 4096 && force != 0) {
       // adjacency as a 0/1 matrix: cameras sharing an eliminated point; max-reduced over the ranks' shards
       std::vector<char> adjb((size_t)ng * ng, 0);
@@ -1851,9 +1900,8 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
           for (int a : run) for (int b : run) if (a != b && !adjb[(size_t)a * ng + b]) __atomic_store_n(&adjb[(size_t)a * ng + b], (char)1, __ATOMIC_RELAXED);
         }
       });
-      std::vector<double> adjm;
       if (ctx->world > 1) {
-        adjm.resize((size_t)ng * ng);
+        std::vector<double> adjm((size_t)ng * ng);
         for (size_t k = 0; k < adjm.size(); k++) adjm[k] = adjb[k] ? 1.0 : 0.0;
         DevBuf<double> dadj;
         HIP_TRY(ctx, dadj.from(adjm, s));
@@ -1864,40 +1912,10 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
         HIP_TRY(ctx, hipStreamSynchronize(s));
         for (size_t k = 0; k < adjm.size(); k++) adjb[k] = adjm[k] != 0.0;
       }
-      CamGraph G;
-      G.n = ng;
-      G.adj.resize(ng);
-      for (int a = 0; a < ng; a++)
-        for (int b = 0; b < ng; b++) if (adjb[(size_t)a * ng + b]) G.adj[a].push_back(b);
-      K = partition_cameras(G, 3 * ba->nmb + 1, force, label);
-      if (getenv("MSFM_VERBOSE") && ctx->rank == 0) {
-        std::vector<int> cnt(K + 1, 0);
-        for (int g = 0; g < ng; g++) cnt[label[g] < 0 ? K : label[g]]++;
-        fprintf(stderr, "msfm: camera graph %d nodes -> %d domain(s):", ng, K);
-        for (int k = 0; k < K; k++) fprintf(stderr, " %d", cnt[k]);
-        fprintf(stderr, "  separator %d\n", K > 1 ? cnt[K] : 0);
-      }
+      adjb8.assign(adjb.begin(), adjb.end());
     }
-    // slots: domain 0, domain 1, ..., separator; inside each group ascending camera index
-    std::vector<int> cb_off_h;
-    int col = 0;
-    std::vector<int> padcol_h;
-    for (int k = 0; k < (K > 1 ? K : 1); k++) {
-      const int begin = col;
-      for (int g = 0; g < ng; g++)
-        if (K <= 1 || label[g] == k) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
-      if (K > 1) {
-        while (col % 64) padcol_h.push_back(col++);  // identity padding up to the next panel boundary
-        ba->plan.dom_begin[k] = begin;
-        ba->plan.dom_end[k] = col;
-      }
-    }
-    if (K > 1) {
-      ba->plan.K = K;
-      ba->plan.sep_begin = col;
-      for (int g = 0; g < ng; g++)
-        if (label[g] < 0) { cam_slot[gcam[g]] = ba->ncb++; ba->h_cb_cam.push_back(gcam[g]); cb_off_h.push_back(col); col += 6; }
-    }
+    std::vector<int> cb_off_h, padcol_h;
+    order_camera_blocks(ctx, ba, gcam, adjb8, force, cam_slot, cb_off_h, padcol_h);
     // ---- order of the eliminated points: by the (sorted) list of camera blocks that see them ----
     // Points seen by the same cameras become neighbours, so the records of a camera pair's common points are
     // runs in both cameras' segments (the pair kernel's gathers and k_point's scattered stores turn near-sequential).
@@ -1942,9 +1960,6 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
         for (size_t i = 0; i < keyed.size(); i++) ba->h_pb_pt[i] = keyed[i].second;
     }
     for (size_t i = 0; i < ba->h_pb_pt.size(); i++) pt_slot[ba->h_pb_pt[i]] = ba->npb++;
-    ba->mo = col;
-    ba->nsys = col + 3 * ba->nmb;
-    ba->n_padcol = (int)padcol_h.size();
     HIP_TRY(ctx, ba->cb_off.from(cb_off_h.empty() ? std::vector<int>(1, 0) : cb_off_h, s));
     HIP_TRY(ctx, ba->padcol.from(padcol_h.empty() ? std::vector<int>(1, 0) : padcol_h, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -1952,9 +1967,9 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
   const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
   ba->nred = 6 * ncb + 3 * nmb;
   ba->npad = 64 * cdiv(ba->nsys + 1, 64);
-  if (ba->plan.K > 1) {
-    ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.sep_begin, 64);
-    HIP_TRY(ctx, ba->corners.alloc((size_t)ba->plan.K * ba->plan.ldc * ba->plan.ldc));
+  if (ba->plan.n_levels > 0) {
+    ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.level[0].b0, 64);
+    HIP_TRY(ctx, ba->corners.alloc((size_t)4 * ba->plan.ldc * ba->plan.ldc));   // up to four K-splits of the corner update
     ba->plan.corners = ba->corners.p;
   }
   ba->has_gps = P->gps_xyz != nullptr;
@@ -2325,15 +2340,23 @@ MSFM_API int msfm_ba_get_layout(const msfm_ba* ba, msfm_ba_layout* out) {
   memset(out, 0, sizeof *out);
   out->reduced_order = ba->nred;
   out->system_order = ba->nsys;
-  const int K = ba->plan.K > 1 ? ba->plan.K : 0;
+  const msfm_chol_plan& pl = ba->plan;
+  const int K = pl.n_levels > 0 ? pl.level[0].K : 0;
   out->n_domains = K ? K : 1;
-  int maxp = 0;
-  for (int k = 0; k < K; k++) {
-    out->domain_cols[k] = ba->plan.dom_end[k] - ba->plan.dom_begin[k];
-    maxp = std::max(maxp, out->domain_cols[k] / 64);
+  int launches = 0;
+  for (int k = 0; k < K; k++) out->domain_cols[k] = pl.level[0].node[k].end - pl.level[0].node[k].begin;
+  for (int l = 0; l < pl.n_levels; l++) {
+    int maxp = 0;
+    for (int k = 0; k < pl.level[l].K; k++) maxp = std::max(maxp, (pl.level[l].node[k].end - pl.level[l].node[k].begin) / 64);
+    launches += maxp + 1;   // the chains + the deferred corner update
+    out->level_nodes[l] = pl.level[l].K;
+    out->level_begin[l] = pl.level[l].begin;
   }
-  out->separator_cols = K ? ba->nsys - ba->plan.sep_begin : ba->nsys;
-  out->panel_launches = K ? maxp + 1 + cdiv(out->separator_cols, 64) : cdiv(ba->nsys, 64);
+  out->n_levels = pl.n_levels;
+  const int root_begin = pl.n_levels > 0 ? pl.level[pl.n_levels - 1].b0 : 0;
+  out->root_cols = ba->nsys - root_begin;
+  out->separator_cols = K ? ba->nsys - pl.level[0].b0 : ba->nsys;
+  out->panel_launches = launches + cdiv(out->root_cols, 64);
   if (!K) out->domain_cols[0] = 0;
   return MSFM_OK;
 }
@@ -2565,7 +2588,7 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
   const bool lead = ctx->rank == 0;
   if (ba->nred > 0) {
     MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, ba->zsys.p, ba->fail.p,
-                                    ba->plan.K > 1 ? &ba->plan : nullptr));
+                                    ba->plan.n_levels > 0 ? &ba->plan : nullptr));
     hipLaunchKernelGGL(k_gather_z, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ncb, nmb, ba->cb_off.p, ba->mo, ba->zsys.p, ba->z.p, ba->fail.p);
   }
   {

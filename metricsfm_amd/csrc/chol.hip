@@ -264,7 +264,9 @@ struct PanelJob {
   int j0;          // panel to apply, < 0: none (first block of a chain)
   int t0;          // block to factor, < 0: update only
   int a0, na16;    // range A, na16 a multiple of 4
-  int b0, nb16;    // range B (nb16 counts the 16-row tiles that carry data)
+  int b0, nb16;    // range B: nb16 16-row tiles that carry data, in up to four segments (a node's ancestors, one per level,
+  int nseg;        // then the root with the rhs row): segment g starts at row sb0[g] and holds sn16[g] tiles, every segment but
+  int sb0[4], sn16[4];   // the last a multiple of four.  nseg == 0: one segment starting at b0
   int nrt;         // 16-row tiles that carry data, over A then B
   int ncw;         // column-0 workgroups
   int wg0, nwg;    // workgroups [wg0, wg0 + nwg) of the launch: ncw column-0 ones, then the bulk ones
@@ -277,8 +279,15 @@ struct PanelJobs {
   int count;
   PanelJob job[8];
 };
-__device__ __forceinline__ int job_row16(const PanelJob& jb, int rt) { return rt < jb.na16 ? jb.a0 + 16 * rt : jb.b0 + 16 * (rt - jb.na16); }
-__device__ __forceinline__ int job_row64(const PanelJob& jb, int ti) { return 4 * ti < jb.na16 ? jb.a0 + 64 * ti : jb.b0 + 64 * (ti - jb.na16 / 4); }
+__device__ __forceinline__ int job_row16(const PanelJob& jb, int rt) {
+  if (rt < jb.na16) return jb.a0 + 16 * rt;
+  int r = rt - jb.na16;
+  if (jb.nseg == 0) return jb.b0 + 16 * r;
+  int g = 0;
+  while (g + 1 < jb.nseg && r >= jb.sn16[g]) { r -= jb.sn16[g]; g++; }
+  return jb.sb0[g] + 16 * r;
+}
+__device__ __forceinline__ int job_row64(const PanelJob& jb, int ti) { return job_row16(jb, 4 * ti); }
 
 __device__ __forceinline__ void p0_load(const double* __restrict__ M, int ld, int t0, int j0, int tid, d2 (&pv)[8]) {
 #pragma unroll
@@ -587,10 +596,14 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
 }
 
 // The separator x separator part of the domain chains' trailing updates, all at once:  corner_r[I][J] = -sum_p X_I,p X_J,p^T
-// over the 64-column panels p = r, r + nsplit, ... of the domain columns [0, b0) (X = the separator rows of the factor).
+// over the 64-column panels p = p_begin + r, p_begin + r + nsplit, ... of the level's columns [64 p_begin, b0) (X = the rows
+// of the factor from b0 on).
 // grid = lower 64x64 tiles of the separator square x nsplit; the next panel's tiles are fetched during the MFMAs.
-__global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ M, int ld, int b0, int nsplit, double* __restrict__ corners,
-                                                      int ldc) {
+// Only panels of leaves / nodes under BOTH blocks' tree nodes contribute (everything else is structurally zero):
+// blk_plo / blk_phi give, per 64-row block of the square, the panel range of the level that lies under its node.
+struct CornerRanges { short plo[128], phi[128]; };
+__global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ M, int ld, int b0, int nsplit,
+                                                      double* __restrict__ corners, int ldc, CornerRanges R) {
   __shared__ double sm[2 * 64 * LDT];
   double* As = sm;
   double* Bs = sm + 64 * LDT;
@@ -601,7 +614,8 @@ __global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ 
   while (I * (I + 1) / 2 > tile) I--;
   while ((I + 1) * (I + 2) / 2 <= tile) I++;
   const int J = tile - I * (I + 1) / 2;
-  const int ri = b0 + 64 * I, rj = b0 + 64 * J, np = b0 / 64;
+  const int ri = b0 + 64 * I, rj = b0 + 64 * J;
+  const int p_begin = max((int)R.plo[I], (int)R.plo[J]), np = min((int)R.phi[I], (int)R.phi[J]);
   d4 acc00 = {0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
   d2 va[8], vb[8];
   auto fetch = [&](int p) {
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ 
       vb[it] = *reinterpret_cast<const d2*>(&M[(size_t)(rj + row) * ld + 64 * p + c2]);
     }
   };
-  int p = r;
+  int p = p_begin + r;
   if (p < np) fetch(p);
   for (; p < np; p += nsplit) {
 #pragma unroll
@@ -727,7 +741,7 @@ __global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__
 // workgroup stores z_j.  Nobody writes w_j in this launch.
 // ---------------------------------------------------------------------------------------
 struct BackJob { int jb, ib, ni, wg0; };
-struct BackJobs { int count; BackJob job[8]; };
+struct BackJobs { int count; BackJob job[16]; };
 __global__ __launch_bounds__(256) void k_backsolve_step(const double* __restrict__ M, int ld, int n, BackJobs jobs,
                                                          const double* __restrict__ Linv, double* __restrict__ w,
                                                          double* __restrict__ z) {
@@ -863,6 +877,8 @@ static int bulk_workgroups(int ntile) { return ntile; }
 static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /*data rows in B*/, double* corner, int ldc) {
   PanelJob jb;
   jb.j0 = j0; jb.t0 = t0; jb.a0 = a0; jb.na16 = 4 * nA64; jb.b0 = b0; jb.nb16 = cdiv(std::max(0, nrows_b), 16);
+  jb.nseg = 0;
+  for (int g = 0; g < 4; g++) { jb.sb0[g] = 0; jb.sn16[g] = 0; }
   jb.nrt = jb.na16 + jb.nb16;
   const int nt = nA64 + cdiv(jb.nb16, 4);
   if (t0 >= 0) {
@@ -887,46 +903,84 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   double* Linv = work + (size_t)npad * 16;
   double* Ldiag = work + (size_t)npad * 80;
   int t_first = 0;
-  if (plan && plan->K > 1) {
-    // ---- the K domain chains, step by step: step l of domain k factors its block l (after applying its panel l-1);
-    //      the step after a domain's last block only applies that last panel to the separator rows ----
-    const int K = plan->K, sb = plan->sep_begin, ldc = plan->ldc;
-    if (K > 8 || sb % NB || !plan->corners || ldc < 64 * cdiv(nrows - sb, 64))
-      return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan");
-    int maxp = 0;
-    for (int k = 0; k < K; k++) maxp = std::max(maxp, (plan->dom_end[k] - plan->dom_begin[k]) / NB);
-    for (int l = 0; l < maxp; l++) {
-      PanelJobs jobs;
-      jobs.count = 0;
-      int wg = 0;
-      for (int k = 0; k < K; k++) {
-        const int P = (plan->dom_end[k] - plan->dom_begin[k]) / NB;
-        if (l >= P) continue;
-        const int t0 = plan->dom_begin[k] + NB * l;
-        const int j0 = l > 0 ? plan->dom_begin[k] + NB * (l - 1) : -1;
-        PanelJob jb = make_job(j0, t0, t0, P - l, sb, nrows - sb, nullptr, 0);
-        // the separator x separator tiles are formed once, after the chains (k_corner_syrk): leave them out here
-        const int nA64 = P - l, nB64 = cdiv(jb.nb16, 4);
-        jb.defer_corner = 1;
-        jb.ntile = j0 >= 0 ? nA64 * (nA64 - 1) / 2 + nB64 * (nA64 - 1) : 0;
-        jb.nwg = jb.ncw + bulk_workgroups(jb.ntile);
-        jb.wg0 = wg;
-        wg += jb.nwg;
-        jobs.job[jobs.count++] = jb;
+  const int n_levels = plan ? plan->n_levels : 0;
+  if (n_levels > 0) {
+    if (n_levels > 3 || !plan->corners) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan");
+    for (int lv = 0; lv < n_levels; lv++) {
+      // ---- the K chains of this level, step by step: step l of node k factors its block l (after applying its panel
+      //      l-1); the step after a node's last block only applies that last panel to the rows from b0 on ----
+      const msfm_chol_level& L = plan->level[lv];
+      const int K = L.K, sb = L.b0, ldc = plan->ldc;
+      if (K < 1 || K > 8 || sb % NB || L.begin % NB || ldc < 64 * cdiv(nrows - sb, 64)) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan level");
+      const int root_begin = plan->level[n_levels - 1].b0;
+      // rows a node's panels reach below the node itself: its ancestors (one node per higher level), then the root
+      // chain with the rhs row - everything else from b0 on is structurally zero in its columns
+      auto ancestors = [&](const msfm_chol_node& nd, PanelJob& jb) {
+        jb.nseg = 0;
+        int rows = 0;
+        for (int h = lv + 1; h < n_levels; h++)
+          for (int q = 0; q < plan->level[h].K; q++) {
+            const msfm_chol_node& a = plan->level[h].node[q];
+            if (a.leaf_lo <= nd.leaf_lo && a.leaf_hi >= nd.leaf_hi) { jb.sb0[jb.nseg] = a.begin; jb.sn16[jb.nseg] = (a.end - a.begin) / 16; jb.nseg++; rows += a.end - a.begin; }
+          }
+        jb.sb0[jb.nseg] = root_begin; jb.sn16[jb.nseg] = cdiv(nrows - root_begin, 16); jb.nseg++;
+        rows += nrows - root_begin;
+        return rows;
+      };
+      int maxp = 0;
+      for (int k = 0; k < K; k++) maxp = std::max(maxp, (L.node[k].end - L.node[k].begin) / NB);
+      for (int l = 0; l < maxp; l++) {
+        PanelJobs jobs;
+        jobs.count = 0;
+        int wg = 0;
+        for (int k = 0; k < K; k++) {
+          const int P = (L.node[k].end - L.node[k].begin) / NB;
+          if (l >= P) continue;
+          const int t0 = L.node[k].begin + NB * l;
+          const int j0 = l > 0 ? L.node[k].begin + NB * (l - 1) : -1;
+          PanelJob seg;
+          const int brows = ancestors(L.node[k], seg);
+          PanelJob jb = make_job(j0, t0, t0, P - l, sb, brows, nullptr, 0);
+          jb.nseg = seg.nseg;
+          for (int g = 0; g < 4; g++) { jb.sb0[g] = seg.sb0[g]; jb.sn16[g] = seg.sn16[g]; }
+          // the tiles among the rows from b0 on are formed once, after the chains (k_corner_syrk): leave them out here
+          const int nA64 = P - l, nB64 = cdiv(jb.nb16, 4);
+          jb.defer_corner = 1;
+          jb.ntile = j0 >= 0 ? nA64 * (nA64 - 1) / 2 + nB64 * (nA64 - 1) : 0;
+          jb.nwg = jb.ncw + bulk_workgroups(jb.ntile);
+          jb.wg0 = wg;
+          wg += jb.nwg;
+          jobs.job[jobs.count++] = jb;
+        }
+        if (!jobs.count) break;
+        KTimer t(ctx, "chol_panel_mfma");
+        hipLaunchKernelGGL(k_panel_v2<true>, dim3(wg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
       }
-      if (!jobs.count) break;
-      KTimer t(ctx, "chol_panel_mfma");
-      hipLaunchKernelGGL(k_panel_v2<true>, dim3(wg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
+      if (maxp > 0) {
+        KTimer t(ctx, "chol_panel_mfma");
+        const int nB64 = cdiv(nrows - sb, 64), ntile = nB64 * (nB64 + 1) / 2;
+        if (nB64 > 128) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: separator part too large for the corner update (%d blocks)", nB64);
+        // per 64-row block of the square: the panels of this level under the block's tree node (the root: all of them)
+        CornerRanges R;
+        for (int I = 0; I < nB64; I++) {
+          const int row = sb + 64 * I;
+          int lo = 0, hi = 0x7fffffff;   // leaf interval of the block's node; the root covers everything
+          for (int h = lv + 1; h < n_levels; h++)
+            for (int q = 0; q < plan->level[h].K; q++)
+              if (row >= plan->level[h].node[q].begin && row < plan->level[h].node[q].end) { lo = plan->level[h].node[q].leaf_lo; hi = plan->level[h].node[q].leaf_hi; }
+          int plo = 0, phi = 0;
+          bool any = false;
+          for (int q = 0; q < K; q++)
+            if (L.node[q].leaf_lo >= lo && L.node[q].leaf_hi <= hi) { if (!any) plo = L.node[q].begin / NB; phi = L.node[q].end / NB; any = true; }
+          R.plo[I] = (short)plo; R.phi[I] = (short)phi;
+        }
+        // K-split so that the workgroups (two fit on a CU) cover the chip once: 1 / 2 / 3 / 4 splits measured 94 / 82 / 58 / 71 us at C3
+        const int nsplit = std::max(1, std::min(4, 512 / std::max(1, ntile)));
+        hipLaunchKernelGGL(k_corner_syrk, dim3(ntile * nsplit), dim3(256), 0, s, M, npad, sb, nsplit, plan->corners, ldc, R);
+        hipLaunchKernelGGL(k_merge_corners, dim3(4 * ntile), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, nsplit);
+      }
+      t_first = sb;
     }
-    {
-      KTimer t(ctx, "chol_panel_mfma");
-      const int nB64 = cdiv(nrows - sb, 64), ntile = nB64 * (nB64 + 1) / 2;
-      // K-split so that the workgroups (two fit on a CU) cover the chip once: 1 / 2 / 3 / 4 splits measured 94 / 82 / 58 / 71 us at C3
-      const int nsplit = std::min(K, std::max(1, std::min(4, 512 / std::max(1, ntile))));
-      hipLaunchKernelGGL(k_corner_syrk, dim3(ntile * nsplit), dim3(256), 0, s, M, npad, sb, nsplit, plan->corners, ldc);
-      hipLaunchKernelGGL(k_merge_corners, dim3(4 * ntile), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, nsplit);
-    }
-    t_first = sb;
   }
   for (int t0 = t_first; t0 < n; t0 += NB) {
     // the separator (or the whole matrix): one job per launch, its first block has nothing left to apply
@@ -944,8 +998,8 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   {
     KTimer t(ctx, "chol_backsolve");
     hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB) + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, cdiv(n, NB), M, npad, w, npad);
-    const int first_dense = (plan && plan->K > 1) ? plan->sep_begin / NB : 0;
-    for (int jb = cdiv(n, NB) - 1; jb >= first_dense;) {  // separator (or everything): couples to every block before it
+    const int first_dense = t_first / NB;
+    for (int jb = cdiv(n, NB) - 1; jb >= first_dense;) {  // root chain (or everything): couples to every block before it
       BackJobs bj;
       bj.count = 1;
       if (jb - 1 >= first_dense) {   // blocks jb and jb-1 together
@@ -958,23 +1012,39 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
         jb -= 1;
       }
     }
-    if (first_dense) {
+    for (int lv = n_levels - 1; lv >= 0; lv--) {
+      // Blocks P_k - 1 - 2l and P_k - 2 - 2l of every node of the level in one launch (a node's last odd block alone).  A
+      // block couples to the earlier blocks of its own node and to its descendants in the lower levels (contiguous in
+      // every level: tree order) - one job per range, all of them recomputing z for themselves; siblings never touch the
+      // same rows.
+      const msfm_chol_level& L = plan->level[lv];
       int maxp = 0;
-      for (int k = 0; k < plan->K; k++) maxp = std::max(maxp, (plan->dom_end[k] - plan->dom_begin[k]) / NB);
-      for (int l = 0; 2 * l < maxp; l++) {  // blocks P_k - 1 - 2l and P_k - 2 - 2l of every domain in one launch (a domain's last odd block alone)
+      for (int k = 0; k < L.K; k++) maxp = std::max(maxp, (L.node[k].end - L.node[k].begin) / NB);
+      for (int l = 0; 2 * l < maxp; l++) {
         BackJobs pj, sj;
         pj.count = sj.count = 0;
         int pwg = 0, swg = 0;
-        for (int k = 0; k < plan->K; k++) {
-          const int ib = plan->dom_begin[k] / NB, P = (plan->dom_end[k] - plan->dom_begin[k]) / NB;
+        for (int k = 0; k < L.K; k++) {
+          const int ib = L.node[k].begin / NB, P = (L.node[k].end - L.node[k].begin) / NB;
           if (2 * l >= P) continue;
           const int jb = ib + P - 1 - 2 * l;
-          if (jb - 1 >= ib) {
-            pj.job[pj.count++] = BackJob{jb, ib, jb - 1 - ib, pwg};
-            pwg += std::max(1, jb - 1 - ib);
-          } else {
-            sj.job[sj.count++] = BackJob{jb, ib, jb - ib, swg};
-            swg += std::max(1, jb - ib);
+          const bool pair = jb - 1 >= ib;
+          BackJobs& J = pair ? pj : sj;
+          int& wg = pair ? pwg : swg;
+          const int own = pair ? jb - 1 - ib : jb - ib;   // earlier blocks of the node itself
+          J.job[J.count++] = BackJob{jb, ib, own, wg};
+          wg += std::max(1, own);
+          for (int lo = lv - 1; lo >= 0; lo--) {   // descendants, level by level
+            const msfm_chol_level& D = plan->level[lo];
+            int d0 = -1, d1 = -1;
+            for (int q = 0; q < D.K; q++)
+              if (D.node[q].leaf_lo >= L.node[k].leaf_lo && D.node[q].leaf_hi <= L.node[k].leaf_hi) { if (d0 < 0) d0 = q; d1 = q; }
+            if (d0 < 0) continue;
+            const int rb = D.node[d0].begin / NB, rn = (D.node[d1].end - D.node[d0].begin) / NB;
+            if (rn <= 0) continue;
+            if (J.count >= 16) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: too many back-substitution ranges in one launch");
+            J.job[J.count++] = BackJob{jb, rb, rn, wg};
+            wg += rn;
           }
         }
         if (pj.count) hipLaunchKernelGGL(k_backsolve_pair, dim3(pwg), dim3(256), 0, s, M, npad, n, pj, Linv, w, z);

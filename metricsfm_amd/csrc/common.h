@@ -146,13 +146,18 @@ static inline void par_ranges(size_t n, int nt, F&& fn, size_t grain = 4096) {  
   for (auto& x : th) x.join();
 }
 
-// Elimination structure of the reduced system (chol.hip): columns [dom_begin[k], dom_end[k]) are K
-// mutually uncoupled camera domains (64-aligned, identity padding inside), [sep_begin, n) is their
-// separator + intrinsics.  K <= 1: plain dense order.  corners: K buffers of ldc x ldc doubles.
+// Elimination structure of the reduced system (chol.hip): a nested-dissection tree of the camera graph laid out level
+// by level.  Level 0 holds the leaf domains, level 1 the deepest separators, ... ; the nodes of one level are mutually
+// uncoupled (their panel chains share launches), each is 64-aligned (identity padding inside) and couples only to its own
+// descendants and to later columns.  Columns from the last level's b0 on (root separator + intrinsics) form the final
+// dense chain.  n_levels = 0: plain dense order.  A node's descendants in a lower level are the nodes whose leaf interval
+// lies inside its own (tree order inside every level makes them contiguous).
+// corners: scratch for the deferred separator x separator updates, `nsplit` buffers of ldc x ldc doubles.
+struct msfm_chol_node { int begin, end, leaf_lo, leaf_hi; };
+struct msfm_chol_level { int K = 0; msfm_chol_node node[8]; int begin = 0, b0 = 0; };
 struct msfm_chol_plan {
-  int K = 0;
-  int dom_begin[8] = {0}, dom_end[8] = {0};
-  int sep_begin = 0;
+  int n_levels = 0;
+  msfm_chol_level level[3];
   double* corners = nullptr;
   int ldc = 0;
 };
