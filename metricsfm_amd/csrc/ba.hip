@@ -2454,6 +2454,34 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     Q.reuse_diag = reuse_diag; Q.mode = mode; Q.fail = ba->fail.p;
     hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, s, Q, ba->gmax_buf.p);
   }
+  // The Schur pair products read only what k_point wrote (T, Tm, Tmu) and write their own partials; the per-camera sums
+  // (k_ftf ... k_modelsum, with the multi-rank exchange of camftf) read T.u and the camera rows.  Outside profiling runs
+  // the pair products therefore go to a second stream beside them and the two meet again at the assembly (with the
+  // per-class timers on, everything stays on the main stream so that the timings remain per kernel).
+  auto launch_pairs = [&](hipStream_t sp) {
+    if (ba->cc.n_chunks)
+      hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, sp, ba->cc.n_chunks, ba->cc.ch_start.p,
+                         ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
+    if (ba->mc.n_chunks)
+      hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->mc.n_chunks, 4)), dim3(256), 0, sp, ba->mc.n_chunks, ba->mc.ch_start.p,
+                         ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->mc.partial.p);
+    if (ba->mm.n_chunks)
+      hipLaunchKernelGGL((k_pairs<3, 3, true>), dim3(cdiv(ba->mm.n_chunks, 4)), dim3(256), 0, sp, ba->mm.n_chunks, ba->mm.ch_start.p,
+                         ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, (size_t)0, ba->mm.partial.p);
+  };
+  static const bool no_overlap = getenv("MSFM_NO_OVERLAP") != nullptr;
+  const bool forked = mode == 0 && !ctx->profile && !no_overlap;
+  if (forked) {
+    if (!ctx->stream2) {
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    launch_pairs(ctx->stream2);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+  }
   double* gmax_c = ba->gmax_buf.p + ba->nblk_pt;
   double* gmax_m = gmax_c + 6 * (size_t)ncb;
   {
@@ -2485,17 +2513,11 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     rj.fail_slot = S_FAIL;
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, rj, ba->swrite);
   }
-  {
+  if (forked) {
+    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+  } else {
     KTimer t(ctx, "ba_schur_pairs");
-    if (ba->cc.n_chunks)
-      hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, s, ba->cc.n_chunks, ba->cc.ch_start.p,
-                         ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
-    if (ba->mc.n_chunks)
-      hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->mc.n_chunks, 4)), dim3(256), 0, s, ba->mc.n_chunks, ba->mc.ch_start.p,
-                         ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->mc.partial.p);
-    if (ba->mm.n_chunks)
-      hipLaunchKernelGGL((k_pairs<3, 3, true>), dim3(cdiv(ba->mm.n_chunks, 4)), dim3(256), 0, s, ba->mm.n_chunks, ba->mm.ch_start.p,
-                         ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, (size_t)0, ba->mm.partial.p);
+    launch_pairs(s);
   }
   {
     KTimer t(ctx, "ba_assemble");

@@ -20,6 +20,10 @@
 struct msfm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream for work that does not depend on what the main stream is doing (the Schur pair products run beside
+  // the per-camera sums: both only read what k_point wrote); created on first use, fork / join by the two events
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   // multi-GPU hook
   msfm_allreduce_fn allreduce = nullptr;

@@ -7,15 +7,18 @@ O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O   # (the local copy under gpurun_out/ keeps older run directories: delete it before a new collection)
 export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-echo "bench done"; tail -c 600 $O/bench.json
+echo "bench done"; tail -c 300 $O/bench.json
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kt.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/kt.log 2>&1
 echo "kernel trace done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-matching > $O/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-matching --no-extras > $O/pmc_fetch.log 2>&1
 echo "pmc fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-matching > $O/pmc_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-matching --no-extras > $O/pmc_write.log 2>&1
 echo "pmc write done"
 cd $R
+python3 scripts/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc > $O/pmc_summary.txt 2>&1 || echo "pmc post-processing failed"
+python3 bench.py --config 5 --window --steps 20 --warmup 3 > $O/bench_c5_window.json 2> $O/bench_c5_window.err
+echo "config 5 window done"
 python3 scripts/extra_bench.py --c5 > $O/extra.json 2> $O/extra.err
 echo "extra done"
-find $O -name "*.csv" | head -20
+find $O -name "*kernel_stats.csv" | head -3
