@@ -31,6 +31,14 @@
 
 #define PSTRIDE 80   // doubles per FTF partial
 #define CHUNK 1024   // entries per reduction chunk (16 per lane)
+// k_ftf's chunks are shorter: a camera has a few thousand rows, and one wave per 1024 of them leaves most of the chip without
+// a wave (C3: 1500 waves for 1024 SIMDs x 2); 256 rows per wave = 4 passes of 64 lanes
+#define FTF_CHUNK 256
+static int ftf_chunk() {
+  const char* e = getenv("MSFM_FTF_CHUNK");   // (experiments)
+  const int v = e ? atoi(e) : 0;
+  return v >= 64 ? v : FTF_CHUNK;
+}
 // FTF partial layout
 #define F_JCJC 0     // 36
 #define F_JMJC 36    // 18 (3x6)
@@ -212,7 +220,8 @@ struct PointPtrs {
   int* fail;
 };
 
-#define GROUP_SUM(x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); }
+// (8-lane groups; after the first two steps the four lanes of a quad hold the same value, so adding lane 7 - i is adding lane i ^ 4)
+#define GROUP_SUM(x) { x += dpp_f64<MSFM_DPP_XOR1>(x); x += dpp_f64<MSFM_DPP_XOR2>(x); x += dpp_f64<MSFM_DPP_HALF_MIRROR>(x); }
 
 // 8 lanes per point, lane = observation (rounds of 8 for longer tracks): the SoA linearisation is
 // read coalesced, the per-point sums are 3-step xor reductions inside the 8-lane group, and every
@@ -287,38 +296,55 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
   }
   if (P.mode != 1) {
     // camera entries: T = (Jc^T Jp) L^-T (one 144-byte record per observation, camera-major), T.u
-    for (int base = f; base < l; base += 8) {
-      const int i = base + sub;
-      if (i < l) {
-        const int cp = P.o_cpos[i];
-        if (cp >= 0) {
-          double a0 = ca0, a1 = ca1, a2 = ca2, b0 = cb0, b1 = cb1, b2 = cb2;
-          if (!single) {
-            a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
-            b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
-          }
-          double T[18], jc[12], tu[6];
+    // Stores: neighbouring lanes hold the observations of ONE point - eight different cameras, eight far-apart addresses,
+    // one 8-byte write request per lane and component (21.6 M at C3).  The lanes of a wave therefore trade records first, (point q, observation s) -> lane 8 s + q: now
+    // neighbouring lanes hold the same observation slot of consecutive points, which sit at consecutive positions of one
+    // camera wherever the points share their cameras, and the stores of a quad merge (k_point 0.229 -> 0.223 ms at C3; a
+    // record-major T was also measured: the same here, but k_pairs 0.28 -> 0.49 ms).
+    const int wl = tid & 63, tsrc = ((wl & 7) << 3) | (wl >> 3);
+    for (int rd = 0; __any(f + rd < l); rd += 8) {
+      const int i = f + rd + sub;
+      int cp = -1;
+      if (i < l) cp = P.o_cpos[i];
+      double T[18], tu[6];
 #pragma unroll
-          for (int a = 0; a < 12; a++) jc[a] = P.lin_Jc[(size_t)a * A + i];  // all loads before the first use
+      for (int k = 0; k < 18; k++) T[k] = 0.0;
 #pragma unroll
-          for (int a = 0; a < 6; a++) {
-            const double ja = jc[a], jb = jc[6 + a];
-            const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
-            const double t0 = w0 * i00;
-            const double t1 = (w1 - l10 * t0) * i11;
-            const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
-            T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
-            tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
-          }
-          double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cp);
-#pragma unroll
-          for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
-          // component-major (T[k][position], positions camera-major): records of consecutive points of a camera are
-          // neighbours in every component plane, so these stores and the pair kernel's loads coalesce over the runs of
-          // points that share their cameras instead of touching one 16-byte piece per lane and instruction
-#pragma unroll
-          for (int k = 0; k < 18; k++) P.T[(size_t)k * P.NCR + cp] = T[k];
+      for (int k = 0; k < 6; k++) tu[k] = 0.0;
+      if (cp >= 0) {
+        double a0 = ca0, a1 = ca1, a2 = ca2, b0 = cb0, b1 = cb1, b2 = cb2;
+        if (!single) {
+          a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
+          b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
         }
+        double jc[12];
+#pragma unroll
+        for (int a = 0; a < 12; a++) jc[a] = P.lin_Jc[(size_t)a * A + i];  // all loads before the first use
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          const double ja = jc[a], jb = jc[6 + a];
+          const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
+          const double t0 = w0 * i00;
+          const double t1 = (w1 - l10 * t0) * i11;
+          const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
+          T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
+          tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+        }
+      }
+      const int cpt = __shfl(cp, tsrc, 64);
+#pragma unroll
+      for (int k = 0; k < 18; k++) T[k] = __shfl(T[k], tsrc, 64);
+#pragma unroll
+      for (int k = 0; k < 6; k++) tu[k] = __shfl(tu[k], tsrc, 64);
+      if (cpt >= 0) {
+        double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cpt);
+#pragma unroll
+        for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
+        // component-major (T[k][position], positions camera-major): records of consecutive points of a camera are
+        // neighbours in every component plane, so these stores and the pair kernel's loads coalesce over the runs of
+        // points that share their cameras
+#pragma unroll
+        for (int k = 0; k < 18; k++) P.T[(size_t)k * P.NCR + cpt] = T[k];
       }
     }
     // (point, intrinsics-block) entries: Tm = (sum Jm^T Jp) L^-T
@@ -1807,9 +1833,10 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
                                      ba->pm_mb.p, ba->o_pm.p, d_err.p);
   // ---- FTF chunks (host: O(cameras + rows / 1024)) ----
   std::vector<int> f_start, f_end, cam_chunk_first(ncb + 1, 0);
+  const int fchunk = ftf_chunk();
   for (int c = 0; c < ncb; c++) {
     cam_chunk_first[c] = (int)f_start.size();
-    for (int e = cam_first[c]; e < cam_first[c + 1]; e += CHUNK) { f_start.push_back(e); f_end.push_back(std::min(e + CHUNK, cam_first[c + 1])); }
+    for (int e = cam_first[c]; e < cam_first[c + 1]; e += fchunk) { f_start.push_back(e); f_end.push_back(std::min(e + fchunk, cam_first[c + 1])); }
   }
   cam_chunk_first[ncb] = (int)f_start.size();
   ba->n_fchunks = (int)f_start.size();
@@ -2106,9 +2133,10 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
   lap("positions + pm entries");
   // ---- FTF chunks (camera-major rows) ----
   std::vector<int> f_start, f_end, cam_chunk_first(ncb + 1, 0);
+  const int fchunk = ftf_chunk();
   for (int c = 0; c < ncb; c++) {
     cam_chunk_first[c] = (int)f_start.size();
-    for (int e = cam_first[c]; e < cam_first[c + 1]; e += CHUNK) { f_start.push_back(e); f_end.push_back(std::min(e + CHUNK, cam_first[c + 1])); }
+    for (int e = cam_first[c]; e < cam_first[c + 1]; e += fchunk) { f_start.push_back(e); f_end.push_back(std::min(e + fchunk, cam_first[c + 1])); }
   }
   cam_chunk_first[ncb] = (int)f_start.size();
   ba->n_fchunks = (int)f_start.size();

@@ -106,14 +106,61 @@ __device__ __forceinline__ void msfm_huber(double a, double s, double& rho0, dou
 }
 
 // Deterministic wave / block sums (fixed butterfly, fixed wave order).
+// The butterfly's partner values travel by DPP (inside a row of 16 lanes) and by the gfx950 row / half-wave swaps - VALU
+// instructions - instead of ds_bpermute through the LDS pipe (two per step and double: 936 of them in one k_ftf wave).
+// Every step adds the same two numbers as `v += __shfl_xor(v, off)` did, so results are bit-identical to that form.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+#define MSFM_DPP_XOR1 0xB1          // quad_perm [1,0,3,2]
+#define MSFM_DPP_XOR2 0x4E          // quad_perm [2,3,0,1]
+#define MSFM_DPP_ROR8 0x128         // row_ror:8 = lane ^ 8 inside a row
+#define MSFM_DPP_HALF_MIRROR 0x141  // lane -> 7 - lane inside each half row
+__device__ __forceinline__ int dpp_xor4_b32(int x) {
+  // lane ^ 4: quads 0 and 2 take from the quad above (row_shl:4), quads 1 and 3 from the quad below (row_shr:4)
+  const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);
+  return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);
+}
+__device__ __forceinline__ double dpp_xor4_f64(double v) {
+  return __hiloint2double(dpp_xor4_b32(__double2hiint(v)), dpp_xor4_b32(__double2loint(v)));
+}
+// the two halves of the row pairs / of the wave side by side: a = [R0 R0 R2 R2], b = [R1 R1 R3 R3] (rows of 16 lanes),
+// resp. a = [lower 32, lower 32], b = [upper 32, upper 32]; a + b is the xor-16 (xor-32) step in every lane
+__device__ __forceinline__ void swap16_f64(double v, double& a, double& b) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  a = __hiloint2double(h[0], l[0]);
+  b = __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ void swap32_f64(double v, double& a, double& b) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  a = __hiloint2double(h[0], l[0]);
+  b = __hiloint2double(h[1], l[1]);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  double a, b;
+  swap32_f64(v, a, b); v = a + b;
+  swap16_f64(v, a, b); v = a + b;
+  v += dpp_f64<MSFM_DPP_ROR8>(v);
+  v += dpp_xor4_f64(v);
+  v += dpp_f64<MSFM_DPP_XOR2>(v);
+  v += dpp_f64<MSFM_DPP_XOR1>(v);
   return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  double a, b;
+  swap32_f64(v, a, b); v = fmax(a, b);
+  swap16_f64(v, a, b); v = fmax(a, b);
+  v = fmax(v, dpp_f64<MSFM_DPP_ROR8>(v));
+  v = fmax(v, dpp_xor4_f64(v));
+  v = fmax(v, dpp_f64<MSFM_DPP_XOR2>(v));
+  v = fmax(v, dpp_f64<MSFM_DPP_XOR1>(v));
   return v;
 }
 // blockDim.x must be 256.  Result valid in thread 0.
