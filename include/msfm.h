@@ -364,13 +364,17 @@ int msfm_epipolar_filter_batch(msfm_ctx* ctx, int n_pairs, const int* offsets, c
  * feature to it (:597-606), else one whose second feature belongs to a point adds the first (:607-616), else a new
  * point is created (:617-633).  std::map::insert semantics are kept: a point holds at most one observation per
  * image (the first), a feature stays with the first point it was mapped to, two existing points are never merged.
- * Host code; the tracks then go to msfm_triangulate_midpoint_batch (th_tri_angle = 3 degrees, points with fewer
+ * msfm_tracks_build is that walk on the host; msfm_tracks_build_device gives the identical result from the GPU (first
+ * appearances by atomicMin, the "joins" forest, a stable sort of the observations by (point, image)) - the form for the
+ * match lists of a whole image set (config 3: 6 M matches).  The tracks then go to msfm_triangulate_midpoint_batch (th_tri_angle = 3 degrees, points with fewer
  * than 3 views or a failed triangulation are marked bad, :638-648).
  * Out: CSR tracks, observations of a track in ascending image order (std::map iteration order). */
 typedef struct msfm_track_set msfm_track_set;
 int msfm_tracks_build(int n_images, const int* n_features, int n_pairs, const int* pair_img /*[n_pairs][2]*/,
                       const int* match_off /*[n_pairs+1]*/, const int* matches /*[match_off[n_pairs]][2]*/,
                       msfm_track_set** out);
+int msfm_tracks_build_device(msfm_ctx* ctx, int n_images, const int* n_features, int n_pairs, const int* pair_img,
+                             const int* match_off, const int* matches, msfm_track_set** out);
 int msfm_track_set_size(const msfm_track_set* set, int* n_tracks, int* n_observations);
 int msfm_track_set_fetch(const msfm_track_set* set, int* track_off /*[n_tracks+1]*/, int* obs_image, int* obs_feature);
 void msfm_track_set_destroy(msfm_track_set* set);

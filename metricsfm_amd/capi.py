@@ -23,7 +23,7 @@ SYMBOLS = [
     "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ba_get_layout", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
-    "msfm_epipolar_filter_batch", "msfm_tracks_build", "msfm_track_set_size", "msfm_track_set_fetch", "msfm_track_set_destroy",
+    "msfm_epipolar_filter_batch", "msfm_tracks_build", "msfm_tracks_build_device", "msfm_track_set_size", "msfm_track_set_fetch", "msfm_track_set_destroy",
     "msfm_epnp_ransac_batch", "msfm_relpose_5pt_batch", "msfm_rccl_get_unique_id", "msfm_ctx_init_rccl", "msfm_ctx_allreduce",
 ]
 
@@ -96,6 +96,7 @@ def lib():
     L.msfm_ctx_init_rccl.argtypes = [vp, C.POINTER(C.c_ubyte), i, i]
     L.msfm_ctx_allreduce.argtypes = [vp, vp, C.c_size_t, i]
     L.msfm_tracks_build.argtypes = [i, A.c_int_p, i, A.c_int_p, A.c_int_p, A.c_int_p, C.POINTER(vp)]
+    L.msfm_tracks_build_device.argtypes = [vp, i, A.c_int_p, i, A.c_int_p, A.c_int_p, A.c_int_p, C.POINTER(vp)]
     L.msfm_track_set_size.argtypes = [vp, A.c_int_p, A.c_int_p]
     L.msfm_track_set_fetch.argtypes = [vp, A.c_int_p, A.c_int_p, A.c_int_p]
     L.msfm_track_set_destroy.argtypes = [vp]
@@ -114,25 +115,18 @@ def default_options(**kw):
     return o
 
 
-def build_tracks(n_features, pairs, matches_per_pair):
-    """SLAMGPS::Triangulation's data association (slam_gps.cc:565-635).  n_features[image]; pairs [(idx1, idx2)] in visiting
-    order; matches_per_pair[p] = int array [m][2] (feature in idx1, feature in idx2).
-    Returns CSR tracks: track_off, obs_image, obs_feature (observations in ascending image order)."""
+def _flatten_matches(n_features, pairs, matches_per_pair):
     nf = A.as_c(np.asarray(n_features, dtype=np.int32), np.int32)
     pr = A.as_c(np.asarray(pairs, dtype=np.int32).reshape(-1, 2), np.int32)
+    lens = np.array([len(m) for m in matches_per_pair], dtype=np.int64)
     off = np.zeros(len(pr) + 1, dtype=np.int32)
-    for p, m in enumerate(matches_per_pair):
-        off[p + 1] = off[p] + len(m)
-    flat = np.zeros((max(1, off[-1]), 2), dtype=np.int32)
-    for p, m in enumerate(matches_per_pair):
-        if len(m):
-            flat[off[p]:off[p + 1]] = np.asarray(m, dtype=np.int32).reshape(-1, 2)
-    flat = A.as_c(flat, np.int32)
-    h = C.c_void_p()
-    rc = lib().msfm_tracks_build(len(nf), A.ptr(nf, A.c_int_p), len(pr), A.ptr(pr, A.c_int_p), A.ptr(off, A.c_int_p),
-                                 A.ptr(flat, A.c_int_p), C.byref(h))
-    if rc != 0:
-        raise MsfmError(rc, "msfm_tracks_build: invalid input")
+    off[1:] = np.cumsum(lens)
+    nonempty = [np.asarray(m, dtype=np.int32).reshape(-1, 2) for m in matches_per_pair if len(m)]
+    flat = np.concatenate(nonempty) if nonempty else np.zeros((1, 2), dtype=np.int32)
+    return nf, pr, off, A.as_c(flat, np.int32)
+
+
+def _fetch_track_set(h):
     try:
         nt, no = C.c_int32(), C.c_int32()
         lib().msfm_track_set_size(h, C.byref(nt), C.byref(no))
@@ -142,6 +136,33 @@ def build_tracks(n_features, pairs, matches_per_pair):
     finally:
         lib().msfm_track_set_destroy(h)
     return toff, oi[:no.value], of[:no.value]
+
+
+def build_tracks(n_features, pairs, matches_per_pair):
+    """SLAMGPS::Triangulation's data association (slam_gps.cc:565-635), the walk over the match lists on the host as the
+    reference does it.  n_features[image]; pairs [(idx1, idx2)] in visiting order; matches_per_pair[p] = int array [m][2]
+    (feature in idx1, feature in idx2).
+    Returns CSR tracks: track_off, obs_image, obs_feature (observations in ascending image order).
+    `Context.build_tracks` returns the same from the GPU."""
+    nf, pr, off, flat = _flatten_matches(n_features, pairs, matches_per_pair)
+    h = C.c_void_p()
+    rc = lib().msfm_tracks_build(len(nf), A.ptr(nf, A.c_int_p), len(pr), A.ptr(pr, A.c_int_p), A.ptr(off, A.c_int_p),
+                                 A.ptr(flat, A.c_int_p), C.byref(h))
+    if rc != 0:
+        raise MsfmError(rc, "msfm_tracks_build: invalid input")
+    return _fetch_track_set(h)
+
+
+def build_tracks_flat(n_features, pairs, match_off, matches):
+    """`build_tracks` on flat int32 arrays (pairs [P][2], match_off [P+1], matches [M][2])."""
+    nf, pr, off = (A.as_c(np.asarray(x, dtype=np.int32), np.int32) for x in (n_features, pairs, match_off))
+    fl = A.as_c(np.asarray(matches, dtype=np.int32).reshape(-1, 2), np.int32)
+    h = C.c_void_p()
+    rc = lib().msfm_tracks_build(len(nf), A.ptr(nf, A.c_int_p), len(pr), A.ptr(pr, A.c_int_p), A.ptr(off, A.c_int_p),
+                                 A.ptr(fl, A.c_int_p), C.byref(h))
+    if rc != 0:
+        raise MsfmError(rc, "msfm_tracks_build: invalid input")
+    return _fetch_track_set(h)
 
 
 def fransac_options(**kw):
@@ -271,6 +292,15 @@ class Context:
         self.check(fn(self._h, C.byref(tracks.struct), th_error, th_angle, A.ptr(X, A.c_double_p),
                       A.ptr(mse, A.c_double_p), A.ptr(ok, A.c_u8_p)))
         return X, mse, ok
+
+    def build_tracks(self, n_features, pairs, matches_per_pair, flat=None):
+        """`build_tracks` on the GPU (msfm_tracks_build_device): identical output.  `flat` = (n_features, pairs [p][2],
+        match_off [p+1], matches [m][2]) int32 arrays skips the per-pair Python lists."""
+        nf, pr, off, fl = flat if flat is not None else _flatten_matches(n_features, pairs, matches_per_pair)
+        h = C.c_void_p()
+        self.check(lib().msfm_tracks_build_device(self._h, len(nf), A.ptr(nf, A.c_int_p), len(pr), A.ptr(pr, A.c_int_p),
+                                                  A.ptr(off, A.c_int_p), A.ptr(fl, A.c_int_p), C.byref(h)))
+        return _fetch_track_set(h)
 
     def triangulate_midpoint(self, tracks, th_error, th_angle, X0=None):
         return self._tri(lib().msfm_triangulate_midpoint_batch, tracks, th_error, th_angle, X0)

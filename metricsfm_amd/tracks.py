@@ -46,6 +46,45 @@ def matches_from_scene(sc, pairs=None):
     return [len(k) for k in keyp], keyp, out_pairs, matches
 
 
+def flat_matches_from_scene(sc, wrong=0.0, seed=0):
+    """`matches_from_scene` for every ordered image pair (i, j != i) of a large scene, as flat int32 arrays (vectorised; config
+    3: 6 M matches): n_features [n_cams], pairs [P][2] in the reference's visiting order (idx1 ascending, idx2 ascending),
+    match_off [P+1], matches [M][2] (points ascending inside a pair).  A fraction `wrong` of the matches has its second
+    feature replaced by a random feature of that image (what a real matcher's outliers look like to the track builder)."""
+    oc = np.asarray(sc.obs_cam, dtype=np.int64)
+    op = np.asarray(sc.obs_pt, dtype=np.int64)
+    n, No = sc.n_cams, len(oc)
+    assert (np.diff(op) >= 0).all()
+    # feature index of an observation = its rank among its camera's observations
+    by_cam = np.argsort(oc, kind="stable")
+    nf = np.bincount(oc, minlength=n)
+    start = np.concatenate([[0], np.cumsum(nf)])
+    feat = np.empty(No, dtype=np.int64)
+    feat[by_cam] = np.arange(No) - start[oc[by_cam]]
+    # every observation paired with the other observations of its point
+    k = np.bincount(op, minlength=sc.n_points)
+    first = np.concatenate([[0], np.cumsum(k)])
+    reps = k[op] - 1
+    a = np.repeat(np.arange(No), reps)
+    r = np.arange(len(a)) - np.repeat(np.cumsum(reps) - reps, reps)
+    pos = np.arange(No) - first[op]
+    b = first[op[a]] + r + (r >= pos[a])
+    key = oc[a] * n + oc[b]
+    order = np.lexsort((op[a], key))
+    a, b, key = a[order], b[order], key[order]
+    keep = oc[a] != oc[b]                                     # (a point seen twice by one camera makes no pair with itself)
+    a, b, key = a[keep], b[keep], key[keep]
+    ukey, counts = np.unique(key, return_counts=True)
+    pairs = np.column_stack([ukey // n, ukey % n]).astype(np.int32)
+    moff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    m = np.column_stack([feat[a], feat[b]]).astype(np.int32)
+    if wrong > 0:
+        rng = np.random.default_rng(seed)
+        w = np.nonzero(rng.random(len(m)) < wrong)[0]
+        m[w, 1] = (rng.random(len(w)) * nf[oc[b[w]]]).astype(np.int32)
+    return nf.astype(np.int32), pairs, moff, np.ascontiguousarray(m)
+
+
 def generate_new_points(ctx: capi.Context, cam1, visible_cams, matches_per_cam, done1, done2_per_cam, keypoints, cam_R, cam_t, cam_c,
                         cam_fk, th_mse_reprojection=3.0, th_angle_small=3.0 / 180.0 * 3.1415, th_angle_large=5.0 / 180.0 * 3.1415):
     """IncrementalSfM::GenerateNew3DPoints (sfm_incremental.cc:755-915) for the newest camera `cam1`: every match with a

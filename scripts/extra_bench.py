@@ -29,6 +29,25 @@ out["float_descriptors"] = dict(pairs=len(pairs), ms=1e3 * dt, Mmatches_per_s=1e
                                 path="MSFM_KNN_EXACT=%s" % os.environ.get("MSFM_KNN_EXACT", "0"))
 ctx.profile(True); ctx.profile_reset(); res.rerun(); ctx.synchronize(); out["float_kernels"] = ctx.profile_get(); ctx.profile(False)
 out["float_stats"] = res.stats()
+# ---- track building at config 3 scale: every ordered pair's matches of the 500-camera scene (+ 2 % wrong ones) ----
+if "--no-tracks" not in sys.argv:
+    from metricsfm_amd import tracks as T
+    sc3 = scene.config_scene(3)
+    flat = T.flat_matches_from_scene(sc3, wrong=0.02, seed=5)
+    ctx.build_tracks(None, None, None, flat=flat)   # (first call: pool allocations)
+    t0 = time.perf_counter()
+    got = ctx.build_tracks(None, None, None, flat=flat)
+    dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    host = capi.build_tracks_flat(*flat)
+    hst = time.perf_counter() - t0
+    same = all(np.array_equal(g, h) for g, h in zip(got, host))
+    out["tracks_config3"] = dict(matches=int(len(flat[3])), pairs=int(len(flat[1])), tracks=int(len(got[0]) - 1), observations=int(len(got[1])),
+                                 device_ms=1e3 * dev, host_walk_ms=1e3 * hst, identical=bool(same),
+                                 Mmatches_per_s_device=1e-6 * len(flat[3]) / dev, Mmatches_per_s_host=1e-6 * len(flat[3]) / hst,
+                                 note="msfm_tracks_build_device incl. upload of the match lists and download of the CSR tracks, "
+                                      "vs msfm_tracks_build (one host thread, the reference's walk)")
+    del sc3, flat, got, host
 # ---- config 5 ----
 if "--c5" in sys.argv:
     t0 = time.time()
