@@ -250,10 +250,12 @@ def main():
     if not win:
         k = np.bincount(sc.obs_pt, minlength=sc.n_points).astype(np.int64)
         n_pairs_cc = int((k * (k + 1) // 2).sum())
-        add("ba_linearize", "hbm", sc.n_obs * (24 + 16 + 46 * 8), "bytes read + written per linearisation")
-        add("ba_point", "hbm", sc.n_obs * 44 * 8 + sc.n_points * 12 * 8, "SoA Jacobians in, T / T.u records out")
+        # (the rows are linearised inside k_point and again inside k_backsub: 52 bytes of row data per observation in,
+        # instead of a 26-double stored Jacobian row written once and read twice)
+        add("ba_point", "hbm", sc.n_obs * (52 + 160 + 144 + 48) + sc.n_points * (24 + 96),
+            "row data + point in; camera-major row (160 B), T (144 B), T.u (48 B) per observation and L, g, diagonal per point out")
         add("ba_schur_pairs", "hbm", (n_pairs_cc + sc.n_obs) * 288 + sc.n_points * 144, "two 144-byte T records gathered per pair entry")
-        add("ba_backsub", "hbm", sc.n_obs * 26 * 8 + sc.n_points * 9 * 8, "SoA Jacobians in, candidate points out")
+        add("ba_backsub", "hbm", sc.n_obs * 52 + sc.n_points * 12 * 8, "row data, point and its 3x3 factor in, candidate point out")
         add("ba_ftf", "hbm", sc.n_obs * 26 * 8, "camera-major rows in")
     dom = kernels[0]
     step_bw = alg_bytes / (ba_s / args.steps) / 1e9

@@ -650,7 +650,8 @@ std::vector<Point3D> BuildTracks(const std::string& fold, const std::vector<std:
     }
   }
   msfm_track_set* set = nullptr;
-  check(msfm_tracks_build(n_img, n_feat.data(), (int)pair_img.size() / 2, pair_img.data(), off.data(), flat.data(), &set), "tracks_build");
+  // the whole image set at once: the GPU form of the walk (identical result, tests/test_gpu_tracks.py)
+  check(msfm_tracks_build_device(Context(), n_img, n_feat.data(), (int)pair_img.size() / 2, pair_img.data(), off.data(), flat.data(), &set), "tracks_build");
   int nt = 0, no = 0;
   msfm_track_set_size(set, &nt, &no);
   std::vector<int> toff(nt + 1), oi(std::max(1, no)), of(std::max(1, no));

@@ -251,7 +251,7 @@ bool ReadinImageFeatures(const std::string& output_fold, int idx, ImageInfo& inf
 
 // Track building, the data association of SLAMGPS::Triangulation (slam_gps.cc:565-635): walk the match graph in the
 // reference's order (idx1 ascending, idx2 ascending over match_graph[idx1][idx2] > 0, matches read back with
-// QueryMatch) and grow points greedily - msfm_tracks_build keeps the std::map::insert semantics.  Returns the new
+// QueryMatch) and grow points greedily - msfm_tracks_build_device keeps the std::map::insert semantics.  Returns the new
 // points with their observations attached (AddObservation(cam, x, y, image id), as :600-603 keys them).
 std::vector<Point3D> BuildTracks(const std::string& output_fold, const std::vector<std::vector<int>>& match_graph,
                                  std::vector<Camera>& cams, const std::vector<std::vector<Vec2>>& keypoints);

@@ -59,74 +59,101 @@ struct BaPtrs {
   const double *cam, *model, *pt;  // parameters being evaluated
   const int *o_cam, *o_model, *o_pt, *o_cb, *o_mb, *o_pb, *o_cpos, *o_pm;
   const double *o_x, *o_y, *o_w;
-  double *lin_r, *lin_Jc, *lin_Jm, *lin_Jp, *camrow;
+  double *lin_r, *lin_Jc, *lin_Jm, *camrow;   // lin_*: the rows [AE, A) only
   const double *scale_c, *scale_m, *scale_p;
   double huber;
 };
 
 // --------------------------------------------------------------------------------------
-// k_linearize: thread per active observation.
+// The linearisation of one observation row: corrected (Huber) and column-scaled residual and Jacobian blocks, as the
+// eliminator and the back substitution use them.  Returns the row's cost 1/2 rho(s).  k_point, k_backsub and k_linearize
+// all evaluate THIS function (26 doubles per row are cheaper to recompute from 52 bytes of row data and cached
+// parameters than to write once and read twice: 0.75 GB per LM iteration at config 3).
+// Rows of frozen blocks come out as zeros (their scales are 0).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ double obs_linearize(const BaPtrs& P, int i, double& r0, double& r1, double (&jc)[12], double (&jm)[6], double (&jp)[6]) {
+  const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
+  const int cb = P.o_cb[i], mb = P.o_mb[i], pb = P.o_pb[i];
+  double pose[6], cm[3], X[3];
+#pragma unroll
+  for (int j = 0; j < 6; j++) pose[j] = P.cam[6 * (size_t)c + j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; X[j] = P.pt[3 * (size_t)p + j]; }
+  const double ox = P.o_x[i], oy = P.o_y[i], ow = P.o_w[i];
+  double sc[6], sm[3], sp[3];   // column scales fetched together with the parameters
+#pragma unroll
+  for (int j = 0; j < 6; j++) sc[j] = cb >= 0 ? P.scale_c[6 * cb + j] : 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; j++) { sm[j] = mb >= 0 ? P.scale_m[3 * mb + j] : 0.0; sp[j] = pb >= 0 ? P.scale_p[3 * (size_t)pb + j] : 0.0; }
+  double r[2], J[24];
+  msfm_reproj(pose, cm, X, ox, oy, ow, r, J);
+  double rho0, rho1;
+  msfm_huber(P.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
+  const double sq = sqrt(rho1);
+  r0 = sq * r[0]; r1 = sq * r[1];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const double s = sq * sc[j];
+    jc[j] = s * J[j];
+    jc[6 + j] = s * J[12 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const double s = sq * sm[j];
+    jm[j] = s * J[6 + j];
+    jm[3 + j] = s * J[12 + 6 + j];
+    const double spj = sq * sp[j];
+    jp[j] = spj * J[9 + j];
+    jp[3 + j] = spj * J[12 + 9 + j];
+  }
+  return 0.5 * rho0;
+}
+// the camera-major copy of a row (160-byte rows: ten 16-byte stores), read by k_ftf
+__device__ __forceinline__ void store_camrow(double* __restrict__ camrow, int cp, const double (&jc)[12], const double (&jm)[6], double r0, double r1) {
+  double2* row = reinterpret_cast<double2*>(camrow + 20 * (size_t)cp);
+#pragma unroll
+  for (int j = 0; j < 6; j++) row[j] = make_double2(jc[2 * j], jc[2 * j + 1]);
+#pragma unroll
+  for (int j = 0; j < 3; j++) row[6 + j] = make_double2(jm[2 * j], jm[2 * j + 1]);
+  row[9] = make_double2(r0, r1);
+}
+
+// --------------------------------------------------------------------------------------
+// k_linearize: thread per active observation, rows [i0, A).  <false>: the cost only (trial points).  <true>: the stored
+// linearisation of the rows that belong to no eliminated point (i0 = AE; their point is frozen) - the rows of the
+// eliminated points are linearised inside k_point.
 // --------------------------------------------------------------------------------------
 template <bool WRITE_JAC>
-__global__ __launch_bounds__(256) void k_linearize(BaPtrs P, double* __restrict__ cost_partial) {
+__global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __restrict__ cost_partial) {
   __shared__ double sh[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = i0 + blockIdx.x * 256 + threadIdx.x;
   double cost = 0.0;
   if (i < P.A) {
-    const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
-    double pose[6], cm[3], X[3];
-#pragma unroll
-    for (int j = 0; j < 6; j++) pose[j] = P.cam[6 * (size_t)c + j];
-#pragma unroll
-    for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; X[j] = P.pt[3 * (size_t)p + j]; }
-    const double ox = P.o_x[i], oy = P.o_y[i], ow = P.o_w[i];
-    const int cb = P.o_cb[i], mb = P.o_mb[i], pb = P.o_pb[i], cp = P.o_cpos[i];
-    double sc[6], sm[3], sp[3];
-    if (WRITE_JAC) {  // column scales fetched together with the parameters, not one by one at the stores
-#pragma unroll
-      for (int j = 0; j < 6; j++) sc[j] = cb >= 0 ? P.scale_c[6 * cb + j] : 0.0;
-#pragma unroll
-      for (int j = 0; j < 3; j++) { sm[j] = mb >= 0 ? P.scale_m[3 * mb + j] : 0.0; sp[j] = pb >= 0 ? P.scale_p[3 * (size_t)pb + j] : 0.0; }
-    }
-    double r[2], J[24];
-    msfm_reproj(pose, cm, X, ox, oy, ow, r, WRITE_JAC ? J : nullptr);
-    double rho0, rho1;
-    msfm_huber(P.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
-    cost = 0.5 * rho0;
     if (WRITE_JAC) {
-      const double sq = sqrt(rho1);
-      const size_t A = P.A;
-      const double r0 = sq * r[0], r1 = sq * r[1];
-      P.lin_r[i] = r0;
-      P.lin_r[A + i] = r1;
-      double jc[12], jm[6];
+      double r0, r1, jc[12], jm[6], jp[6];
+      cost = obs_linearize(P, i, r0, r1, jc, jm, jp);
+      // stored rows exist for [AE, A) only: component-major over the A - AE rows (read by k_mcc_rest)
+      const size_t nt = (size_t)(P.A - P.AE), it = (size_t)(i - P.AE);
+      P.lin_r[it] = r0;
+      P.lin_r[nt + it] = r1;
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        const double s = sq * sc[j];
-        jc[j] = s * J[j];
-        jc[6 + j] = s * J[12 + j];
-        P.lin_Jc[(size_t)j * A + i] = jc[j];
-        P.lin_Jc[(size_t)(6 + j) * A + i] = jc[6 + j];
-      }
+      for (int j = 0; j < 12; j++) P.lin_Jc[(size_t)j * nt + it] = jc[j];
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const double s = sq * sm[j];
-        jm[j] = s * J[6 + j];
-        jm[3 + j] = s * J[12 + 6 + j];
-        P.lin_Jm[(size_t)j * A + i] = jm[j];
-        P.lin_Jm[(size_t)(3 + j) * A + i] = jm[3 + j];
-        const double spj = sq * sp[j];
-        P.lin_Jp[(size_t)j * A + i] = spj * J[9 + j];
-        P.lin_Jp[(size_t)(3 + j) * A + i] = spj * J[12 + 9 + j];
-      }
-      if (cp >= 0) {
-        double2* row = reinterpret_cast<double2*>(P.camrow + 20 * (size_t)cp);  // 160-byte rows: ten 16-byte stores
+      for (int j = 0; j < 6; j++) P.lin_Jm[(size_t)j * nt + it] = jm[j];
+      const int cp = P.o_cpos[i];
+      if (cp >= 0) store_camrow(P.camrow, cp, jc, jm, r0, r1);
+    } else {
+      const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
+      double pose[6], cm[3], X[3];
 #pragma unroll
-        for (int j = 0; j < 6; j++) row[j] = make_double2(jc[2 * j], jc[2 * j + 1]);
+      for (int j = 0; j < 6; j++) pose[j] = P.cam[6 * (size_t)c + j];
 #pragma unroll
-        for (int j = 0; j < 3; j++) row[6 + j] = make_double2(jm[2 * j], jm[2 * j + 1]);
-        row[9] = make_double2(r0, r1);
-      }
+      for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; X[j] = P.pt[3 * (size_t)p + j]; }
+      double r[2];
+      msfm_reproj(pose, cm, X, P.o_x[i], P.o_y[i], P.o_w[i], r, nullptr);
+      double rho0, rho1;
+      msfm_huber(P.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
+      cost = 0.5 * rho0;
     }
   }
   const double t = block_sum256(cost, sh);
@@ -206,47 +233,57 @@ __global__ __launch_bounds__(1024) void k_reduce(ReduceJobs J, double* __restric
 }
 
 // --------------------------------------------------------------------------------------
-// k_point: thread per eliminated point.  mode 0: full; mode 1: raw squared column norms only.
+// k_point: the eliminated points.  mode 0: full; mode 1: raw squared column norms only.
 // --------------------------------------------------------------------------------------
 struct PointPtrs {
-  int A, npb, NCR;
-  const int *pt_first, *o_cpos, *o_mb, *pm_first, *pm_mb;
-  const double *lin_r, *lin_Jc, *lin_Jm, *lin_Jp;
+  BaPtrs B;            // row data, parameters and scales the rows are linearised with
+  int npb, NCR;
+  const int *pt_first, *pm_first, *pm_mb;
   double *diag_p;
-  const double* scale_p;
   double *ptL, *ptg, *T, *Tu, *Tm, *Tmu;
   double radius, dmin, dmax;
   int reuse_diag, mode;
+  int store_rows;      // first pass at this linearisation point: also write the camera-major rows (k_ftf) and the cost
+  double* cost_partial;
   int* fail;
 };
 
 // (8-lane groups; after the first two steps the four lanes of a quad hold the same value, so adding lane 7 - i is adding lane i ^ 4)
 #define GROUP_SUM(x) { x += dpp_f64<MSFM_DPP_XOR1>(x); x += dpp_f64<MSFM_DPP_XOR2>(x); x += dpp_f64<MSFM_DPP_HALF_MIRROR>(x); }
 
-// 8 lanes per point, lane = observation (rounds of 8 for longer tracks): the SoA linearisation is
-// read coalesced, the per-point sums are 3-step xor reductions inside the 8-lane group, and every
-// lane then finishes its own observation's T = (Jc^T Jp) L^-T.  256 threads = 32 points.
+// 8 lanes per point, lane = observation (rounds of 8 for longer tracks).  Every lane linearises its own row
+// (obs_linearize: the row data is read coalesced, the parameters come from cache), the per-point sums are 3-step
+// reductions inside the 8-lane group, and every lane then finishes its own observation's T = (Jc^T Jp) L^-T.
+// 256 threads = 32 points.  Tracks of up to 8 views keep their rows in registers; longer ones linearise them again.
 __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__ gmax_partial) {
   __shared__ double sh[4];
   const int tid = threadIdx.x, sub = tid & 7;
   const int pb = blockIdx.x * 32 + (tid >> 3);
   const bool act = pb < P.npb;
-  const size_t A = P.A;
   int f = 0, l = 0;
   if (act) { f = P.pt_first[pb]; l = P.pt_first[pb + 1]; }
   const bool single = (l - f) <= 8;
   double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0;
-  double ca0 = 0, ca1 = 0, ca2 = 0, cb0 = 0, cb1 = 0, cb2 = 0;  // this lane's Jp of the (only) round
+  double jcs[12], jms[6], jps[6];   // this lane's row of the (only) round
+#pragma unroll
+  for (int k = 0; k < 12; k++) jcs[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { jms[k] = 0.0; jps[k] = 0.0; }
+  double cost = 0.0;
   for (int base = f; base < l; base += 8) {
     const int i = base + sub;
     if (i < l) {
-      const double a0 = P.lin_Jp[i], a1 = P.lin_Jp[A + i], a2 = P.lin_Jp[2 * A + i];
-      const double b0 = P.lin_Jp[3 * A + i], b1 = P.lin_Jp[4 * A + i], b2 = P.lin_Jp[5 * A + i];
-      const double r0 = P.lin_r[i], r1 = P.lin_r[A + i];
+      double r0, r1;
+      const double ci = obs_linearize(P.B, i, r0, r1, jcs, jms, jps);
+      if (P.store_rows) {
+        cost += ci;
+        const int cp = P.B.o_cpos[i];
+        if (cp >= 0) store_camrow(P.B.camrow, cp, jcs, jms, r0, r1);
+      }
+      const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
       V00 += a0 * a0 + b0 * b0; V10 += a1 * a0 + b1 * b0; V11 += a1 * a1 + b1 * b1;
       V20 += a2 * a0 + b2 * b0; V21 += a2 * a1 + b2 * b1; V22 += a2 * a2 + b2 * b2;
       g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
-      ca0 = a0; ca1 = a1; ca2 = a2; cb0 = b0; cb1 = b1; cb2 = b2;
     }
   }
   GROUP_SUM(V00) GROUP_SUM(V10) GROUP_SUM(V11) GROUP_SUM(V20) GROUP_SUM(V21) GROUP_SUM(V22)
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
         L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
         double* gp = P.ptg + 3 * (size_t)pb;
         gp[0] = g0; gp[1] = g1; gp[2] = g2;
-        const double* sp = P.scale_p + 3 * (size_t)pb;
+        const double* sp = P.B.scale_p + 3 * (size_t)pb;
         gmax = fmax(fabs(g0 / sp[0]), fmax(fabs(g1 / sp[1]), fabs(g2 / sp[2])));
       }
     }
@@ -297,32 +334,27 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
   if (P.mode != 1) {
     // camera entries: T = (Jc^T Jp) L^-T (one 144-byte record per observation, camera-major), T.u
     // Stores: neighbouring lanes hold the observations of ONE point - eight different cameras, eight far-apart addresses,
-    // one 8-byte write request per lane and component (21.6 M at C3).  The lanes of a wave therefore trade records first, (point q, observation s) -> lane 8 s + q: now
-    // neighbouring lanes hold the same observation slot of consecutive points, which sit at consecutive positions of one
-    // camera wherever the points share their cameras, and the stores of a quad merge (k_point 0.229 -> 0.223 ms at C3; a
-    // record-major T was also measured: the same here, but k_pairs 0.28 -> 0.49 ms).
+    // one 8-byte write request per lane and component (21.6 M at C3).  The lanes of a wave therefore trade records first,
+    // (point q, observation s) -> lane 8 s + q: now neighbouring lanes hold the same observation slot of consecutive
+    // points, which sit at consecutive positions of one camera wherever the points share their cameras, and the stores
+    // of a quad merge (k_point 0.229 -> 0.223 ms at C3; a record-major T was also measured: the same here, but k_pairs
+    // 0.28 -> 0.49 ms).
     const int wl = tid & 63, tsrc = ((wl & 7) << 3) | (wl >> 3);
     for (int rd = 0; __any(f + rd < l); rd += 8) {
       const int i = f + rd + sub;
       int cp = -1;
-      if (i < l) cp = P.o_cpos[i];
+      if (i < l) cp = P.B.o_cpos[i];
       double T[18], tu[6];
 #pragma unroll
       for (int k = 0; k < 18; k++) T[k] = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; k++) tu[k] = 0.0;
       if (cp >= 0) {
-        double a0 = ca0, a1 = ca1, a2 = ca2, b0 = cb0, b1 = cb1, b2 = cb2;
-        if (!single) {
-          a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
-          b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
-        }
-        double jc[12];
-#pragma unroll
-        for (int a = 0; a < 12; a++) jc[a] = P.lin_Jc[(size_t)a * A + i];  // all loads before the first use
+        if (!single) { double r0, r1; obs_linearize(P.B, i, r0, r1, jcs, jms, jps); }
+        const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-          const double ja = jc[a], jb = jc[6 + a];
+          const double ja = jcs[a], jb = jcs[6 + a];
           const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
           const double t0 = w0 * i00;
           const double t1 = (w1 - l10 * t0) * i11;
@@ -356,19 +388,15 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
       for (int k = 0; k < 9; k++) W[k] = 0.0;
       for (int base = f; base < l; base += 8) {
         const int i = base + sub;
-        if (i < l && P.o_mb[i] == mb) {
-          double a0 = ca0, a1 = ca1, a2 = ca2, b0 = cb0, b1 = cb1, b2 = cb2;
-          if (!single) {
-            a0 = P.lin_Jp[i]; a1 = P.lin_Jp[A + i]; a2 = P.lin_Jp[2 * A + i];
-            b0 = P.lin_Jp[3 * A + i]; b1 = P.lin_Jp[4 * A + i]; b2 = P.lin_Jp[5 * A + i];
-          }
-          double jm[6];
-#pragma unroll
-          for (int a = 0; a < 6; a++) jm[a] = P.lin_Jm[(size_t)a * A + i];
+        if (i < l && P.B.o_mb[i] == mb) {
+          if (!single) { double r0, r1; obs_linearize(P.B, i, r0, r1, jcs, jms, jps); }
+          const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
 #pragma unroll
           for (int a = 0; a < 3; a++) {
-            const double ja = jm[a], jb = jm[3 + a];
-            W[a * 3 + 0] += ja * a0 + jb * b0; W[a * 3 + 1] += ja * a1 + jb * b1; W[a * 3 + 2] += ja * a2 + jb * b2;
+            const double ja = jms[a], jb = jms[3 + a];
+            W[a * 3 + 0] += ja * a0 + jb * b0;
+            W[a * 3 + 1] += ja * a1 + jb * b1;
+            W[a * 3 + 2] += ja * a2 + jb * b2;
           }
         }
       }
@@ -387,6 +415,10 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
         }
       }
     }
+  }
+  if (P.store_rows) {
+    const double tc = block_sum256(cost, sh);
+    if (threadIdx.x == 0) P.cost_partial[blockIdx.x] = tc;
   }
   const double t = block_max256(gmax, sh);
   if (threadIdx.x == 0) gmax_partial[blockIdx.x] = t;
@@ -754,9 +786,10 @@ __global__ __launch_bounds__(256) void k_update_blocks(int nblocks, int dim, con
 }
 
 struct BackPtrs {
-  int A, npb, ncb;
-  const int *pt_first, *o_cb, *o_mb, *pb_pt;
-  const double *lin_r, *lin_Jc, *lin_Jm, *lin_Jp, *ptL, *z, *scale_p, *pt;
+  BaPtrs B;   // the rows are linearised again (obs_linearize) at the point the reduced system was built at
+  int npb, ncb;
+  const int *pt_first, *pb_pt;
+  const double *ptL, *z;
   double* pt_c;
 };
 
@@ -770,24 +803,16 @@ __global__ __launch_bounds__(256) void k_backsub(BackPtrs P, double* __restrict_
   const int tid = threadIdx.x, sub = tid & 7;
   const int pb = blockIdx.x * 32 + (tid >> 3);
   const bool act = pb < P.npb;
-  const size_t A = P.A;
   int f = 0, l = 0;
   if (act) { f = P.pt_first[pb]; l = P.pt_first[pb + 1]; }
   double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0, h0 = 0, h1 = 0, h2 = 0, qr = 0, qq = 0;
   for (int base = f; base < l; base += 8) {
     const int i = base + sub;
     if (i < l) {
-      // every load of this observation is issued before the first use (hipcc otherwise waits after
-      // each one inside the predicated region); rows of frozen blocks hold zeros, so no branches
-      const int cb = P.o_cb[i], mb = P.o_mb[i];
-      double jc[12], jm[6], jp[6], zc[6], zm[3];
-#pragma unroll
-      for (int j = 0; j < 12; j++) jc[j] = P.lin_Jc[(size_t)j * A + i];
-#pragma unroll
-      for (int j = 0; j < 6; j++) jm[j] = P.lin_Jm[(size_t)j * A + i];
-#pragma unroll
-      for (int j = 0; j < 6; j++) jp[j] = P.lin_Jp[(size_t)j * A + i];
-      const double r0 = P.lin_r[i], r1 = P.lin_r[A + i];
+      // rows of frozen blocks come out as zeros, so no branches
+      const int cb = P.B.o_cb[i], mb = P.B.o_mb[i];
+      double jc[12], jm[6], jp[6], zc[6], zm[3], r0, r1;
+      obs_linearize(P.B, i, r0, r1, jc, jm, jp);
       const double* zcp = P.z + 6 * (cb >= 0 ? cb : 0);
       const double* zmp = P.z + 6 * P.ncb + 3 * (mb >= 0 ? mb : 0);
 #pragma unroll
@@ -822,9 +847,9 @@ __global__ __launch_bounds__(256) void k_backsub(BackPtrs P, double* __restrict_
     q1 = (q1 - l21 * q2) / l11;
     q0 = (q0 - l10 * q1 - l20 * q2) / l00;
     const double s0 = -q0, s1 = -q1, s2 = -q2;  // step (scaled space)
-    const double* sc = P.scale_p + 3 * (size_t)pb;
+    const double* sc = P.B.scale_p + 3 * (size_t)pb;
     const size_t p = P.pb_pt[pb];
-    const double x0 = P.pt[3 * p], x1 = P.pt[3 * p + 1], x2v = P.pt[3 * p + 2];
+    const double x0 = P.B.pt[3 * p], x1 = P.B.pt[3 * p + 1], x2v = P.B.pt[3 * p + 2];
     const double c0 = x0 + s0 * sc[0], c1 = x1 + s1 * sc[1], c2 = x2v + s2 * sc[2];
     P.pt_c[3 * p] = c0; P.pt_c[3 * p + 1] = c1; P.pt_c[3 * p + 2] = c2;
     dx2 = (c0 - x0) * (c0 - x0) + (c1 - x1) * (c1 - x1) + (c2 - x2v) * (c2 - x2v);
@@ -850,14 +875,14 @@ __global__ __launch_bounds__(256) void k_mcc_rest(int A, int AE, int ncb, const 
   double mcc = 0.0;
   if (t < nrest) {
     const int i = AE + t;
-    const size_t As = A;
+    const size_t As = (size_t)nrest, it = (size_t)t;   // the stored rows are indexed from AE
     double m0 = 0, m1 = 0;
     const int cb = o_cb[i], mb = o_mb[i];
     if (cb >= 0)
-      for (int j = 0; j < 6; j++) { const double sj = -z[6 * cb + j]; m0 += lin_Jc[(size_t)j * As + i] * sj; m1 += lin_Jc[(size_t)(6 + j) * As + i] * sj; }
+      for (int j = 0; j < 6; j++) { const double sj = -z[6 * cb + j]; m0 += lin_Jc[(size_t)j * As + it] * sj; m1 += lin_Jc[(size_t)(6 + j) * As + it] * sj; }
     if (mb >= 0)
-      for (int j = 0; j < 3; j++) { const double sj = -z[6 * ncb + 3 * mb + j]; m0 += lin_Jm[(size_t)j * As + i] * sj; m1 += lin_Jm[(size_t)(3 + j) * As + i] * sj; }
-    mcc -= m0 * (lin_r[i] + m0 / 2.0) + m1 * (lin_r[As + i] + m1 / 2.0);
+      for (int j = 0; j < 3; j++) { const double sj = -z[6 * ncb + 3 * mb + j]; m0 += lin_Jm[(size_t)j * As + it] * sj; m1 += lin_Jm[(size_t)(3 + j) * As + it] * sj; }
+    mcc -= m0 * (lin_r[it] + m0 / 2.0) + m1 * (lin_r[As + it] + m1 / 2.0);
   } else if (has_gps && t < nrest + ncb) {
     const int cb = t - nrest;
     for (int k = 0; k < 3; k++) {
@@ -917,7 +942,7 @@ struct msfm_ba {
   DevBuf<int> cb_cam, mb_model, pb_pt, cb_mb;
   DevBuf<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
   DevBuf<double> o_x, o_y, o_w;
-  DevBuf<double> lin_r, lin_Jc, lin_Jm, lin_Jp, camrow, T, Tu, Tm, Tmu;
+  DevBuf<double> lin_r, lin_Jc, lin_Jm, camrow, T, Tu, Tm, Tmu;
   DevBuf<int> cpos_pb;
   DevBuf<double> scale_c, scale_m, scale_p, diag_c, diag_m, diag_p;
   DevBuf<int> pt_first, pm_first, pm_mb;
@@ -937,6 +962,8 @@ struct msfm_ba {
   hipEvent_t ev_scal = nullptr;
   int* h_fail = nullptr;
   int nblk_obs = 0, nblk_pt = 0;
+  bool lin_pending = false;   // run_evaluate(jac) was asked for: the next k_point linearises, writes the camera rows and the cost
+  double lin_huber = 1.0;
   double setup_ms = 0;
   int world_at_create = 1;
   // multi-rank: camera-camera blocks present on ANY rank, packed for the per-iteration sum
@@ -2314,7 +2341,8 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
 #define AL(buf, n) HIP_TRY(ctx, ba->buf.alloc((size_t)std::max<size_t>(1, (n))))
   AL(cam, 6 * (size_t)Nc); AL(model, 3 * (size_t)Nm); AL(pt, 3 * (size_t)std::max(1, Np));
   AL(cam_c, 6 * (size_t)Nc); AL(model_c, 3 * (size_t)Nm); AL(pt_c, 3 * (size_t)std::max(1, Np));
-  AL(lin_r, 2 * As); AL(lin_Jc, 12 * As); AL(lin_Jm, 6 * As); AL(lin_Jp, 6 * As);
+  const size_t Atail = (size_t)std::max(1, A - ba->AE);   // rows of frozen points: the only ones whose linearisation is stored
+  AL(lin_r, 2 * Atail); AL(lin_Jc, 12 * Atail); AL(lin_Jm, 6 * Atail);
   AL(camrow, 20 * (size_t)NCR); AL(T, 18 * (size_t)NCR); AL(Tu, 6 * (size_t)NCR);
   AL(Tm, 9 * (size_t)NPM); AL(Tmu, 3 * (size_t)NPM);
   AL(scale_c, 6 * (size_t)ncb); AL(scale_m, 3 * (size_t)nmb); AL(scale_p, 3 * (size_t)npb);
@@ -2334,7 +2362,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   {
     // every device buffer a kernel may dereference must exist before the first launch
     const void* must[] = {ba->cam.p, ba->model.p, ba->pt.p, ba->cam_c.p, ba->model_c.p, ba->pt_c.p, ba->lin_r.p, ba->lin_Jc.p,
-                          ba->lin_Jm.p, ba->lin_Jp.p, ba->camrow.p, ba->T.p, ba->Tu.p, ba->Tm.p, ba->Tmu.p, ba->scale_c.p,
+                          ba->lin_Jm.p, ba->camrow.p, ba->T.p, ba->Tu.p, ba->Tm.p, ba->Tmu.p, ba->scale_c.p,
                           ba->scale_m.p, ba->scale_p.p, ba->diag_c.p, ba->diag_m.p, ba->diag_p.p, ba->ptL.p, ba->ptg.p,
                           ba->f_partial.p, ba->camftf.p, ba->modelsum.p, ba->M.p, ba->Linv.p, ba->w.p, ba->z.p, ba->g_r.p,
                           ba->g_J.p, ba->partial.p, ba->partial2.p, ba->partial3.p, ba->gmax_buf.p, ba->scal.p, ba->fail.p};
@@ -2421,7 +2449,7 @@ static BaPtrs make_ptrs(msfm_ba* ba, bool candidate, double huber) {
   P.o_cam = ba->o_cam.p; P.o_model = ba->o_model.p; P.o_pt = ba->o_pt.p; P.o_cb = ba->o_cb.p; P.o_mb = ba->o_mb.p;
   P.o_pb = ba->o_pb.p; P.o_cpos = ba->o_cpos.p; P.o_pm = ba->o_pm.p;
   P.o_x = ba->o_x.p; P.o_y = ba->o_y.p; P.o_w = ba->o_w.p;
-  P.lin_r = ba->lin_r.p; P.lin_Jc = ba->lin_Jc.p; P.lin_Jm = ba->lin_Jm.p; P.lin_Jp = ba->lin_Jp.p; P.camrow = ba->camrow.p;
+  P.lin_r = ba->lin_r.p; P.lin_Jc = ba->lin_Jc.p; P.lin_Jm = ba->lin_Jm.p; P.camrow = ba->camrow.p;
   P.scale_c = ba->scale_c.p; P.scale_m = ba->scale_m.p; P.scale_p = ba->scale_p.p;
   P.huber = huber;
   return P;
@@ -2446,14 +2474,23 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int
   // only the lead rank counts their cost
   const int nb = ba->nblk_obs, ng = ba->has_gps ? cdiv(ba->ncb, 256) : 0;
   BaPtrs P = make_ptrs(ba, candidate, huber);
+  if (jac) {
+    // The rows of the eliminated points are linearised inside the next k_point (run_assemble), which also writes their
+    // camera-major copies and cost partials [0, nblk_pt); here only the rows of frozen points (their blocks
+    // [nblk_pt, nblk_pt + ntail)) and the GPS rows.  The sum into `slot` follows k_point.
+    KTimer t(ctx, "ba_linearize");
+    const int ntail = cdiv(ba->A - ba->AE, 256);
+    if (ntail) hipLaunchKernelGGL(k_linearize<true>, dim3(ntail), dim3(256), 0, s, P, ba->AE, ba->partial.p + ba->nblk_pt);
+    if (ng) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + ba->nblk_pt + ntail);
+    ba->lin_pending = true;
+    ba->lin_huber = huber;
+    (void)slot;   // S_XCOST
+    return MSFM_OK;
+  }
   {
-    KTimer t(ctx, jac ? "ba_linearize" : "ba_cost");
-    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb), dim3(256), 0, s, P, ba->partial.p);
-    else hipLaunchKernelGGL(k_linearize<false>, dim3(nb), dim3(256), 0, s, P, ba->partial.p);
-    if (ng) {
-      if (jac) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
-      else hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
-    }
+    KTimer t(ctx, "ba_cost");
+    hipLaunchKernelGGL(k_linearize<false>, dim3(nb), dim3(256), 0, s, P, 0, ba->partial.p);
+    if (ng) hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
     ReduceJobs rj;
     rj.count = 1;
     rj.job[0] = {ba->partial.p, nb + (lead ? ng : 0), slot, 0};
@@ -2470,16 +2507,19 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   hipStream_t s = ctx->stream;
   const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
   const int lead = ctx->rank == 0 ? 1 : 0;
+  const bool store_rows = ba->lin_pending;   // new linearisation point (else: the same rows again, new radius)
+  ba->lin_pending = false;
   {
     KTimer t(ctx, "ba_point");
     PointPtrs Q;
-    Q.A = ba->A; Q.npb = npb; Q.NCR = std::max(1, ba->NCR); Q.pt_first = ba->pt_first.p; Q.o_cpos = ba->o_cpos.p; Q.o_mb = ba->o_mb.p;
+    Q.B = make_ptrs(ba, false, ba->lin_huber);
+    Q.npb = npb; Q.NCR = std::max(1, ba->NCR); Q.pt_first = ba->pt_first.p;
     Q.pm_first = ba->pm_first.p; Q.pm_mb = ba->pm_mb.p;
-    Q.lin_r = ba->lin_r.p; Q.lin_Jc = ba->lin_Jc.p; Q.lin_Jm = ba->lin_Jm.p; Q.lin_Jp = ba->lin_Jp.p;
-    Q.diag_p = ba->diag_p.p; Q.scale_p = ba->scale_p.p; Q.ptL = ba->ptL.p; Q.ptg = ba->ptg.p;
+    Q.diag_p = ba->diag_p.p; Q.ptL = ba->ptL.p; Q.ptg = ba->ptg.p;
     Q.T = ba->T.p; Q.Tu = ba->Tu.p; Q.Tm = ba->Tm.p; Q.Tmu = ba->Tmu.p;
     Q.radius = radius; Q.dmin = opt->min_lm_diagonal; Q.dmax = opt->max_lm_diagonal;
     Q.reuse_diag = reuse_diag; Q.mode = mode; Q.fail = ba->fail.p;
+    Q.store_rows = store_rows ? 1 : 0; Q.cost_partial = ba->partial.p;
     hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, s, Q, ba->gmax_buf.p);
   }
   // The Schur pair products read only what k_point wrote (T, Tm, Tmu) and write their own partials; the per-camera sums
@@ -2537,9 +2577,15 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     ReduceJobs rj;
     rj.count = 1;
     rj.job[0] = {ba->gmax_buf.p, ba->nblk_pt + 6 * ncb + 3 * nmb, S_GMAX, 1};
+    if (store_rows) {
+      // cost at x: k_point's blocks, the frozen points' rows, the GPS rows (lead rank only) - see run_evaluate
+      const int ntail = cdiv(ba->A - ba->AE, 256), ng = (ba->has_gps && lead) ? cdiv(ncb, 256) : 0;
+      rj.job[1] = {ba->partial.p, ba->nblk_pt + ntail + ng, S_XCOST, 0};
+      rj.count = 2;
+    }
     rj.fail = ba->fail.p;
     rj.fail_slot = S_FAIL;
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, rj, ba->swrite);
+    hipLaunchKernelGGL(k_reduce, dim3(rj.count), dim3(1024), 0, s, rj, ba->swrite);
   }
   if (forked) {
     HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
@@ -2658,9 +2704,9 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
     int moff = 0;
     if (npb) {
       BackPtrs Q;
-      Q.A = ba->A; Q.npb = npb; Q.ncb = ncb; Q.pt_first = ba->pt_first.p; Q.o_cb = ba->o_cb.p; Q.o_mb = ba->o_mb.p; Q.pb_pt = ba->pb_pt.p;
-      Q.lin_r = ba->lin_r.p; Q.lin_Jc = ba->lin_Jc.p; Q.lin_Jm = ba->lin_Jm.p; Q.lin_Jp = ba->lin_Jp.p; Q.ptL = ba->ptL.p; Q.z = ba->z.p;
-      Q.scale_p = ba->scale_p.p; Q.pt = ba->pt.p; Q.pt_c = ba->pt_c.p;
+      Q.B = make_ptrs(ba, false, ba->lin_huber);
+      Q.npb = npb; Q.ncb = ncb; Q.pt_first = ba->pt_first.p; Q.pb_pt = ba->pb_pt.p;
+      Q.ptL = ba->ptL.p; Q.z = ba->z.p; Q.pt_c = ba->pt_c.p;
       hipLaunchKernelGGL(k_backsub, dim3(nbp), dim3(256), 0, s, Q, ba->partial.p, ba->partial2.p + off, ba->partial3.p + off);
       off += nbp; moff += nbp;
     }
