@@ -305,6 +305,19 @@ __device__ __forceinline__ void p0_store(double* Bs, int tid, const d2 (&pv)[8])
   }
 }
 
+// Workgroup 0 of a job publishes the factor of the diagonal block and the inverses of its 16x16 diagonal blocks.
+// Sub-panel jbp (16 columns) is final once potrf16_v2<jbp> has passed its barrier: the helper waves write it out while
+// wave 0 factors the next sub-panel, so that only the last quarter is left for the tail of the launch (the launch ends
+// with workgroup 0: 33.7 k cycles against 31.4 k for the other column-0 workgroups before this).
+__device__ __forceinline__ void publish_subpanel(const double* Ls, const double* dinv, double* __restrict__ lo, double* __restrict__ out, int jbp,
+                                                 int h, int nh) {
+  for (int e = h; e < 1024; e += nh) {
+    const int r = e >> 4, c = 16 * jbp + (e & 15);
+    lo[r * NB + c] = (c <= r) ? Ls[r * LDT + c] : 0.0;
+  }
+  for (int e = h; e < 256; e += nh) out[256 * jbp + e] = dinv[(16 * jbp + (e >> 4)) * DV + (e & 15)];
+}
+
 // Column-0 workgroup.  Wave 0 and the helper waves run two different programs with the same number
 // of barriers (the branch is wave-uniform), so that the register file of a wave holds either the
 // pivot chain's state or a helper's tiles, never both.
@@ -354,6 +367,8 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     if (upd) p0_load(M, ld, t0, j0, tid, pv);
     const int rt = 4 + 3 * b + wave - 1;
     const bool own = rt < nrt;
+    double* const pub_lo = Ldiag + (size_t)(t0 / NB) * NB * NB;
+    double* const pub_out = Dinv + (size_t)(t0 / NB) * 1024;
     const size_t r0 = (size_t)job_row16(jb, own ? rt : 0);
     double preg[16];
     d4 T[4];
@@ -412,6 +427,7 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
 #pragma unroll
       for (int s = 0; s < 4; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(16 + lr) * LDT + lk + 4 * s], X[0][s], T[1], 0, 0, 0);
     }
+    if (b == 0) publish_subpanel(Ls, dinv, pub_lo, pub_out, 0, tid - 64, 192);
     __syncthreads();
     // ---- A2: (2,2), (3,2) -= L_x1 L_21^T ----
     if (wave != 3) tile_st(Ls, tb, 2, lr, lk, mm_nt_neg<4>(Ls, 16 * tb, Ls, 32, 16, lr, lk, tile_ld(Ls, tb, 2, lr, lk)));
@@ -432,6 +448,7 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
 #pragma unroll
         for (int s = 0; s < 4; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(32 + lr) * LDT + 16 * i2 + lk + 4 * s], X[i2][s], T[2], 0, 0, 0);
     }
+    if (b == 0) publish_subpanel(Ls, dinv, pub_lo, pub_out, 1, tid - 64, 192);
     __syncthreads();
     // ---- A3: (3,3) -= L_32 L_32^T ----
     if (wave == 3) tile_st(Ls, 3, 3, lr, lk, mm_nt_neg<4>(Ls, 48, Ls, 48, 32, lr, lk, tile_ld(Ls, 3, 3, lr, lk)));
@@ -451,6 +468,7 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
 #pragma unroll
         for (int s = 0; s < 4; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(48 + lr) * LDT + 16 * i2 + lk + 4 * s], X[i2][s], T[3], 0, 0, 0);
     }
+    if (b == 0) publish_subpanel(Ls, dinv, pub_lo, pub_out, 2, tid - 64, 192);
     __syncthreads();
     // ---- tail: X_3 = T_3 Dinv_3^T, store the own rows ----
     if (own) {
@@ -466,11 +484,8 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     }
   }
   if (b == 0) {
-    // workgroup 0 publishes the factor of the diagonal block
-    double* lo = Ldiag + (size_t)(t0 / NB) * NB * NB;
-    for (int e = tid; e < NB * NB; e += 256) lo[e] = ((e & 63) <= (e >> 6)) ? Ls[(e >> 6) * LDT + (e & 63)] : 0.0;
-    double* out = Dinv + (size_t)(t0 / NB) * 1024;
-    for (int e = tid; e < 1024; e += 256) out[e] = dinv[(e >> 4) * DV + (e & 15)];
+    // the last sub-panel of the diagonal block's factor (the helper waves wrote the other three during the launch)
+    publish_subpanel(Ls, dinv, Ldiag + (size_t)(t0 / NB) * NB * NB, Dinv + (size_t)(t0 / NB) * 1024, 3, tid, 256);
     if (!FULL) {
       // last, partial block: it also holds the rhs row (row n), whose entries are the tail of
       // w = L^-1 rhs that the back substitution reads from M.  No other workgroup reads this tile
