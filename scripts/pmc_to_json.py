@@ -16,9 +16,8 @@ import sys
 
 CLASSES = {  # bench.py kernel class -> substrings of the kernel names it launches
     "chol_panel_mfma": ["k_panel_v2"],
-    "ba_schur_pairs": ["k_pairs"],
-    "ba_point": ["k_point"],
-    "ba_linearize": ["k_linearize<true>", "k_linearize<(bool)1>"],
+    "ba_schur_pairs": ["k_pairs<"],          # (not devsetup::k_pairs_of_points, the list builders of msfm_ba_create)
+    "ba_point": ["k_point("],                # (not devsetup::k_point_keys / k_point_lengths)
     "ba_backsub": ["k_backsub"],
     "ba_ftf": ["k_ftf"],
 }
@@ -47,7 +46,7 @@ def main():
            "--no-matching`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts wide reads at 1/2, MI355X_MICROARCH.md "
            "HBM section); gather kernels are not under-counted: see bytes_per_launch_uncorrected")
     for cls, pats in CLASSES.items():
-        names = [k for k in fetch if any(p in k for p in pats)]
+        names = [k for k in fetch if any(p in k for p in pats) and "devsetup::" not in k]
         if not names:
             continue
         # one launch of the class = one launch of each member kernel (k_pairs has three instantiations per assembly)
