@@ -57,6 +57,7 @@ enum { S_COST = 0, S_MCC, S_DX2, S_X2, S_FAIL, S_XCOST, S_GMAX, S_RANK0 = 8, S_N
 struct BaPtrs {
   int A, AE, ncb, nmb, npb, NCR;
   const double *cam, *model, *pt;  // parameters being evaluated
+  const double* rot;               // msfm_rot_prepare of `cam` ([Nc][4])
   const int *o_cam, *o_model, *o_pt, *o_cb, *o_mb, *o_pb, *o_cpos, *o_pm;
   const double *o_x, *o_y, *o_w;
   double *lin_r, *lin_Jc, *lin_Jm, *camrow;   // lin_*: the rows [AE, A) only
@@ -74,19 +75,23 @@ struct BaPtrs {
 __device__ __forceinline__ double obs_linearize(const BaPtrs& P, int i, double& r0, double& r1, double (&jc)[12], double (&jm)[6], double (&jp)[6]) {
   const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
   const int cb = P.o_cb[i], mb = P.o_mb[i], pb = P.o_pb[i];
-  double pose[6], cm[3], X[3];
+  double pose[6], rc[4], cm[3], X[3];
 #pragma unroll
   for (int j = 0; j < 6; j++) pose[j] = P.cam[6 * (size_t)c + j];
 #pragma unroll
+  for (int j = 0; j < 4; j++) rc[j] = P.rot[4 * (size_t)c + j];
+#pragma unroll
   for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; X[j] = P.pt[3 * (size_t)p + j]; }
   const double ox = P.o_x[i], oy = P.o_y[i], ow = P.o_w[i];
-  double sc[6], sm[3], sp[3];   // column scales fetched together with the parameters
+  double r[2], J[24];
+  msfm_reproj(pose, rc, cm, X, ox, oy, ow, r, J);
+  // the column scales are fetched only now: twelve registers less while the projection is evaluated
+  __builtin_amdgcn_sched_barrier(0);
+  double sc[6], sm[3], sp[3];
 #pragma unroll
   for (int j = 0; j < 6; j++) sc[j] = cb >= 0 ? P.scale_c[6 * cb + j] : 0.0;
 #pragma unroll
   for (int j = 0; j < 3; j++) { sm[j] = mb >= 0 ? P.scale_m[3 * mb + j] : 0.0; sp[j] = pb >= 0 ? P.scale_p[3 * (size_t)pb + j] : 0.0; }
-  double r[2], J[24];
-  msfm_reproj(pose, cm, X, ox, oy, ow, r, J);
   double rho0, rho1;
   msfm_huber(P.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
   const double sq = sqrt(rho1);
@@ -144,13 +149,15 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __r
       if (cp >= 0) store_camrow(P.camrow, cp, jc, jm, r0, r1);
     } else {
       const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
-      double pose[6], cm[3], X[3];
+      double pose[6], rc[4], cm[3], X[3];
 #pragma unroll
       for (int j = 0; j < 6; j++) pose[j] = P.cam[6 * (size_t)c + j];
 #pragma unroll
+      for (int j = 0; j < 4; j++) rc[j] = P.rot[4 * (size_t)c + j];
+#pragma unroll
       for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; X[j] = P.pt[3 * (size_t)p + j]; }
       double r[2];
-      msfm_reproj(pose, cm, X, P.o_x[i], P.o_y[i], P.o_w[i], r, nullptr);
+      msfm_reproj(pose, rc, cm, X, P.o_x[i], P.o_y[i], P.o_w[i], r, nullptr);
       double rho0, rho1;
       msfm_huber(P.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
       cost = 0.5 * rho0;
@@ -158,6 +165,12 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __r
   }
   const double t = block_sum256(cost, sh);
   if (threadIdx.x == 0) cost_partial[blockIdx.x] = t;
+}
+
+// rot[c] = msfm_rot_prepare(cam[c]) for all cameras (run start; the candidates' are formed inside k_backsub)
+__global__ __launch_bounds__(256) void k_rot_cache(int Nc, const double* __restrict__ cam, double* __restrict__ rot) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < Nc) msfm_rot_prepare(cam + 6 * (size_t)c, rot + 4 * (size_t)c);
 }
 
 // GPS residual per camera block (gps_error_pose_absolute.h:31-44; d|x|/dx = x<0 ? -1 : 1).
@@ -255,8 +268,7 @@ struct PointPtrs {
 // (obs_linearize: the row data is read coalesced, the parameters come from cache), the per-point sums are 3-step
 // reductions inside the 8-lane group, and every lane then finishes its own observation's T = (Jc^T Jp) L^-T.
 // 256 threads = 32 points.  Tracks of up to 8 views keep their rows in registers; longer ones linearise them again.
-__global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__ gmax_partial) {
-  __shared__ double sh[4];
+__device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restrict__ gmax_partial, double* sh, double* park) {
   const int tid = threadIdx.x, sub = tid & 7;
   const int pb = blockIdx.x * 32 + (tid >> 3);
   const bool act = pb < P.npb;
@@ -264,17 +276,18 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
   if (act) { f = P.pt_first[pb]; l = P.pt_first[pb + 1]; }
   const bool single = (l - f) <= 8;
   double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0;
-  double jcs[12], jms[6], jps[6];   // this lane's row of the (only) round
-#pragma unroll
-  for (int k = 0; k < 12; k++) jcs[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; k++) { jms[k] = 0.0; jps[k] = 0.0; }
+  // The lane's row of the (only) round waits in LDS (component-major, one column per thread: no bank conflicts) while
+  // the point's 3x3 system is reduced and factored - 48 registers less across that phase.
   double cost = 0.0;
   for (int base = f; base < l; base += 8) {
     const int i = base + sub;
     if (i < l) {
-      double r0, r1;
+      double r0, r1, jcs[12], jms[6], jps[6];
       const double ci = obs_linearize(P.B, i, r0, r1, jcs, jms, jps);
+#pragma unroll
+      for (int k = 0; k < 12; k++) park[k * 256 + tid] = jcs[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { park[(12 + k) * 256 + tid] = jms[k]; park[(18 + k) * 256 + tid] = jps[k]; }
       if (P.store_rows) {
         cost += ci;
         const int cp = P.B.o_cpos[i];
@@ -350,7 +363,14 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
 #pragma unroll
       for (int k = 0; k < 6; k++) tu[k] = 0.0;
       if (cp >= 0) {
+        double jcs[12], jms[6], jps[6];
         if (!single) { double r0, r1; obs_linearize(P.B, i, r0, r1, jcs, jms, jps); }
+        else {
+#pragma unroll
+          for (int k = 0; k < 12; k++) jcs[k] = park[k * 256 + tid];
+#pragma unroll
+          for (int k = 0; k < 6; k++) jps[k] = park[(18 + k) * 256 + tid];
+        }
         const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
 #pragma unroll
         for (int a = 0; a < 6; a++) {
@@ -389,7 +409,12 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
       for (int base = f; base < l; base += 8) {
         const int i = base + sub;
         if (i < l && P.B.o_mb[i] == mb) {
+          double jcs[12], jms[6], jps[6];
           if (!single) { double r0, r1; obs_linearize(P.B, i, r0, r1, jcs, jms, jps); }
+          else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) { jms[k] = park[(12 + k) * 256 + tid]; jps[k] = park[(18 + k) * 256 + tid]; }
+          }
           const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
 #pragma unroll
           for (int a = 0; a < 3; a++) {
@@ -422,6 +447,13 @@ __global__ __launch_bounds__(256) void k_point(PointPtrs P, double* __restrict__
   }
   const double t = block_max256(gmax, sh);
   if (threadIdx.x == 0) gmax_partial[blockIdx.x] = t;
+}
+// (three waves per SIMD: 168 registers with three dwords of scratch, against 175 and two waves: 0.337 -> 0.309 ms at C3;
+// the 48 KB of parked rows allow exactly three workgroups per CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_point(PointPtrs P, double* __restrict__ gmax_partial) {
+  __shared__ double sh[4];
+  __shared__ double park[24 * 256];
+  k_point_body(P, gmax_partial, sh, park);
 }
 
 // --------------------------------------------------------------------------------------
@@ -791,18 +823,22 @@ struct BackPtrs {
   const int *pt_first, *pb_pt;
   const double *ptL, *z;
   double* pt_c;
+  int Nc;                  // the first Nc threads of the launch also prepare the candidate cameras' rotations
+  const double* cam_c;     // (final before this launch: k_copy3 + k_update_blocks)
+  double* rot_c;
 };
 
 // 8 lanes per point, lane = observation, single pass: besides y = sum Jp^T (r + q) with
 // q = -(Jc z_c + Jm z_m), the group accumulates the moments that give this point's model cost change
 //   -(J s)^T (r + J s / 2) = -[ sp.g + sum q.r + 1/2 sp^T V sp + sp.(sum Jp^T q) + 1/2 sum q.q ]
 // so the step sp (known only after the group reduction) never needs a second sweep.
-__global__ __launch_bounds__(256) void k_backsub(BackPtrs P, double* __restrict__ mcc_partial, double* __restrict__ dx2_partial,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_backsub(BackPtrs P, double* __restrict__ mcc_partial, double* __restrict__ dx2_partial,
                                                   double* __restrict__ x2_partial) {
   __shared__ double sh[4];
   const int tid = threadIdx.x, sub = tid & 7;
   const int pb = blockIdx.x * 32 + (tid >> 3);
   const bool act = pb < P.npb;
+  for (int c = blockIdx.x * 256 + tid; c < P.Nc; c += gridDim.x * 256) msfm_rot_prepare(P.cam_c + 6 * (size_t)c, P.rot_c + 4 * (size_t)c);
   int f = 0, l = 0;
   if (act) { f = P.pt_first[pb]; l = P.pt_first[pb + 1]; }
   double V00 = 0, V10 = 0, V11 = 0, V20 = 0, V21 = 0, V22 = 0, g0 = 0, g1 = 0, g2 = 0, h0 = 0, h1 = 0, h2 = 0, qr = 0, qq = 0;
@@ -813,6 +849,7 @@ __global__ __launch_bounds__(256) void k_backsub(BackPtrs P, double* __restrict_
       const int cb = P.B.o_cb[i], mb = P.B.o_mb[i];
       double jc[12], jm[6], jp[6], zc[6], zm[3], r0, r1;
       obs_linearize(P.B, i, r0, r1, jc, jm, jp);
+      __builtin_amdgcn_sched_barrier(0);   // the step is fetched after the row is formed: nine registers less before
       const double* zcp = P.z + 6 * (cb >= 0 ? cb : 0);
       const double* zmp = P.z + 6 * P.ncb + 3 * (mb >= 0 ? mb : 0);
 #pragma unroll
@@ -942,7 +979,7 @@ struct msfm_ba {
   DevBuf<int> cb_cam, mb_model, pb_pt, cb_mb;
   DevBuf<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
   DevBuf<double> o_x, o_y, o_w;
-  DevBuf<double> lin_r, lin_Jc, lin_Jm, camrow, T, Tu, Tm, Tmu;
+  DevBuf<double> lin_r, lin_Jc, lin_Jm, camrow, T, Tu, Tm, Tmu, rot, rot_c;
   DevBuf<int> cpos_pb;
   DevBuf<double> scale_c, scale_m, scale_p, diag_c, diag_m, diag_p;
   DevBuf<int> pt_first, pm_first, pm_mb;
@@ -2341,6 +2378,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
 #define AL(buf, n) HIP_TRY(ctx, ba->buf.alloc((size_t)std::max<size_t>(1, (n))))
   AL(cam, 6 * (size_t)Nc); AL(model, 3 * (size_t)Nm); AL(pt, 3 * (size_t)std::max(1, Np));
   AL(cam_c, 6 * (size_t)Nc); AL(model_c, 3 * (size_t)Nm); AL(pt_c, 3 * (size_t)std::max(1, Np));
+  AL(rot, 4 * (size_t)Nc); AL(rot_c, 4 * (size_t)Nc);
   const size_t Atail = (size_t)std::max(1, A - ba->AE);   // rows of frozen points: the only ones whose linearisation is stored
   AL(lin_r, 2 * Atail); AL(lin_Jc, 12 * Atail); AL(lin_Jm, 6 * Atail);
   AL(camrow, 20 * (size_t)NCR); AL(T, 18 * (size_t)NCR); AL(Tu, 6 * (size_t)NCR);
@@ -2444,6 +2482,7 @@ static BaPtrs make_ptrs(msfm_ba* ba, bool candidate, double huber) {
   BaPtrs P;
   P.A = ba->A; P.AE = ba->AE; P.ncb = ba->ncb; P.nmb = ba->nmb; P.npb = ba->npb; P.NCR = ba->NCR;
   P.cam = candidate ? ba->cam_c.p : ba->cam.p;
+  P.rot = candidate ? ba->rot_c.p : ba->rot.p;
   P.model = candidate ? ba->model_c.p : ba->model.p;
   P.pt = candidate ? ba->pt_c.p : ba->pt.p;
   P.o_cam = ba->o_cam.p; P.o_model = ba->o_model.p; P.o_pt = ba->o_pt.p; P.o_cb = ba->o_cb.p; P.o_mb = ba->o_mb.p;
@@ -2707,8 +2746,11 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
       Q.B = make_ptrs(ba, false, ba->lin_huber);
       Q.npb = npb; Q.ncb = ncb; Q.pt_first = ba->pt_first.p; Q.pb_pt = ba->pb_pt.p;
       Q.ptL = ba->ptL.p; Q.z = ba->z.p; Q.pt_c = ba->pt_c.p;
+      Q.Nc = ba->Nc; Q.cam_c = ba->cam_c.p; Q.rot_c = ba->rot_c.p;
       hipLaunchKernelGGL(k_backsub, dim3(nbp), dim3(256), 0, s, Q, ba->partial.p, ba->partial2.p + off, ba->partial3.p + off);
       off += nbp; moff += nbp;
+    } else {
+      hipLaunchKernelGGL(k_rot_cache, dim3(cdiv(std::max(1, ba->Nc), 256)), dim3(256), 0, s, ba->Nc, ba->cam_c.p, ba->rot_c.p);
     }
     const int ngps = (ba->has_gps && lead) ? ncb : 0;
     const int nrest = (ba->A - ba->AE) + ngps;
@@ -2766,6 +2808,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   if (ncb) hipLaunchKernelGGL(k_fill, dim3(cdiv(6 * ncb, 256)), dim3(256), 0, s, 6 * ncb, 1.0, ba->scale_c.p);
   if (nmb) hipLaunchKernelGGL(k_fill, dim3(cdiv(3 * nmb, 256)), dim3(256), 0, s, 3 * nmb, 1.0, ba->scale_m.p);
   if (npb) hipLaunchKernelGGL(k_fill, dim3(cdiv(3 * npb, 256)), dim3(256), 0, s, 3 * npb, 1.0, ba->scale_p.p);
+  hipLaunchKernelGGL(k_rot_cache, dim3(cdiv(std::max(1, ba->Nc), 256)), dim3(256), 0, s, ba->Nc, ba->cam.p, ba->rot.p);
   lap("scales reset");
   hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
@@ -2835,7 +2878,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
       if (std::fabs(it.cost_change) <= opt->function_tolerance * x_cost) { termination = MSFM_BA_CONVERGENCE_FUNCTION; break; }
       it.relative_decrease = (x_cost - cand_cost) / mcc;
       if (it.relative_decrease > opt->min_relative_decrease) {
-        ba->cam.swap(ba->cam_c); ba->model.swap(ba->model_c); ba->pt.swap(ba->pt_c);
+        ba->cam.swap(ba->cam_c); ba->model.swap(ba->model_c); ba->pt.swap(ba->pt_c); ba->rot.swap(ba->rot_c);
         relinearise = true;
         it.step_is_successful = 1;
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));

@@ -9,7 +9,23 @@
 // J (if non-null) is 2x12 row-major: [d pose(6) | d cam(3) | d xyz(3)], already times weight.
 // The rotation derivative is the exact derivative of the evaluated formula (including the
 // first-order branch at theta^2 <= DBL_EPSILON), i.e. what Ceres' Jets propagate.
-__device__ __forceinline__ void msfm_reproj(const double* __restrict__ pose, const double* __restrict__ cam,
+// What depends on the camera's angle-axis vector alone: which branch of the rotation formula applies, and sin, cos and
+// 1 / |a|.  A camera is seen by thousands of observations per evaluation; msfm_rot_prepare computes these four numbers
+// once per camera and parameter set (rot[4 c ..]: flag, sin, cos, 1/theta) with the operations msfm_reproj would use.
+__device__ __forceinline__ void msfm_rot_prepare(const double* __restrict__ pose, double* __restrict__ rc) {
+  const double a0 = pose[0], a1 = pose[1], a2 = pose[2];
+  const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
+  double s = 0.0, c = 1.0, ti = 0.0, flag = 0.0;
+  if (theta2 > 2.220446049250313e-16) {
+    const double theta = sqrt(theta2);
+    sincos(theta, &s, &c);
+    ti = 1.0 / theta;
+    flag = 1.0;
+  }
+  rc[0] = flag; rc[1] = s; rc[2] = c; rc[3] = ti;
+}
+
+__device__ __forceinline__ void msfm_reproj(const double* __restrict__ pose, const double* __restrict__ rc, const double* __restrict__ cam,
                                             const double* __restrict__ xyz, double ox, double oy, double weight,
                                             double* r, double* J) {
   const double a0 = pose[0], a1 = pose[1], a2 = pose[2];
@@ -17,12 +33,8 @@ __device__ __forceinline__ void msfm_reproj(const double* __restrict__ pose, con
   double p0, p1, p2;
   double dpdw[9];
   double R[9];
-  const double theta2 = a0 * a0 + a1 * a1 + a2 * a2;
-  if (theta2 > 2.220446049250313e-16) {
-    const double theta = sqrt(theta2);
-    double s, c;
-    sincos(theta, &s, &c);
-    const double ti = 1.0 / theta;
+  if (rc[0] != 0.0) {
+    const double s = rc[1], c = rc[2], ti = rc[3];
     const double w0 = a0 * ti, w1 = a1 * ti, w2 = a2 * ti;
     const double wx0 = w1 * X2 - w2 * X1, wx1 = w2 * X0 - w0 * X2, wx2 = w0 * X1 - w1 * X0;
     const double wdx = w0 * X0 + w1 * X1 + w2 * X2;
