@@ -31,9 +31,10 @@
 
 #define PSTRIDE 80   // doubles per FTF partial
 #define CHUNK 1024   // entries per reduction chunk (16 per lane)
-// k_ftf's chunks are shorter: a camera has a few thousand rows, and one wave per 1024 of them leaves most of the chip without
-// a wave (C3: 1500 waves for 1024 SIMDs x 2); 256 rows per wave = 4 passes of 64 lanes
-#define FTF_CHUNK 256
+// k_ftf's chunks are shorter: a camera has a few thousand rows, and one wave per 1024 of them leaves part of the chip without
+// a wave (C3: 1500 waves for 1024 SIMDs x 2); 512 rows per wave = 8 passes of 64 lanes (measured 128 .. 1024: 0.117, 0.107,
+// 0.102, 0.100 ms for the three per-camera kernels together - flat from 512 on)
+#define FTF_CHUNK 512
 static int ftf_chunk() {
   const char* e = getenv("MSFM_FTF_CHUNK");   // (experiments)
   const int v = e ? atoi(e) : 0;
@@ -474,42 +475,92 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
                                               const int* __restrict__ cpos_pb, double* __restrict__ partial) {
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (chunk >= nchunk) return;
-  double acc[78];
+  // Jc^T Jc and Jm^T Jm are symmetric: 21 + 6 of their 36 + 9 entries are accumulated (the mirrored ones are the same
+  // products in the other order, so the stored 78 values are what the full loops gave) - 60 accumulators leave room for
+  // the NEXT row's ten 16-byte loads to be in flight while this row is added.
+  double sjc[21], sjmc[18], sjm[6], scr[6], smr[3], stu[6];
 #pragma unroll
-  for (int k = 0; k < 78; k++) acc[k] = 0.0;
-  for (int e = ch_start[chunk] + lane; e < ch_end[chunk]; e += 64) {
+  for (int k = 0; k < 21; k++) sjc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 18; k++) sjmc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { sjm[k] = 0.0; scr[k] = 0.0; stu[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) smr[k] = 0.0;
+  const int e1 = ch_end[chunk];
+  int e = ch_start[chunk] + lane;
+  double2 nx[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) nx[k] = make_double2(0.0, 0.0);
+  if (e < e1) {
     // rows are 160 bytes and 16-byte aligned: ten 16-byte loads instead of twenty 8-byte ones
     const double2* row2 = reinterpret_cast<const double2*>(camrow + 20 * (size_t)e);
+#pragma unroll
+    for (int k = 0; k < 10; k++) nx[k] = row2[k];
+  }
+  for (; e < e1; e += 64) {
     double rw[20];
 #pragma unroll
-    for (int k = 0; k < 10; k++) { const double2 t = row2[k]; rw[2 * k] = t.x; rw[2 * k + 1] = t.y; }
-    double jc[12], jm[6];
+    for (int k = 0; k < 10; k++) { rw[2 * k] = nx[k].x; rw[2 * k + 1] = nx[k].y; }
+    const bool has_tu = cpos_pb[e] >= 0;
+    double2 tu2[3];
+    if (has_tu) {
+      const double2* tp = reinterpret_cast<const double2*>(Tu + 6 * (size_t)e);
 #pragma unroll
-    for (int k = 0; k < 12; k++) jc[k] = rw[k];
+      for (int a = 0; a < 3; a++) tu2[a] = tp[a];
+    }
+    if (e + 64 < e1) {
+      const double2* row2 = reinterpret_cast<const double2*>(camrow + 20 * (size_t)(e + 64));
 #pragma unroll
-    for (int k = 0; k < 6; k++) jm[k] = rw[12 + k];
+      for (int k = 0; k < 10; k++) nx[k] = row2[k];
+    }
+    const double* jc = rw;
+    const double* jm = rw + 12;
     const double r0 = rw[18], r1 = rw[19];
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
-      for (int b = 0; b < 6; b++) acc[F_JCJC + a * 6 + b] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b];
-      acc[F_JCR + a] += jc[a] * r0 + jc[6 + a] * r1;
+      for (int b = 0; b <= a; b++) sjc[a * (a + 1) / 2 + b] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b];
+      scr[a] += jc[a] * r0 + jc[6 + a] * r1;
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
 #pragma unroll
-      for (int b = 0; b < 6; b++) acc[F_JMJC + a * 6 + b] += jm[a] * jc[b] + jm[3 + a] * jc[6 + b];
+      for (int b = 0; b < 6; b++) sjmc[a * 6 + b] += jm[a] * jc[b] + jm[3 + a] * jc[6 + b];
 #pragma unroll
-      for (int b = 0; b < 3; b++) acc[F_JMJM + a * 3 + b] += jm[a] * jm[b] + jm[3 + a] * jm[3 + b];
-      acc[F_JMR + a] += jm[a] * r0 + jm[3 + a] * r1;
+      for (int b = 0; b <= a; b++) sjm[a * (a + 1) / 2 + b] += jm[a] * jm[b] + jm[3 + a] * jm[3 + b];
+      smr[a] += jm[a] * r0 + jm[3 + a] * r1;
     }
-    if (cpos_pb[e] >= 0) {
-      const double2* tu2 = reinterpret_cast<const double2*>(Tu + 6 * (size_t)e);
+    if (has_tu) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) { const double2 t = tu2[a]; acc[F_TU + 2 * a] += t.x; acc[F_TU + 2 * a + 1] += t.y; }
+      for (int a = 0; a < 3; a++) { stu[2 * a] += tu2[a].x; stu[2 * a + 1] += tu2[a].y; }
     }
   }
-  wave_reduce_store<78>(acc, partial + (size_t)chunk * PSTRIDE, lane);
+  double* out = partial + (size_t)chunk * PSTRIDE;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      const double v = wave_sum(sjc[a * (a + 1) / 2 + b]);
+      if (lane == 0) { out[F_JCJC + a * 6 + b] = v; out[F_JCJC + b * 6 + a] = v; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 18; k++) { const double v = wave_sum(sjmc[k]); if (lane == 0) out[F_JMJC + k] = v; }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int b = 0; b <= a; b++) {
+      const double v = wave_sum(sjm[a * (a + 1) / 2 + b]);
+      if (lane == 0) { out[F_JMJM + a * 3 + b] = v; out[F_JMJM + b * 3 + a] = v; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) { const double v = wave_sum(scr[k]); if (lane == 0) out[F_JCR + k] = v; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const double v = wave_sum(smr[k]); if (lane == 0) out[F_JMR + k] = v; }
+#pragma unroll
+  for (int k = 0; k < 6; k++) { const double v = wave_sum(stu[k]); if (lane == 0) out[F_TU + k] = v; }
 }
 
 // Sum the FTF partials of each camera block (fixed order) -> camftf[cb][PSTRIDE]; the GPS rows
@@ -523,7 +574,14 @@ __global__ __launch_bounds__(128) void k_camftf(int ncb, const int* __restrict__
   const int cb = blockIdx.x, t = threadIdx.x;
   if (t < PSTRIDE) {
     double s = 0.0;
-    for (int ch = cam_chunk_first[cb]; ch < cam_chunk_first[cb + 1]; ch++) s += partial[(size_t)ch * PSTRIDE + t];
+    int ch = cam_chunk_first[cb];
+    const int ch1 = cam_chunk_first[cb + 1];
+    for (; ch + 4 <= ch1; ch += 4) {   // four loads in flight, summed in chunk order as the single loop would
+      const double* q = partial + (size_t)ch * PSTRIDE + t;
+      const double p0 = q[0], p1 = q[PSTRIDE], p2 = q[2 * PSTRIDE], p3 = q[3 * PSTRIDE];
+      s += p0; s += p1; s += p2; s += p3;
+    }
+    for (; ch < ch1; ch++) s += partial[(size_t)ch * PSTRIDE + t];
     if (add_gps) {
       if (t >= F_JCJC && t < F_JCJC + 36) {
         const int a = (t - F_JCJC) / 6, b = (t - F_JCJC) % 6;
