@@ -463,11 +463,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // --------------------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void wave_reduce_store(double (&acc)[N], double* out, int lane) {
-#pragma unroll
-  for (int k = 0; k < N; k++) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) out[k] = v;
-  }
+  double v;
+  int k;
+  wave_reduce_scatter<N>(acc, lane, v, k);
+  if (k >= 0) out[k] = v;   // one store instruction: every value ends in its own lane
 }
 
 __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
@@ -478,15 +477,11 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
   // Jc^T Jc and Jm^T Jm are symmetric: 21 + 6 of their 36 + 9 entries are accumulated (the mirrored ones are the same
   // products in the other order, so the stored 78 values are what the full loops gave) - 60 accumulators leave room for
   // the NEXT row's ten 16-byte loads to be in flight while this row is added.
-  double sjc[21], sjmc[18], sjm[6], scr[6], smr[3], stu[6];
+  // acc: Jc^T Jc lower triangle (21, row-wise) | Jm^T Jc (18) | Jm^T Jm lower (6) | Jc^T r (6) | Jm^T r (3) | sum T.u (6)
+  constexpr int O_JC = 0, O_JMC = 21, O_JM = 39, O_CR = 45, O_MR = 51, O_TU = 54;
+  double acc[60];
 #pragma unroll
-  for (int k = 0; k < 21; k++) sjc[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 18; k++) sjmc[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 6; k++) { sjm[k] = 0.0; scr[k] = 0.0; stu[k] = 0.0; }
-#pragma unroll
-  for (int k = 0; k < 3; k++) smr[k] = 0.0;
+  for (int k = 0; k < 60; k++) acc[k] = 0.0;
   const int e1 = ch_end[chunk];
   int e = ch_start[chunk] + lane;
   double2 nx[10];
@@ -520,47 +515,52 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
-      for (int b = 0; b <= a; b++) sjc[a * (a + 1) / 2 + b] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b];
-      scr[a] += jc[a] * r0 + jc[6 + a] * r1;
+      for (int b = 0; b <= a; b++) acc[O_JC + a * (a + 1) / 2 + b] += jc[a] * jc[b] + jc[6 + a] * jc[6 + b];
+      acc[O_CR + a] += jc[a] * r0 + jc[6 + a] * r1;
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
 #pragma unroll
-      for (int b = 0; b < 6; b++) sjmc[a * 6 + b] += jm[a] * jc[b] + jm[3 + a] * jc[6 + b];
+      for (int b = 0; b < 6; b++) acc[O_JMC + a * 6 + b] += jm[a] * jc[b] + jm[3 + a] * jc[6 + b];
 #pragma unroll
-      for (int b = 0; b <= a; b++) sjm[a * (a + 1) / 2 + b] += jm[a] * jm[b] + jm[3 + a] * jm[3 + b];
-      smr[a] += jm[a] * r0 + jm[3 + a] * r1;
+      for (int b = 0; b <= a; b++) acc[O_JM + a * (a + 1) / 2 + b] += jm[a] * jm[b] + jm[3 + a] * jm[3 + b];
+      acc[O_MR + a] += jm[a] * r0 + jm[3 + a] * r1;
     }
     if (has_tu) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) { stu[2 * a] += tu2[a].x; stu[2 * a + 1] += tu2[a].y; }
+      for (int a = 0; a < 3; a++) { acc[O_TU + 2 * a] += tu2[a].x; acc[O_TU + 2 * a + 1] += tu2[a].y; }
     }
   }
+  // every sum ends in one lane (wave_reduce_scatter); that lane stores it, and its mirror image for the two symmetric blocks
   double* out = partial + (size_t)chunk * PSTRIDE;
-#pragma unroll
-  for (int a = 0; a < 6; a++) {
-#pragma unroll
-    for (int b = 0; b <= a; b++) {
-      const double v = wave_sum(sjc[a * (a + 1) / 2 + b]);
-      if (lane == 0) { out[F_JCJC + a * 6 + b] = v; out[F_JCJC + b * 6 + a] = v; }
+  double v;
+  int k;
+  wave_reduce_scatter<60>(acc, lane, v, k);
+  if (k >= 0) {
+    int o1, o2;
+    if (k < O_JMC) {
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= k) a++;
+      const int b_ = k - a * (a + 1) / 2;
+      o1 = F_JCJC + a * 6 + b_; o2 = F_JCJC + b_ * 6 + a;
+    } else if (k < O_JM) {
+      o1 = o2 = F_JMJC + (k - O_JMC);
+    } else if (k < O_CR) {
+      const int t = k - O_JM;
+      int a = 0;
+      while ((a + 1) * (a + 2) / 2 <= t) a++;
+      const int b_ = t - a * (a + 1) / 2;
+      o1 = F_JMJM + a * 3 + b_; o2 = F_JMJM + b_ * 3 + a;
+    } else if (k < O_MR) {
+      o1 = o2 = F_JCR + (k - O_CR);
+    } else if (k < O_TU) {
+      o1 = o2 = F_JMR + (k - O_MR);
+    } else {
+      o1 = o2 = F_TU + (k - O_TU);
     }
+    out[o1] = v;
+    if (o2 != o1) out[o2] = v;
   }
-#pragma unroll
-  for (int k = 0; k < 18; k++) { const double v = wave_sum(sjmc[k]); if (lane == 0) out[F_JMJC + k] = v; }
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int b = 0; b <= a; b++) {
-      const double v = wave_sum(sjm[a * (a + 1) / 2 + b]);
-      if (lane == 0) { out[F_JMJM + a * 3 + b] = v; out[F_JMJM + b * 3 + a] = v; }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) { const double v = wave_sum(scr[k]); if (lane == 0) out[F_JCR + k] = v; }
-#pragma unroll
-  for (int k = 0; k < 3; k++) { const double v = wave_sum(smr[k]); if (lane == 0) out[F_JMR + k] = v; }
-#pragma unroll
-  for (int k = 0; k < 6; k++) { const double v = wave_sum(stu[k]); if (lane == 0) out[F_TU + k] = v; }
 }
 
 // Sum the FTF partials of each camera block (fixed order) -> camftf[cb][PSTRIDE]; the GPS rows

@@ -175,6 +175,62 @@ __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_f64<MSFM_DPP_XOR1>(v));
   return v;
 }
+// Sums of N per-lane values over the wave, every sum with the pairing tree of wave_sum (xor 32, 16, 8, 4, 2, 1), but as a
+// reduce-scatter: at every step a lane keeps only half of its values (the lower half of the index range if its bit of the
+// step is clear, the upper half otherwise) and adds its partner's copies of those - N + N/2 + N/4 + ... additions instead
+// of 6 N, and after the last step every value sits in exactly one lane.  The two widest steps are one
+// v_permlane{32,16}_swap per dword and pair of values.  Returns this lane's value and its index (-1: none).
+// Bit-identical to wave_sum of each value (missing partners of an odd count are +0.0).
+template <int D>
+__device__ __forceinline__ double partner_f64(double t) {
+  if constexpr (D == 8) return dpp_f64<MSFM_DPP_ROR8>(t);
+  else if constexpr (D == 4) return dpp_xor4_f64(t);
+  else if constexpr (D == 2) return dpp_f64<MSFM_DPP_XOR2>(t);
+  else return dpp_f64<MSFM_DPP_XOR1>(t);
+}
+template <int D, int n, int N>
+__device__ __forceinline__ void reduce_scatter_step(double (&v)[N], int lane) {
+  constexpr int h = (n + 1) / 2;
+  const bool low = (lane & D) == 0;
+#pragma unroll
+  for (int j = 0; j < h; j++) {
+    const double a = v[j], b = (h + j < n) ? v[h + j] : 0.0;
+    if constexpr (D == 32) { double x, y; const unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+      const auto l = __builtin_amdgcn_permlane32_swap(al, bl, false, false); const auto hh = __builtin_amdgcn_permlane32_swap(ah, bh, false, false);
+      x = __hiloint2double(hh[0], l[0]); y = __hiloint2double(hh[1], l[1]); v[j] = x + y;
+    } else if constexpr (D == 16) { double x, y; const unsigned al = __double2loint(a), ah = __double2hiint(a), bl = __double2loint(b), bh = __double2hiint(b);
+      const auto l = __builtin_amdgcn_permlane16_swap(al, bl, false, false); const auto hh = __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+      x = __hiloint2double(hh[0], l[0]); y = __hiloint2double(hh[1], l[1]); v[j] = x + y;
+    } else {
+      const double t = low ? b : a;            // what the partner keeps
+      const double mine = low ? a : b;
+      v[j] = mine + partner_f64<D>(t);
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void wave_reduce_scatter(double (&v)[N], int lane, double& val, int& idx) {
+  constexpr int n1 = (N + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2, n4 = (n3 + 1) / 2, n5 = (n4 + 1) / 2;
+  static_assert(N <= 64 && (n5 + 1) / 2 == 1, "at most 64 values");
+  reduce_scatter_step<32, N>(v, lane);
+  reduce_scatter_step<16, n1>(v, lane);
+  reduce_scatter_step<8, n2>(v, lane);
+  reduce_scatter_step<4, n3>(v, lane);
+  reduce_scatter_step<2, n4>(v, lane);
+  reduce_scatter_step<1, n5>(v, lane);
+  val = v[0];
+  // which value that is: every lane has the same number of slots n (the upper half of an odd count is padded with one
+  // empty slot), of which the first nv hold values lo, lo + 1, ...
+  int lo = 0, nv = N, n = N;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int h = (n + 1) / 2;
+    if (lane & d) { lo += h; nv = max(0, nv - h); } else nv = min(nv, h);
+    n = h;
+  }
+  idx = nv > 0 ? lo : -1;
+}
+
 // blockDim.x must be 256.  Result valid in thread 0.
 __device__ __forceinline__ double block_sum256(double v, double* sh /*[4]*/) {
   v = wave_sum(v);
