@@ -245,7 +245,16 @@ def main():
             note += ("; %d camera domains of %s columns are factored side by side, then the %d-column separator: %.2f GFLOP actually executed"
                      % (lay["n_domains"], lay["domain_cols"], lay["separator_cols"], exe_flops / 1e9))
         add("chol_panel_mfma", "mfma", dense_flops * n_solves / max(1, st["launches"]), note)
-        rooflines["chol_panel_mfma"]["executed_tflops"] = exe_flops * n_solves / (st["total_ms"] * 1e-3) / 1e12
+        # the deferred corner updates of the elimination levels (k_corner_syrk + k_merge_corners, their own timing class) are part
+        # of the same factorisation: `achieved` charges their time to it; avg_launch_us stays the panel kernel's own (the figure
+        # the rocprofv3 kernel trace reports for k_panel_v2)
+        syrk = ba_stats.get("chol_corner_syrk")
+        fac_s = (st["total_ms"] + (syrk["total_ms"] if syrk else 0.0)) * 1e-3
+        rl = rooflines["chol_panel_mfma"]
+        rl["achieved"] = dense_flops * n_solves / fac_s / 1e12
+        rl["frac"] = rl["achieved"] / rl["peak"]
+        rl["factorisation_ms"] = 1e3 * fac_s / max(1, n_solves)
+        rl["executed_tflops"] = exe_flops * n_solves / fac_s / 1e12
         rooflines["chol_panel_mfma"]["layout"] = lay
     if not win:
         k = np.bincount(sc.obs_pt, minlength=sc.n_points).astype(np.int64)

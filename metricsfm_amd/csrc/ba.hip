@@ -2623,16 +2623,19 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   // (k_ftf ... k_modelsum, with the multi-rank exchange of camftf) read T.u and the camera rows.  Outside profiling runs
   // the pair products therefore go to a second stream beside them and the two meet again at the assembly (with the
   // per-class timers on, everything stays on the main stream so that the timings remain per kernel).
+  // (order: the two small lists first - they share the chip with k_ftf, which needs the bandwidth as much as the
+  // camera x camera list does, so those two would only slow each other down - and the large list last, beside the
+  // latency-bound k_camftf / k_modelsum / k_reduce tail of the main stream)
   auto launch_pairs = [&](hipStream_t sp) {
-    if (ba->cc.n_chunks)
-      hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, sp, ba->cc.n_chunks, ba->cc.ch_start.p,
-                         ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
     if (ba->mc.n_chunks)
       hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->mc.n_chunks, 4)), dim3(256), 0, sp, ba->mc.n_chunks, ba->mc.ch_start.p,
                          ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->mc.partial.p);
     if (ba->mm.n_chunks)
       hipLaunchKernelGGL((k_pairs<3, 3, true>), dim3(cdiv(ba->mm.n_chunks, 4)), dim3(256), 0, sp, ba->mm.n_chunks, ba->mm.ch_start.p,
                          ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, (size_t)0, ba->mm.partial.p);
+    if (ba->cc.n_chunks)
+      hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, sp, ba->cc.n_chunks, ba->cc.ch_start.p,
+                         ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
   };
   static const bool no_overlap = getenv("MSFM_NO_OVERLAP") != nullptr;
   const bool forked = mode == 0 && !ctx->profile && !no_overlap;

@@ -944,6 +944,8 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
       };
       int maxp = 0;
       for (int k = 0; k < K; k++) maxp = std::max(maxp, (L.node[k].end - L.node[k].begin) / NB);
+      KTimer chain_timer(ctx, "chol_panel_mfma");   // the level's chain of panel launches as a whole
+      chain_timer.count = 0;
       for (int l = 0; l < maxp; l++) {
         PanelJobs jobs;
         jobs.count = 0;
@@ -968,11 +970,13 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
           jobs.job[jobs.count++] = jb;
         }
         if (!jobs.count) break;
-        KTimer t(ctx, "chol_panel_mfma");
         hipLaunchKernelGGL(k_panel_v2<true>, dim3(wg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
+        chain_timer.count++;
       }
+      chain_timer.stop();
       if (maxp > 0) {
-        KTimer t(ctx, "chol_panel_mfma");
+        KTimer t(ctx, "chol_corner_syrk");
+        t.count = 2;
         const int nB64 = cdiv(nrows - sb, 64), ntile = nB64 * (nB64 + 1) / 2;
         if (nB64 > 128) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: separator part too large for the corner update (%d blocks)", nB64);
         // per 64-row block of the square: the panels of this level under the block's tree node (the root: all of them)
@@ -997,6 +1001,8 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
       t_first = sb;
     }
   }
+  KTimer root_timer(ctx, "chol_panel_mfma");
+  root_timer.count = 0;
   for (int t0 = t_first; t0 < n; t0 += NB) {
     // the separator (or the whole matrix): one job per launch, its first block has nothing left to apply
     const int j0 = t0 > t_first ? t0 - NB : -1;
@@ -1006,10 +1012,12 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     jobs.job[0].nrt = cdiv(nrows - t0, 16);  // 16-row tiles from t0 down that carry data
     jobs.job[0].ncw = std::max(1, cdiv(jobs.job[0].nrt - 4, 3));
     jobs.job[0].nwg = jobs.job[0].ncw + bulk_workgroups(jobs.job[0].ntile);
-    KTimer t(ctx, "chol_panel_mfma");  // trailing update with panel j0 + potrf / trsm of the panel at t0
+    // trailing update with panel j0 + potrf / trsm of the panel at t0
     if (n - t0 >= NB) hipLaunchKernelGGL(k_panel_v2<true>, dim3(jobs.job[0].nwg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
     else hipLaunchKernelGGL(k_panel_v2<false>, dim3(jobs.job[0].nwg), dim3(256), 0, s, M, npad, n, Dinv, Ldiag, fail, jobs);
+    root_timer.count++;
   }
+  root_timer.stop();
   {
     KTimer t(ctx, "chol_backsolve");
     hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB) + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, cdiv(n, NB), M, npad, w, npad);

@@ -74,8 +74,11 @@ int msfm_set_error(msfm_ctx* ctx, int code, const char* fmt, ...);
 struct KTimer {
   msfm_ctx* ctx;
   int idx = -1;
+  int count = 1;   // kernel launches between the two events (a chain of dependent launches is timed as a whole: an event
+                   // pair around every single launch would put its own few microseconds into each of them)
   hipEvent_t a = nullptr, b = nullptr;
   KTimer(msfm_ctx* c, const char* name);
+  void stop();   // records the closing event now (the destructor then does nothing)
   ~KTimer();
 };
 

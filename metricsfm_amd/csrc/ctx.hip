@@ -305,12 +305,15 @@ KTimer::KTimer(msfm_ctx* c, const char* name) : ctx(c) {
   (void)hipEventRecord(a, ctx->stream);
 }
 
-KTimer::~KTimer() {
+void KTimer::stop() {
   if (idx < 0) return;
   (void)hipEventRecord(b, ctx->stream);
-  ctx->stats[idx].launches++;
+  ctx->stats[idx].launches += count;
   ctx->pending.push_back({idx, a, b});
+  idx = -1;
 }
+
+KTimer::~KTimer() { stop(); }
 
 static void resolve_pending(msfm_ctx* ctx) {
   if (ctx->pending.empty()) return;
