@@ -145,7 +145,8 @@ def main():
         # the model is in its adjusted state, the newest camera comes straight from localisation (tests/test_gpu_ba.py)
         sc = scene.config_scene(5, n_models=2000, rot_sigma=2e-4, trans_sigma=0.01, point_sigma=0.02)
         scene.perturb_camera(sc, sc.n_cams - 1)
-        full, win = window.partial_bundle_adjustment_problem(sc, sc.n_cams - 1, gps=True)
+        # (compact: only the rows that make residual blocks are handed over, as the reference's own loop adds them)
+        full, win = window.partial_bundle_adjustment_problem(sc, sc.n_cams - 1, gps=True, compact=True)
         workload = ("BASELINE config 5: partial bundle adjustment (sfm_incremental.cc:917-1014) of the newest of %d cameras / %d points / "
                     "%d observations: window of %d cameras (> 5 shared matches), %d free points, one CameraModel per camera, weight 2.0, "
                     "GPS rows (slam_gps.cc:818-830) on the window, dense-Schur LM, Huber(1)"

@@ -239,18 +239,25 @@ void BundleAdjuster::RunOptimizetion(bool is_initial_run, double weight) {
       if (p->cams_.size() == 2) p->weight = 1.0;        // optimizer.cc:69-78
       if (p->cams_.size() >= 3) p->weight = weight;
     }
+    // a residual block exists only where the point or the camera is free (optimizer.cc:86-125): rows of a frozen point in
+    // frozen cameras, and points left without any row, are not part of the problem (for the window of one camera out of
+    // thousands that is nearly everything)
     const int pid = (int)used.size();
+    bool any = false;
+    auto ic = p->cams_.begin();
+    auto ip = p->pts2d_.begin();
+    for (; ic != p->cams_.end(); ++ic, ++ip) {
+      if (!p->is_mutable_ && !ic->second->is_mutable_) continue;
+      obs_cam.push_back(cam_id.at(ic->second));
+      obs_pt.push_back(pid);
+      obs_xy.push_back(ip->second.x); obs_xy.push_back(ip->second.y);
+      any = true;
+    }
+    if (!any) continue;
     used.push_back(p);
     for (int k = 0; k < 3; k++) point.push_back(p->data[k]);
     pt_weight.push_back(p->weight);
     pt_mut.push_back(p->is_mutable_);
-    auto ic = p->cams_.begin();
-    auto ip = p->pts2d_.begin();
-    for (; ic != p->cams_.end(); ++ic, ++ip) {
-      obs_cam.push_back(cam_id.at(ic->second));
-      obs_pt.push_back(pid);
-      obs_xy.push_back(ip->second.x); obs_xy.push_back(ip->second.y);
-    }
   }
   msfm_ba_problem P;
   P.n_cams = (int)cams_.size(); P.n_models = (int)cam_models_.size(); P.n_points = (int)used.size(); P.n_obs = (int)obs_cam.size();

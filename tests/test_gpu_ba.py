@@ -361,3 +361,24 @@ def test_device_built_structures_match_the_host_build():
         outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600))
         assert outs[-1].returncode == 0, outs[-1].stderr[-3000:]
     assert outs[0].stdout == outs[1].stdout and outs[0].stdout.strip()
+
+
+def test_compact_window_hand_over_gives_the_same_solution(ctx):
+    """window.gather(compact=True) hands over only the rows that make residual blocks and the points that have one (what
+    the reference's own loop adds, optimizer.cc:86-125); the library drops the rest of a full hand-over itself.  Same
+    accept / reject sequence and costs, parameters equal to rounding (the point blocks are numbered differently)."""
+    from metricsfm_amd import capi, window
+    sc = scene.make_aerial_scene(120, 30000, seed=91, n_models=120, gps_sigma=0.5, rot_sigma=2e-3, trans_sigma=0.05, point_sigma=0.05)
+    scene.perturb_camera(sc, 119)
+    full, fi = window.partial_bundle_adjustment_problem(sc, 119, gps=True)
+    comp, ci = window.partial_bundle_adjustment_problem(sc, 119, gps=True, compact=True)
+    assert len(comp.obs_cam) < len(full.obs_cam) // 2
+    opt = capi.default_options(max_num_iterations=8)
+    rf, rc = ctx.ba_solve(full, opt), ctx.ba_solve(comp, opt)
+    assert rf["num_residuals"] == rc["num_residuals"] and rf["num_reduced_params"] == rc["num_reduced_params"]
+    assert rf["num_iterations"] == rc["num_iterations"]
+    np.testing.assert_allclose(rc["iterations"]["cost"], rf["iterations"]["cost"], rtol=1e-11)
+    np.testing.assert_allclose(comp.cam_pose, full.cam_pose, rtol=0, atol=1e-9)
+    pos = {p: i for i, p in enumerate(fi["kept"])}
+    sel = np.array([pos[p] for p in ci["kept"]])
+    np.testing.assert_allclose(comp.point, full.point[sel], rtol=0, atol=1e-9)

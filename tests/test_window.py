@@ -117,3 +117,28 @@ def test_window_problem_residual_count_through_the_oracle(oracle):
     assert (arr.cam_pose[frozen_c] == sc.cam_pose[frozen_c]).all() and (arr.point[frozen_p] == sc.point[frozen_p]).all()
     assert (arr.cam_model[frozen_c] == sc.cam_model[frozen_c]).all()
     assert r["iterations"]["cost"][-1] < r["iterations"]["cost"][0]
+
+
+def test_compact_gather_is_the_same_problem(oracle):
+    """Handing over only the rows that make residual blocks (and only the points that have one) is the problem the
+    reference builds (optimizer.cc:86-125); the full hand-over relies on the solver to drop the rest.  Same trajectory, same
+    result, through the oracle."""
+    sc = scene.make_aerial_scene(24, 1200, seed=45, n_models=24, gps_sigma=0.5, rot_sigma=0.02, trans_sigma=0.2, point_sigma=0.2)
+    bad = np.zeros(sc.n_points, bool)
+    bad[5::11] = True
+    full, fi = window.partial_bundle_adjustment_problem(sc, 23, bad=bad, gps=True)
+    comp, ci = window.partial_bundle_adjustment_problem(sc, 23, bad=bad, gps=True, compact=True)
+    assert len(comp.obs_cam) < len(full.obs_cam) and len(comp.point) < len(full.point)
+    assert comp.struct.gps_weight == full.struct.gps_weight
+    assert set(ci["kept"]) <= set(fi["kept"])
+    # every point the compact form leaves out is frozen and seen by frozen cameras only
+    left_out = np.setdiff1d(fi["kept"], ci["kept"])
+    assert not fi["pt_mutable"][left_out].any()
+    opt = oracle.default_options(max_num_iterations=4)
+    rf, rc = oracle.ba_solve(full, opt), oracle.ba_solve(comp, opt)
+    assert rf["num_residuals"] == rc["num_residuals"] and rf["num_reduced_params"] == rc["num_reduced_params"]
+    np.testing.assert_allclose(rc["iterations"]["cost"], rf["iterations"]["cost"], rtol=1e-12)
+    np.testing.assert_allclose(comp.cam_pose, full.cam_pose, rtol=0, atol=1e-11)
+    pos = {p: i for i, p in enumerate(fi["kept"])}
+    sel = np.array([pos[p] for p in ci["kept"]])
+    np.testing.assert_allclose(comp.point, full.point[sel], rtol=0, atol=1e-11)
