@@ -35,10 +35,17 @@
 // a wave (C3: 1500 waves for 1024 SIMDs x 2); 512 rows per wave = 8 passes of 64 lanes (measured 128 .. 1024: 0.117, 0.107,
 // 0.102, 0.100 ms for the three per-camera kernels together - flat from 512 on)
 #define FTF_CHUNK 512
-static int ftf_chunk() {
+// Small problems (the window of one new camera: a few hundred thousand rows) would leave most of the chip without a wave at
+// those lengths: chunks shrink, in steps of 64, until a list makes about 1024 waves (more, shorter chunks cost the
+// assembly, which adds a block's chunk partials in order, what they save here: measured at config 3).
+static int chunk_for(long total, int max_chunk) {
+  const long c = 64 * ((total / 1024 + 63) / 64);
+  return (int)std::max<long>(64, std::min<long>(max_chunk, c));
+}
+static int ftf_chunk(long rows) {
   const char* e = getenv("MSFM_FTF_CHUNK");   // (experiments)
   const int v = e ? atoi(e) : 0;
-  return v >= 64 ? v : FTF_CHUNK;
+  return v >= 64 ? v : chunk_for(rows, FTF_CHUNK);
 }
 // FTF partial layout
 #define F_JCJC 0     // 36
@@ -1299,11 +1306,12 @@ static int finish_jobs(msfm_ba* ba, PairJobs& J, const std::vector<int>& pa, con
   J.h_row = brow;
   J.h_col = bcol;
   std::vector<int> cs, ce, bcf(J.n_blocks + 1, 0);
+  const int chunk = chunk_for((long)pa.size(), CHUNK);
   for (int b = 0; b < J.n_blocks; b++) {
     bcf[b] = (int)cs.size();
-    for (long e = key_first[b]; e < key_first[b + 1]; e += CHUNK) {
+    for (long e = key_first[b]; e < key_first[b + 1]; e += chunk) {
       cs.push_back((int)e);
-      ce.push_back((int)std::min<long>(e + CHUNK, key_first[b + 1]));
+      ce.push_back((int)std::min<long>(e + chunk, key_first[b + 1]));
     }
   }
   bcf[J.n_blocks] = (int)cs.size();
@@ -1651,20 +1659,21 @@ __global__ __launch_bounds__(256) void k_gather2(int n, const int* __restrict__ 
   if (i < n) { a2[i] = a[perm[i]]; b2[i] = b[perm[i]]; }
 }
 // a block exists if it has entries or must be assembled from the F^T F terms alone
-__global__ __launch_bounds__(256) void k_block_flags(long nkey, long ncol, int kind, const int* __restrict__ key_hist, const int* __restrict__ cb_mb,
-                                                      int* __restrict__ flag, int* __restrict__ nchunk) {
+__global__ __launch_bounds__(256) void k_block_flags(long nkey, long ncol, int kind, int chunk, const int* __restrict__ key_hist,
+                                                      const int* __restrict__ cb_mb, int* __restrict__ flag, int* __restrict__ nchunk) {
   const long k = (long)blockIdx.x * 256 + threadIdx.x;
   if (k >= nkey) return;
   const long r = k / ncol, c = k % ncol;
   const bool force = kind == 1 ? (cb_mb[c] == r) : (r == c);
   const int n = key_hist[k];
   flag[k] = (n > 0 || force) ? 1 : 0;
-  nchunk[k] = (n + CHUNK - 1) / CHUNK;
+  nchunk[k] = (n + chunk - 1) / chunk;
 }
 __global__ __launch_bounds__(256) void k_block_lists(long nkey, long ncol, const int* __restrict__ flag, const int* __restrict__ blk_of_key,
                                                       const int* __restrict__ key_first, const int* __restrict__ key_hist,
-                                                      const int* __restrict__ chunk_first_of_key, int* __restrict__ blk_row, int* __restrict__ blk_col,
-                                                      int* __restrict__ blk_chunk_first, int* __restrict__ ch_start, int* __restrict__ ch_end) {
+                                                      const int* __restrict__ chunk_first_of_key, int chunk, int* __restrict__ blk_row,
+                                                      int* __restrict__ blk_col, int* __restrict__ blk_chunk_first, int* __restrict__ ch_start,
+                                                      int* __restrict__ ch_end) {
   const long k = (long)blockIdx.x * 256 + threadIdx.x;
   if (k >= nkey || !flag[k]) return;
   const int b = blk_of_key[k];
@@ -1673,7 +1682,7 @@ __global__ __launch_bounds__(256) void k_block_lists(long nkey, long ncol, const
   const int cf = chunk_first_of_key[k];
   blk_chunk_first[b] = cf;
   const int e0 = key_first[k], n = key_hist[k];
-  for (int q = 0, e = e0; e < e0 + n; e += CHUNK, q++) { ch_start[cf + q] = e; ch_end[cf + q] = min(e + CHUNK, e0 + n); }
+  for (int q = 0, e = e0; e < e0 + n; e += chunk, q++) { ch_start[cf + q] = e; ch_end[cf + q] = min(e + chunk, e0 + n); }
 }
 
 }  // namespace devsetup
@@ -1723,7 +1732,8 @@ static int build_pairs_device(msfm_ctx* ctx, msfm_ba* ba, PairJobs& J, int nout,
   // blocks and chunks
   DTRY(flag.alloc((size_t)nkey + 1)); DTRY(nchunk.alloc((size_t)nkey + 1)); DTRY(blk_of_key.alloc((size_t)nkey + 1)); DTRY(chunk_first.alloc((size_t)nkey + 1));
   DTRY(hipMemsetAsync(flag.p + nkey, 0, sizeof(int), s)); DTRY(hipMemsetAsync(nchunk.p + nkey, 0, sizeof(int), s));
-  hipLaunchKernelGGL(k_block_flags, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, KIND, key_hist.p, ba->cb_mb.p, flag.p, nchunk.p);
+  const int chunk = chunk_for((long)total, CHUNK);   // (the host build, finish_jobs, takes the same length)
+  hipLaunchKernelGGL(k_block_flags, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, KIND, chunk, key_hist.p, ba->cb_mb.p, flag.p, nchunk.p);
   DTRY(excl_scan(flag.p, blk_of_key.p, (size_t)nkey + 1, s, tmp));
   DTRY(excl_scan(nchunk.p, chunk_first.p, (size_t)nkey + 1, s, tmp));
   int nbc[2] = {0, 0};
@@ -1735,7 +1745,7 @@ static int build_pairs_device(msfm_ctx* ctx, msfm_ba* ba, PairJobs& J, int nout,
   DTRY(J.blk_chunk_first.alloc((size_t)J.n_blocks + 1));
   DTRY(J.ch_start.alloc((size_t)std::max(1, J.n_chunks))); DTRY(J.ch_end.alloc((size_t)std::max(1, J.n_chunks)));
   hipLaunchKernelGGL(k_block_lists, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, flag.p, blk_of_key.p, key_first.p, key_hist.p, chunk_first.p,
-                     J.blk_row.p, J.blk_col.p, J.blk_chunk_first.p, J.ch_start.p, J.ch_end.p);
+                     chunk, J.blk_row.p, J.blk_col.p, J.blk_chunk_first.p, J.ch_start.p, J.ch_end.p);
   DTRY(hipMemcpyAsync(J.blk_chunk_first.p + J.n_blocks, &J.n_chunks, sizeof(int), hipMemcpyHostToDevice, s));
   DTRY(J.partial.alloc((size_t)std::max(1, J.n_chunks) * nout));
   if (want_host_blocks && J.n_blocks) {
@@ -1955,7 +1965,7 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
                                      ba->pm_mb.p, ba->o_pm.p, d_err.p);
   // ---- FTF chunks (host: O(cameras + rows / 1024)) ----
   std::vector<int> f_start, f_end, cam_chunk_first(ncb + 1, 0);
-  const int fchunk = ftf_chunk();
+  const int fchunk = ftf_chunk(cam_first[ncb]);
   for (int c = 0; c < ncb; c++) {
     cam_chunk_first[c] = (int)f_start.size();
     for (int e = cam_first[c]; e < cam_first[c + 1]; e += fchunk) { f_start.push_back(e); f_end.push_back(std::min(e + fchunk, cam_first[c + 1])); }
@@ -2255,7 +2265,7 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
   lap("positions + pm entries");
   // ---- FTF chunks (camera-major rows) ----
   std::vector<int> f_start, f_end, cam_chunk_first(ncb + 1, 0);
-  const int fchunk = ftf_chunk();
+  const int fchunk = ftf_chunk(cam_first[ncb]);
   for (int c = 0; c < ncb; c++) {
     cam_chunk_first[c] = (int)f_start.size();
     for (int e = cam_first[c]; e < cam_first[c + 1]; e += fchunk) { f_start.push_back(e); f_end.push_back(std::min(e + fchunk, cam_first[c + 1])); }
