@@ -6,8 +6,6 @@ R=$PWD
 O=$R/gpurun_out/prof
 rm -rf $O && mkdir -p $O   # (the local copy under gpurun_out/ keeps older run directories: delete it before a new collection)
 export TMPDIR=/tmp
-python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-echo "bench done"; tail -c 300 $O/bench.json
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/kt.log 2>&1
 echo "kernel trace done"
@@ -17,6 +15,10 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write
 echo "pmc write done"
 cd $R
 python3 scripts/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc > $O/pmc_summary.txt 2>&1 || echo "pmc post-processing failed"
+# the bench line comes after the counters so that it can attach them (same kernel sources: the hash inside matches)
+cp $O/pmc_traffic.json profiles/pmc_traffic.json
+python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+echo "bench done"; tail -c 300 $O/bench.json
 python3 bench.py --config 5 --window --steps 20 --warmup 3 > $O/bench_c5_window.json 2> $O/bench_c5_window.err
 echo "config 5 window done"
 python3 scripts/extra_bench.py --c5 > $O/extra.json 2> $O/extra.err
