@@ -382,3 +382,29 @@ def test_compact_window_hand_over_gives_the_same_solution(ctx):
     pos = {p: i for i, p in enumerate(fi["kept"])}
     sel = np.array([pos[p] for p in ci["kept"]])
     np.testing.assert_allclose(comp.point, full.point[sel], rtol=0, atol=1e-9)
+
+
+def test_ba_small_angle_branch_cameras(ctx, oracle):
+    """Cameras whose angle-axis vector is exactly zero, or so short that |a|^2 <= DBL_EPSILON, take the first-order branch of
+    the rotation formula (SfM/src/utils/basic_funcs.cc:122,165) and its exact derivative; the per-camera rotation data
+    (msfm_rot_prepare) carries the branch flag.  Iteration 0 is evaluated in that branch, later ones leave it."""
+    rng = np.random.default_rng(77)
+    n_cams, n_pts = 8, 600
+    pose = np.zeros((n_cams, 6))
+    pose[:, 3] = -np.linspace(0.0, 7.0, n_cams)                 # t = -R c, cameras in a row along x, looking along +z
+    pose[3, :3] = [1e-9, -2e-9, 5e-10]
+    pose[4, :3] = [-3e-10, 1e-10, 8e-9]
+    pose[5:, :3] = rng.normal(0, 0.05, (3, 3))
+    pt = np.column_stack([rng.uniform(-5, 12, n_pts), rng.uniform(-3, 3, n_pts), rng.uniform(8, 14, n_pts)])
+    model = np.array([[800.0, 0.0, 0.0]])
+    obs_cam = np.tile(np.arange(n_cams, dtype=np.int32), n_pts)
+    obs_pt = np.repeat(np.arange(n_pts, dtype=np.int32), n_cams)
+    uv, depth = scene.project(pose[obs_cam], model[np.zeros(len(obs_cam), int)], pt[obs_pt])
+    assert (depth > 0).all()
+    sc = scene.Scene(name="small-angle", cam_pose_gt=pose.copy(), cam_model_gt=model.copy(), point_gt=pt.copy(), cam_pose=pose.copy(),
+                     cam_model=model.copy(), point=pt + rng.normal(0, 0.05, pt.shape), cam_model_of_cam=np.zeros(n_cams, np.int32),
+                     obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=uv + rng.normal(0, 0.3, uv.shape), pt_weight=np.ones(n_pts))
+    assert ((sc.cam_pose[:5, :3] ** 2).sum(axis=1) <= 2.220446049250313e-16).all()
+    r, _, a = check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc), dict(max_num_iterations=6))
+    assert r["iterations"]["cost"][-1] < r["iterations"]["cost"][0]
+    assert np.abs(a.cam_pose[:5, :3]).max() > 1e-7             # the adjusted cameras have left the branch
