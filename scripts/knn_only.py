@@ -5,9 +5,10 @@ import numpy as np
 from metricsfm_amd import capi, scene
 ctx = capi.Context(0)
 sc = scene.config_scene(2)
-scene.add_features(sc, 4096, images=list(range(12)))
-ds = capi.DescSet(ctx, [sc.desc[i] for i in range(12)])
-pairs = np.array([(i, j) for i in range(12) for j in range(12) if i != j], dtype=np.int32)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+scene.add_features(sc, 4096, images=list(range(N)))
+ds = capi.DescSet(ctx, [sc.desc[i] for i in range(N)])
+pairs = np.array([(i, j) for i in range(N) for j in range(N) if i != j], dtype=np.int32)
 for _ in range(3):
     t0 = time.perf_counter()
     res = ds.match_pairs(pairs)
