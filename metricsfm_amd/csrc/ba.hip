@@ -831,19 +831,7 @@ __global__ void k_pad_diag(int npadcol, const int* __restrict__ padcol, double* 
   if (i < npadcol) M[(size_t)padcol[i] * ld + padcol[i]] = 1.0;
 }
 
-// solver order (domains, padding, separator, intrinsics) -> block order of the BA kernels
-// the solution in block order (the system is solved in elimination order), with the finiteness check on the way
-__global__ void k_gather_z(int ncb, int nmb, const int* __restrict__ cb_off, int mo, const double* __restrict__ zsys, double* __restrict__ z,
-                           int* __restrict__ fail) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double v;
-  if (i < 6 * ncb) v = zsys[cb_off[i / 6] + i % 6];
-  else if (i < 6 * ncb + 3 * nmb) v = zsys[mo + (i - 6 * ncb)];
-  else return;
-  z[i] = v;
-  if (!isfinite(v)) atomicOr(fail, 4);
-}
-// candidate buffers start as copies of x so that inactive blocks carry over: the three copies in one launch
+// candidate buffers start as copies of x so that inactive blocks carry over: the three copies in one launch (run start)
 __global__ __launch_bounds__(256) void k_copy3(size_t n0, const double* __restrict__ a0, double* __restrict__ b0, size_t n1,
                                                const double* __restrict__ a1, double* __restrict__ b1, size_t n2,
                                                const double* __restrict__ a2, double* __restrict__ b2) {
@@ -860,19 +848,42 @@ __global__ void k_scale_scal(double* __restrict__ scal, int slot, double f) { sc
 // After the reduced solve: camera / intrinsics update, point back substitution, model cost.
 // z = solution of S z = rhs (scaled space); step = -z.
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_blocks(int nblocks, int dim, const int* __restrict__ blk_param, const double* __restrict__ z,
-                                                        int zoff, const double* __restrict__ scale, const double* __restrict__ x,
-                                                        double* __restrict__ xc, double* __restrict__ dx2_partial,
-                                                        double* __restrict__ x2_partial, double count_weight) {
+// The camera and intrinsics part of the step in one launch: the solution leaves the solver's elimination order (zsys) for
+// the block order of the BA kernels (z, read by k_backsub / k_mcc_rest), with the finiteness check on the way, and the
+// candidates x - z * scale go to the candidate buffers.  (Inactive blocks of the candidate buffers were filled once, at the
+// start of the run: nothing writes them.)  One launch instead of k_gather_z + k_copy3 + 2 x k_update_blocks.
+__global__ __launch_bounds__(256) void k_update_params(int ncb, int nmb, const int* __restrict__ cb_cam, const int* __restrict__ mb_model,
+                                                        const int* __restrict__ cb_off, int mo, const double* __restrict__ zsys,
+                                                        const double* __restrict__ scale_c, const double* __restrict__ scale_m,
+                                                        const double* __restrict__ cam, double* __restrict__ cam_c,
+                                                        const double* __restrict__ model, double* __restrict__ model_c, double* __restrict__ z,
+                                                        int* __restrict__ fail, double* __restrict__ dx2_partial, double* __restrict__ x2_partial,
+                                                        double count_weight) {
   __shared__ double sh[4];
   const int i = blockIdx.x * 256 + threadIdx.x;
   double dx2 = 0.0, x2 = 0.0;
-  if (i < nblocks * dim) {
-    const int b = i / dim, a = i % dim;
-    const size_t k = (size_t)blk_param[b] * dim + a;
-    const double xv = x[k];
-    const double cand = xv + (-z[zoff + i]) * scale[i];
-    xc[k] = cand;
+  if (i < 6 * ncb + 3 * nmb) {
+    double zv, sc, xv;
+    double* dst;
+    if (i < 6 * ncb) {
+      const int b = i / 6, a = i % 6;
+      zv = zsys[cb_off[b] + a];
+      sc = scale_c[i];
+      const size_t k = (size_t)cb_cam[b] * 6 + a;
+      xv = cam[k];
+      dst = cam_c + k;
+    } else {
+      const int j = i - 6 * ncb, b = j / 3, a = j % 3;
+      zv = zsys[mo + j];
+      sc = scale_m[j];
+      const size_t k = (size_t)mb_model[b] * 3 + a;
+      xv = model[k];
+      dst = model_c + k;
+    }
+    z[i] = zv;
+    if (!isfinite(zv)) atomicOr(fail, 4);
+    const double cand = xv + (-zv) * sc;
+    *dst = cand;
     const double d = cand - xv;
     dx2 = d * d * count_weight;  // replicated blocks are counted by the lead rank only
     x2 = xv * xv * count_weight;
@@ -889,7 +900,7 @@ struct BackPtrs {
   const double *ptL, *z;
   double* pt_c;
   int Nc;                  // the first Nc threads of the launch also prepare the candidate cameras' rotations
-  const double* cam_c;     // (final before this launch: k_copy3 + k_update_blocks)
+  const double* cam_c;     // (final before this launch: k_update_params)
   double* rot_c;
 };
 
@@ -2795,22 +2806,19 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
   if (ba->nred > 0) {
     MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, ba->zsys.p, ba->fail.p,
                                     ba->plan.n_levels > 0 ? &ba->plan : nullptr));
-    hipLaunchKernelGGL(k_gather_z, dim3(cdiv(ba->nred, 256)), dim3(256), 0, s, ncb, nmb, ba->cb_off.p, ba->mo, ba->zsys.p, ba->z.p, ba->fail.p);
   }
   {
     KTimer t(ctx, "ba_backsub");
-    const int nbc = cdiv(std::max(1, 6 * ncb), 256), nbm = cdiv(std::max(1, 3 * nmb), 256), nbp = ba->nblk_pt;
-    // candidate buffers start as copies of x so inactive blocks carry over
-    {
-      const size_t n0 = 6 * (size_t)ba->Nc, n1 = 3 * (size_t)ba->Nm, n2 = 3 * (size_t)ba->Np;
-      hipLaunchKernelGGL(k_copy3, dim3(cdiv((long)std::max(n0, std::max(n1, n2)), 256)), dim3(256), 0, s, n0, ba->cam.p, ba->cam_c.p, n1,
-                         ba->model.p, ba->model_c.p, n2, ba->pt.p, ba->pt_c.p);
-    }
+    const int nbu = cdiv(std::max(1, ba->nred), 256), nbp = ba->nblk_pt;
     int off = 0;
     const double wrep = lead ? 1.0 : 0.0;
     // partial2 = |dx|^2 partials, partial3 = |x|^2 partials, partial = model cost partials
-    if (ncb) { hipLaunchKernelGGL(k_update_blocks, dim3(nbc), dim3(256), 0, s, ncb, 6, ba->cb_cam.p, ba->z.p, 0, ba->scale_c.p, ba->cam.p, ba->cam_c.p, ba->partial2.p + off, ba->partial3.p + off, wrep); off += nbc; }
-    if (nmb) { hipLaunchKernelGGL(k_update_blocks, dim3(nbm), dim3(256), 0, s, nmb, 3, ba->mb_model.p, ba->z.p, 6 * ncb, ba->scale_m.p, ba->model.p, ba->model_c.p, ba->partial2.p + off, ba->partial3.p + off, wrep); off += nbm; }
+    if (ba->nred > 0) {
+      hipLaunchKernelGGL(k_update_params, dim3(nbu), dim3(256), 0, s, ncb, nmb, ba->cb_cam.p, ba->mb_model.p, ba->cb_off.p, ba->mo, ba->zsys.p,
+                         ba->scale_c.p, ba->scale_m.p, ba->cam.p, ba->cam_c.p, ba->model.p, ba->model_c.p, ba->z.p, ba->fail.p,
+                         ba->partial2.p + off, ba->partial3.p + off, wrep);
+      off += nbu;
+    }
     int moff = 0;
     if (npb) {
       BackPtrs Q;
@@ -2880,6 +2888,13 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   if (nmb) hipLaunchKernelGGL(k_fill, dim3(cdiv(3 * nmb, 256)), dim3(256), 0, s, 3 * nmb, 1.0, ba->scale_m.p);
   if (npb) hipLaunchKernelGGL(k_fill, dim3(cdiv(3 * npb, 256)), dim3(256), 0, s, 3 * npb, 1.0, ba->scale_p.p);
   hipLaunchKernelGGL(k_rot_cache, dim3(cdiv(std::max(1, ba->Nc), 256)), dim3(256), 0, s, ba->Nc, ba->cam.p, ba->rot.p);
+  {
+    // the candidate buffers start as copies of x: the steps overwrite every active block, the inactive ones never change
+    // (x and its candidate swap roles at every accepted step, so both must hold them)
+    const size_t n0 = 6 * (size_t)ba->Nc, n1 = 3 * (size_t)ba->Nm, n2 = 3 * (size_t)ba->Np;
+    hipLaunchKernelGGL(k_copy3, dim3(cdiv((long)std::max(n0, std::max(n1, n2)), 256)), dim3(256), 0, s, n0, ba->cam.p, ba->cam_c.p, n1,
+                       ba->model.p, ba->model_c.p, n2, ba->pt.p, ba->pt_c.p);
+  }
   lap("scales reset");
   hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
