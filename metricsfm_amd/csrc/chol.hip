@@ -703,47 +703,64 @@ __global__ __launch_bounds__(256) void k_merge_corners(double* __restrict__ M, i
 // ---------------------------------------------------------------------------------------
 // Workgroups past the last diagonal block copy the eliminated rhs row (row n of M) into w for the back substitution
 // (one launch fewer on the dependent chain).
+// C (16 x 16 tile at rows rc, columns cc of Cm) = sign * A[ra.., ka..ka+K) * B[kb..kb+K, cb..) with all three row-major in LDS
+// (stride LDT), one wave, K a multiple of 4: the f64 MFMA takes A[m = lane & 15][k = lane >> 4] and B[k = lane >> 4][n = lane & 15].
+template <int K>
+__device__ __forceinline__ void tile_mm(double* Cm, int rc, int cc, const double* A, int ra, int ka, const double* B, int kb, int cb, bool negate,
+                                        int lr, int lk) {
+  d4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int ks = 0; ks < K / 4; ks++) {
+    const double a = A[(ra + lr) * LDT + ka + 4 * ks + lk];
+    const double b = B[(kb + 4 * ks + lk) * LDT + cb + lr];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -a : a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) Cm[(rc + lk + 4 * i) * LDT + cc + lr] = acc[i];
+}
+
 __global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ Ldiag, int n, const double* __restrict__ Dinv,
                                                        double* __restrict__ Linv, int nblk, const double* __restrict__ M, int ld,
                                                        double* __restrict__ w, int npad) {
-  __shared__ double L[NB][NB + 1];
-  __shared__ double v[NB][NB + 1];
-  __shared__ double t[NB][NB + 1];
+  __shared__ double L[NB * LDT];
+  __shared__ double v[NB * LDT];
+  __shared__ double t[NB * LDT];
   if ((int)blockIdx.x >= nblk) {
     const int i = ((int)blockIdx.x - nblk) * 256 + (int)threadIdx.x;
     if (i < npad) w[i] = (i < n) ? M[(size_t)n * ld + i] : 0.0;
     return;
   }
   const int blk = blockIdx.x, j0 = blk * NB, tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   const int ncol = min(NB, n - j0);
   for (int e = tid; e < NB * NB; e += 256) {
     const int r = e >> 6, c = e & 63;
-    L[r][c] = (c <= r && r < ncol) ? Ldiag[(size_t)blk * NB * NB + r * NB + c] : 0.0;
+    L[r * LDT + c] = (c <= r && r < ncol) ? Ldiag[(size_t)blk * NB * NB + r * NB + c] : 0.0;
     const bool diag16 = (r >> 4) == (c >> 4);
-    v[r][c] = diag16 ? Dinv[(size_t)blk * 1024 + ((r >> 4) * 16 + (r & 15)) * 16 + (c & 15)] : 0.0;
+    v[r * LDT + c] = diag16 ? Dinv[(size_t)blk * 1024 + ((r >> 4) * 16 + (r & 15)) * 16 + (c & 15)] : 0.0;
   }
   __syncthreads();
-  for (int s = 16; s < 64; s *= 2) {
-    const int npair = 64 / (2 * s), ss = s * s;
-    for (int e = tid; e < npair * ss; e += 256) {
-      const int pr = e / ss, rem = e - pr * ss, r = rem / s, c = rem - r * s;
-      const int o = pr * 2 * s;
-      double acc = 0.0;
-      for (int k = c; k < s; k++) acc += L[o + s + r][o + k] * v[o + k][o + c];
-      t[o + s + r][o + c] = acc;
-    }
-    __syncthreads();
-    for (int e = tid; e < npair * ss; e += 256) {
-      const int pr = e / ss, rem = e - pr * ss, r = rem / s, c = rem - r * s;
-      const int o = pr * 2 * s;
-      double acc = 0.0;
-      for (int k = 0; k <= r; k++) acc += v[o + s + r][o + s + k] * t[o + s + k][o + c];
-      v[o + s + r][o + c] = -acc;
-    }
-    __syncthreads();
+  // s = 16: the two 32 x 32 diagonal blocks, off-diagonal tile  -C^-1 (B A^-1)  each (waves 0 and 1)
+  if (wave < 2) {
+    const int o = 32 * wave;
+    tile_mm<16>(t, o + 16, o, L, o + 16, o, v, o, o, false, lr, lk);            // t = B A^-1
   }
+  __syncthreads();
+  if (wave < 2) {
+    const int o = 32 * wave;
+    tile_mm<16>(v, o + 16, o, v, o + 16, o + 16, t, o + 16, o, true, lr, lk);   // -C^-1 t
+  }
+  __syncthreads();
+  // s = 32: the lower-left 32 x 32 block, one 16 x 16 tile per wave
+  {
+    const int tr = wave >> 1, tc = wave & 1;
+    tile_mm<32>(t, 32 + 16 * tr, 16 * tc, L, 32 + 16 * tr, 0, v, 0, 16 * tc, false, lr, lk);
+    __syncthreads();
+    tile_mm<32>(v, 32 + 16 * tr, 16 * tc, v, 32 + 16 * tr, 32, t, 32, 16 * tc, true, lr, lk);
+  }
+  __syncthreads();
   double* out = Linv + (size_t)blk * NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) out[e] = v[e >> 6][e & 63];
+  for (int e = tid; e < NB * NB; e += 256) out[e] = v[(e >> 6) * LDT + (e & 63)];
 }
 
 // ---------------------------------------------------------------------------------------
