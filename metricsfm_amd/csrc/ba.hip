@@ -720,6 +720,24 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
 // --------------------------------------------------------------------------------------
 // Assembly of the padded dense system M (row-major npad x npad, lower triangle; row n = rhs).
 // --------------------------------------------------------------------------------------
+// Zero fill of the reduced system before the assembly: only the 64 x 64 tiles of the lower triangle that the factorisation
+// reads or writes.  With an elimination tree those are, for a column block, the rows of its own node, of the nodes above it
+// and of the root chain (everything else is structurally zero and never touched: at config 3 one tile in five of the square).
+// lev[b] / lo[b] / hi[b]: level and leaf interval of the node that owns 64-block b (root: level 127, every leaf).
+struct ZeroMap { unsigned char lev[256]; short lo[256], hi[256]; int nb; };
+__global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int ld, ZeroMap Z) {
+  const int tile = blockIdx.x;
+  int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > tile) I--;
+  while ((I + 1) * (I + 2) / 2 <= tile) I++;
+  const int J = tile - I * (I + 1) / 2;
+  const bool same = Z.lev[I] == Z.lev[J] && Z.lo[I] == Z.lo[J] && Z.hi[I] == Z.hi[J];
+  const bool above = Z.lev[I] > Z.lev[J] && Z.lo[I] <= Z.lo[J] && Z.hi[I] >= Z.hi[J];
+  if (!same && !above) return;
+  double2* base = reinterpret_cast<double2*>(M + (size_t)(64 * I) * ld + 64 * J);
+  for (int e = threadIdx.x; e < 64 * 32; e += 256) base[(size_t)(e >> 5) * (ld / 2) + (e & 31)] = make_double2(0.0, 0.0);
+}
+
 // camera-camera blocks: 64 threads (36 used) per block.
 __device__ __forceinline__ void asm_cc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                        const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
@@ -2716,7 +2734,21 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   }
   {
     KTimer t(ctx, "ba_assemble");
-    HIP_TRY(ctx, hipMemsetAsync(ba->M.p, 0, sizeof(double) * (size_t)ba->npad * ba->npad, s));
+    const int nb64 = ba->npad / 64;
+    if (ctx->world > 1 || nb64 > 256) {
+      // (several ranks sum whole rows of M: every entry must be defined)
+      HIP_TRY(ctx, hipMemsetAsync(ba->M.p, 0, sizeof(double) * (size_t)ba->npad * ba->npad, s));
+    } else {
+      ZeroMap Z;
+      Z.nb = nb64;
+      for (int b = 0; b < nb64; b++) { Z.lev[b] = 127; Z.lo[b] = 0; Z.hi[b] = 0x7fff; }   // root chain / dense order: couples to everything
+      for (int lv = 0; lv < ba->plan.n_levels; lv++)
+        for (int k = 0; k < ba->plan.level[lv].K; k++) {
+          const msfm_chol_node& nd = ba->plan.level[lv].node[k];
+          for (int b = nd.begin / 64; b < nd.end / 64; b++) { Z.lev[b] = (unsigned char)lv; Z.lo[b] = (short)nd.leaf_lo; Z.hi[b] = (short)nd.leaf_hi; }
+        }
+      hipLaunchKernelGGL(k_zero_system, dim3(nb64 * (nb64 + 1) / 2), dim3(256), 0, s, ba->M.p, ba->npad, Z);
+    }
     AsmArgs aa;
     aa.n_cc = ba->cc.n_blocks; aa.n_mc = ba->mc.n_blocks; aa.n_mm = ba->mm.n_blocks; aa.n_rhs = cdiv(6 * ncb, 64);
     aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
