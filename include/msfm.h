@@ -91,10 +91,13 @@ int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim /* 128 */, msfm_des
  * msfm_match_result_fetch on them return MSFM_E_INVAL; create a new result with msfm_match_pairs. */
 int msfm_descset_upload(msfm_descset* set, int image, const float* desc, int count);
 int msfm_descset_count(const msfm_descset* set, int image);
+/* Ordering rule: a set may be destroyed before its match results.  The results then keep what they own - counts, codes
+ * and (with keep_knn) the 2-NN arrays stay readable through msfm_match_result_counts / _fetch / _stats - while
+ * msfm_match_pairs_rerun on them returns MSFM_E_INVAL; they are released by msfm_match_result_destroy as usual. */
 void msfm_descset_destroy(msfm_descset* set);
 
 /* Batched pair matching with the ratio tests fused in
- * (fine_matching_graph.cc:87-133; SLAM variant slam_gps.cc:469-477).
+ * (fine_matching_graph.cc:87-133; the SLAM variant slam_gps.cc:469-503 is msfm_match_pairs_slam below).
  * pairs[p] = {idx1 (train image), idx2 (query image)}.
  * For pair p and query feature m of image idx2 (in feature order, which is the order of
  * the reference loop fine_matching_graph.cc:116-133):
@@ -126,6 +129,33 @@ void msfm_match_result_destroy(msfm_match_result* res);
 /* Re-run the same pair list into an existing result object (steady-state bench loop:
  * no allocation, no host transfer). */
 int msfm_match_pairs_rerun(msfm_descset* set, msfm_match_result* res);
+
+/* Keypoint positions of an image's features, [count][2] float as cv::Point2f (`db_.keypoints_[id]->pts[k].pt`), resident
+ * beside its descriptors; `count` must equal the image's descriptor count.  Needed by msfm_match_pairs_slam; uploading the
+ * descriptors of the image again drops them. */
+int msfm_descset_upload_keypoints(msfm_descset* set, int image, const float* xy, int count);
+
+/* The matching loop of SLAMGPS::FeatureMatching step 2 (SfM/src/slam_gps.cc:455-503), batched over image pairs, in place of
+ * flann_find_nearest_neighbors_index (:463) and the three checks behind it.  For pair p = {id1 (train), id2 (query)} with
+ * its prior F = Fs[i][j] and H = Hs[i][j] (row-major [9], as cv::Mat_<double>(3,3)) and query feature m:
+ *     check1 (:469-475)  ratio = sqdist0 / sqdist1;  rejected if ratio > th_first_second_ratio
+ *                        (`>`: a ratio equal to the threshold, or 0/0 from duplicate descriptors, passes - unlike the
+ *                        `ratio < th` tests of fine_matching_graph.cc:118-130 behind msfm_match_pairs)
+ *     check2 (:478-488)  l = F [x1 y1 1]^T, rejected if |l . [x2 y2 1]| / sqrt(l0^2 + l1^2) > th_epipolar
+ *     check3 (:490-499)  q = H [x1 y1 1]^T / q2, rejected if |[x2 y2] - q| > 40 * th_distance
+ * with (x1, y1) the position of train feature id0 and (x2, y2) of query feature m, binary64 arithmetic as cv::Mat does it.
+ *     code = id0 (no flag bits) for a match that passes all three, -1 otherwise   -> matches[j] = (code, m) in m order (:503)
+ *     n_good[p] = survivors of check1,  n_all[p] = survivors of all three (= matches[j].size() before :509)
+ * The survivors then go to msfm_fundamental_ransac_batch (GeoVerificationFundamental, :509). */
+typedef struct msfm_slam_match_options {
+  float th_first_second_ratio; /* 0.80               (slam_gps.cc:320) */
+  float th_epipolar;           /* 2.0 / resize_ratio (slam_gps.cc:316) */
+  float th_distance;           /* 5.0 / resize_ratio (slam_gps.cc:317) */
+} msfm_slam_match_options;
+void msfm_slam_match_default_options(msfm_slam_match_options* opt);
+int msfm_match_pairs_slam(msfm_descset* set, const int* pairs /*[n_pairs][2]*/, int n_pairs,
+                          const double* F /*[n_pairs][9]*/, const double* H /*[n_pairs][9]*/,
+                          const msfm_slam_match_options* opt, int keep_knn, msfm_match_result** out);
 
 /* ==================================================================================== *
  *  Bundle adjustment  

@@ -40,6 +40,11 @@ class FransacOptions(C.Structure):
                 ("min_points", C.c_int), ("min_inliers", C.c_int), ("seed", C.c_uint64)]
 
 
+class SlamMatchOptions(C.Structure):
+    """msfm_slam_match_options (include/msfm.h)."""
+    _fields_ = [("th_first_second_ratio", C.c_float), ("th_epipolar", C.c_float), ("th_distance", C.c_float)]
+
+
 class BaOptions(C.Structure):
     _fields_ = [("max_num_iterations", C.c_int), ("num_threads", C.c_int), ("progress_to_stdout", C.c_int),
                 ("huber_delta", C.c_double), ("function_tolerance", C.c_double),

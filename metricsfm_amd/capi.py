@@ -19,7 +19,8 @@ SYMBOLS = [
     "msfm_ctx_synchronize", "msfm_ctx_profile_enable", "msfm_ctx_profile_reset", "msfm_ctx_profile_get",
     "msfm_knn2_f32", "msfm_descset_create", "msfm_descset_upload", "msfm_descset_count", "msfm_descset_destroy",
     "msfm_match_pairs", "msfm_match_result_counts", "msfm_match_result_fetch", "msfm_match_result_stats", "msfm_match_result_destroy",
-    "msfm_match_pairs_rerun", "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
+    "msfm_match_pairs_rerun", "msfm_descset_upload_keypoints", "msfm_slam_match_default_options", "msfm_match_pairs_slam",
+    "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
     "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ba_get_layout", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
@@ -63,6 +64,10 @@ def lib():
     L.msfm_descset_destroy.restype = None
     L.msfm_match_pairs.argtypes = [vp, A.c_int_p, i, f, f, i, C.POINTER(vp)]
     L.msfm_match_pairs_rerun.argtypes = [vp, vp]
+    L.msfm_descset_upload_keypoints.argtypes = [vp, i, A.c_float_p, i]
+    L.msfm_slam_match_default_options.argtypes = [C.POINTER(A.SlamMatchOptions)]
+    L.msfm_slam_match_default_options.restype = None
+    L.msfm_match_pairs_slam.argtypes = [vp, A.c_int_p, i, A.c_double_p, A.c_double_p, C.POINTER(A.SlamMatchOptions), i, C.POINTER(vp)]
     L.msfm_match_result_counts.argtypes = [vp, A.c_int_p, A.c_int_p]
     L.msfm_match_result_fetch.argtypes = [vp, i, A.c_int_p, A.c_int_p, A.c_float_p]
     L.msfm_match_result_stats.argtypes = [vp, A.c_int_p, A.c_int_p]
@@ -270,8 +275,8 @@ class Context:
                                        len(query), train.shape[1], A.ptr(ids, A.c_int_p), A.ptr(d, A.c_float_p)))
         return ids, d
 
-    def descset(self, descs):
-        return DescSet(self, descs)
+    def descset(self, descs, keypoints=None):
+        return DescSet(self, descs, keypoints)
 
     # -- bundle adjustment --
     def ba_solve(self, arrays: A.BaArrays, options=None, capacity=512):
@@ -391,7 +396,7 @@ class Context:
 class DescSet:
     """Device-resident descriptors of a set of images (msfm_descset)."""
 
-    def __init__(self, ctx: Context, descs):
+    def __init__(self, ctx: Context, descs, keypoints=None):
         self.ctx = ctx
         self._h = C.c_void_p()
         dim = descs[0].shape[1]
@@ -400,9 +405,22 @@ class DescSet:
             d = A.as_c(d, np.float32)
             ctx.check(lib().msfm_descset_upload(self._h, i, A.ptr(d, A.c_float_p), len(d)))
         self.counts = [len(d) for d in descs]
+        if keypoints is not None:
+            for i, xy in enumerate(keypoints):
+                if xy is not None:
+                    self.upload_keypoints(i, xy)
+
+    def upload_keypoints(self, image, xy):
+        """msfm_descset_upload_keypoints: [count][2] float positions of the image's features (cv::Point2f)."""
+        xy = A.as_c(np.asarray(xy).reshape(-1, 2), np.float32)
+        self.ctx.check(lib().msfm_descset_upload_keypoints(self._h, image, A.ptr(xy, A.c_float_p), len(xy)))
 
     def match_pairs(self, pairs, ratio_good=0.6, ratio_all=0.85, keep_knn=False):
         return MatchResult(self, pairs, ratio_good, ratio_all, keep_knn)
+
+    def match_pairs_slam(self, pairs, F, H, keep_knn=False, **opts):
+        """msfm_match_pairs_slam (slam_gps.cc:455-503): ratio test `> th`, then the prior F / H gates; F, H [n_pairs][3][3]."""
+        return MatchResult(self, pairs, None, None, keep_knn, slam=(F, H, opts))
 
     def close(self):
         if self._h:
@@ -417,11 +435,26 @@ class DescSet:
 
 
 class MatchResult:
-    def __init__(self, ds: DescSet, pairs, ratio_good, ratio_all, keep_knn):
+    def __init__(self, ds: DescSet, pairs, ratio_good, ratio_all, keep_knn, slam=None):
         self.ds, self.ctx = ds, ds.ctx
         self.pairs = A.as_c(np.asarray(pairs).reshape(-1, 2), np.int32)
         self.keep_knn = keep_knn
         self._h = C.c_void_p()
+        if slam is not None:
+            F, H, kw = slam
+            F = A.as_c(np.asarray(F, dtype=np.float64).reshape(-1, 9), np.float64)
+            H = A.as_c(np.asarray(H, dtype=np.float64).reshape(-1, 9), np.float64)
+            if len(F) != len(self.pairs) or len(H) != len(self.pairs):
+                raise ValueError("one F and one H per pair")
+            o = A.SlamMatchOptions()
+            lib().msfm_slam_match_default_options(C.byref(o))
+            for k, v in kw.items():
+                if not hasattr(o, k):
+                    raise AttributeError(k)
+                setattr(o, k, v)
+            self.ctx.check(lib().msfm_match_pairs_slam(ds._h, A.ptr(self.pairs, A.c_int_p), len(self.pairs), A.ptr(F, A.c_double_p),
+                                                       A.ptr(H, A.c_double_p), C.byref(o), int(keep_knn), C.byref(self._h)))
+            return
         self.ctx.check(lib().msfm_match_pairs(ds._h, A.ptr(self.pairs, A.c_int_p), len(self.pairs), ratio_good,
                                               ratio_all, int(keep_knn), C.byref(self._h)))
 

@@ -1244,6 +1244,12 @@ static bool choose_dissection(const CamGraph& G, int tail_cols, int force_depth,
     if (T.leaves.size() < 2 || T.leaves.size() > 8 || T.seps.empty()) continue;
     bool ok = true;
     for (size_t d = 1; d < T.seps.size(); d++) ok = ok && T.seps[d].size() <= 8;
+    // everything behind the leaves (padded separators, root, intrinsics, rhs row) is the square of the deferred corner
+    // update, whose per-block panel ranges travel as a kernel argument of MSFM_CORNER_MAX_BLOCKS entries (chol.hip)
+    long behind = 6 * (long)T.seps[0][0].cams.size() + tail_cols;
+    for (size_t d = 1; d < T.seps.size(); d++)
+      for (auto& q : T.seps[d]) behind += 64 * cdiv(6 * (long)q.cams.size(), 64);
+    if (cdiv(behind, 64) > MSFM_CORNER_MAX_BLOCKS) ok = false;
     if (!ok) continue;
     long chain = 0, maxp = 0;
     for (auto& l : T.leaves) maxp = std::max<long>(maxp, cdiv(6 * (long)l.cams.size(), 64));
@@ -1381,6 +1387,7 @@ MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
   msfm_ctx* ctx = ba->ctx;
   (void)hipSetDevice(ctx->device);   // the caller's thread may have another device current (Python __del__ after set_device)
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);   // the pair kernels read T / Tm and write the partials freed below
   if (ba->h_scal) (void)hipHostFree(ba->h_scal);
   if (ba->ev_scal) (void)hipEventDestroy(ba->ev_scal);
   if (ba->h_fail) (void)hipHostFree(ba->h_fail);
@@ -2689,6 +2696,13 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     launch_pairs(ctx->stream2);
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   }
+  // Every way out of this function from here on - the error returns of the collective hook and of HIP_TRY included - must
+  // leave the second stream joined: whoever synchronises ctx->stream afterwards (msfm_ba_destroy, the pool) then also
+  // waits for the pair kernels that read T / Tm and write the partials.
+  struct JoinGuard {
+    msfm_ctx* c; hipStream_t s; bool armed;
+    ~JoinGuard() { if (armed && hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(c->stream2); }
+  } join{ctx, s, forked};
   double* gmax_c = ba->gmax_buf.p + ba->nblk_pt;
   double* gmax_m = gmax_c + 6 * (size_t)ncb;
   {
@@ -2727,7 +2741,9 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     hipLaunchKernelGGL(k_reduce, dim3(rj.count), dim3(1024), 0, s, rj, ba->swrite);
   }
   if (forked) {
-    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    join.armed = false;
+    const hipError_t je = hipStreamWaitEvent(s, ctx->ev_join, 0);
+    if (je != hipSuccess) { (void)hipStreamSynchronize(ctx->stream2); HIP_TRY(ctx, je); }
   } else {
     KTimer t(ctx, "ba_schur_pairs");
     launch_pairs(s);
@@ -2815,13 +2831,11 @@ static int read_scalars(msfm_ba* ba) {
   // loop so that a collective never completes, must surface as an error code, not as a host thread spinning forever.
   static const double limit_s = [] { const char* e = getenv("MSFM_SYNC_TIMEOUT_S"); const double v = e ? atof(e) : 120.0; return v > 0 ? v : 120.0; }();
   hipError_t q;
-  unsigned spins = 0;
-  std::chrono::steady_clock::time_point t0;
+  unsigned long long spins = 0;
+  const auto t0 = std::chrono::steady_clock::now();   // taken once: the deadline never re-arms, whatever the poll count does
   while ((q = hipEventQuery(ba->ev_scal)) == hipErrorNotReady) {
-    if ((++spins & 0xFFFu) == 0) {   // look at the clock every 4096 polls only
-      const auto now = std::chrono::steady_clock::now();
-      if (spins == 0x1000u) t0 = now;
-      else if (std::chrono::duration<double>(now - t0).count() > limit_s)
+    if ((++spins & 0xFFFull) == 0) {   // look at the clock every 4096 polls only
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
         return msfm_set_error(ctx, MSFM_E_DEVICE, "device did not finish an LM iteration within %.0f s (MSFM_SYNC_TIMEOUT_S)", limit_s);
     }
   }

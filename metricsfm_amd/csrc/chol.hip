@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
 // grid = lower 64x64 tiles of the separator square x nsplit; the next panel's tiles are fetched during the MFMAs.
 // Only panels of leaves / nodes under BOTH blocks' tree nodes contribute (everything else is structurally zero):
 // blk_plo / blk_phi give, per 64-row block of the square, the panel range of the level that lies under its node.
-struct CornerRanges { short plo[128], phi[128]; };
+struct CornerRanges { short plo[MSFM_CORNER_MAX_BLOCKS], phi[MSFM_CORNER_MAX_BLOCKS]; };
 __global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ M, int ld, int b0, int nsplit,
                                                       double* __restrict__ corners, int ldc, CornerRanges R) {
   __shared__ double sm[2 * 64 * LDT];
@@ -938,6 +938,14 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   const int n_levels = plan ? plan->n_levels : 0;
   if (n_levels > 0) {
     if (n_levels > 3 || !plan->corners) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan");
+    // every level is checked before the first launch: a refusal must not leave half a factorisation behind
+    for (int lv = 0; lv < n_levels; lv++) {
+      const msfm_chol_level& L = plan->level[lv];
+      if (L.K < 1 || L.K > 8 || L.b0 % NB || L.begin % NB || plan->ldc < 64 * cdiv(nrows - L.b0, 64))
+        return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan level");
+      if (cdiv(nrows - L.b0, 64) > MSFM_CORNER_MAX_BLOCKS)
+        return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: separator part too large for the corner update (%d blocks)", cdiv(nrows - L.b0, 64));
+    }
     for (int lv = 0; lv < n_levels; lv++) {
       // ---- the K chains of this level, step by step: step l of node k factors its block l (after applying its panel
       //      l-1); the step after a node's last block only applies that last panel to the rows from b0 on ----
@@ -995,7 +1003,8 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
         KTimer t(ctx, "chol_corner_syrk");
         t.count = 2;
         const int nB64 = cdiv(nrows - sb, 64), ntile = nB64 * (nB64 + 1) / 2;
-        if (nB64 > 128) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: separator part too large for the corner update (%d blocks)", nB64);
+        if (nB64 > MSFM_CORNER_MAX_BLOCKS)   // (choose_dissection never picks such a tree: checked before anything is launched)
+          return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: separator part too large for the corner update (%d blocks)", nB64);
         // per 64-row block of the square: the panels of this level under the block's tree node (the root: all of them)
         CornerRanges R;
         for (int I = 0; I < nB64; I++) {

@@ -160,6 +160,7 @@ static inline void par_ranges(size_t n, int nt, F&& fn, size_t grain = 4096) {  
 // dense chain.  n_levels = 0: plain dense order.  A node's descendants in a lower level are the nodes whose leaf interval
 // lies inside its own (tree order inside every level makes them contiguous).
 // corners: scratch for the deferred separator x separator updates, `nsplit` buffers of ldc x ldc doubles.
+#define MSFM_CORNER_MAX_BLOCKS 128   // 64-column blocks behind the leaf level that k_corner_syrk's range table holds
 struct msfm_chol_node { int begin, end, leaf_lo, leaf_hi; };
 struct msfm_chol_level { int K = 0; msfm_chol_node node[8]; int begin = 0, b0 = 0; };
 struct msfm_chol_plan {

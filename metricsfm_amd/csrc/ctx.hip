@@ -171,9 +171,10 @@ MSFM_API void msfm_ctx_destroy(msfm_ctx* ctx) {
   if (ctx->ba_scratch && ctx->ba_scratch_free) ctx->ba_scratch_free(ctx->ba_scratch);
   for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);   // before its events go
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

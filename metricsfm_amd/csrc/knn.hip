@@ -3,14 +3,15 @@
 // (SfM/src/graph/fine_matching_graph.cc:72-81,99; SfM/src/slam_gps.cc:438-447,463) and fuses
 // the ratio tests of fine_matching_graph.cc:116-133.
 //
-// Fast path (descriptors integer-valued in [0,255], e.g. SIFT bytes stored as float):
-//   d(a,b) = |a|^2 + |b|^2 - 2 a.b is evaluated as a bf16 MFMA GEMM with fp32 accumulators;
-//   every operand (<= 255, and -2*b <= 510) is exact in bf16 and every partial sum is an
-//   integer below 2^24, so the distances are exact and the indices identical to a binary64
-//   brute force.  One workgroup = 4 waves = 128 query descriptors of one image pair; each
-//   wave keeps its 32 queries as MFMA B fragments in registers for the whole sweep, train
-//   descriptors stream through an XOR-swizzled LDS tile shared by the 4 waves; the running
-//   top-2 per query lives in packed (distance << 8 | row) keys, 4 VALU ops per candidate.
+// Fast path (descriptors integer-valued in [0,255], e.g. SIFT bytes stored as float): k_knn2_i8.
+//   |a-b|^2 = 2 sum (a-128)(127-b) + alpha(a) + beta(b) is evaluated as an int8 MFMA GEMM
+//   (v_mfma_i32_32x32x32_i8, int32 accumulators): operands a-128 and 127-b fit int8 exactly and every sum is an
+//   exact integer, so the distances are exact and the indices identical to a binary64 brute force.  One workgroup
+//   = 4 waves = 256 query descriptors of one image pair; each wave keeps its 64 queries as MFMA B fragments in
+//   registers for the whole sweep, train descriptors stream through a double-buffered XOR-swizzled LDS tile shared
+//   by the 4 waves; the running top-2 per query lives in packed keys (m << 9 | parity << 8 | row), 3 VALU operations
+//   per candidate (lshl_or, min, med3).  MSFM_KNN_BF16=1 selects the older bf16 kernel (128 queries per workgroup,
+//   fp32 accumulators, 4 VALU operations per candidate) for comparison.
 // General path (any float32 descriptors): one f16 MFMA product per term with a rigorous error bound, the four
 //   smallest approximate distances per half-wave lane, exact binary64 re-evaluation of the plausible candidates and a
 //   certificate that nothing outside the lists can win; the rare uncertified query is redone by exact brute force.
@@ -33,9 +34,13 @@ typedef unsigned int u32;
 #define QPB 256        // queries per workgroup (4 waves x 64)
 #define NORM_BIAS 8388608.0f  // 2^23: keeps a2 - 2ab positive for the integer key
 
+struct msfm_match_result;
+static void orphan_result(msfm_match_result* R);
 struct msfm_descset {
   msfm_ctx* ctx;
   int n_images, dim;
+  std::vector<msfm_match_result*> results;   // live results of this set: orphaned (set = nullptr) when the set is destroyed first
+  std::vector<DevBuf<float>*> kp;            // [count][2] keypoint positions (msfm_descset_upload_keypoints), nullptr: none
   std::vector<int> count;
   std::vector<DevBuf<float>*> f32;       // [count][dim]
   std::vector<DevBuf<unsigned short>*> bf16;  // [count][dim], train copy (plain) — query copy is scaled by -2 on load
@@ -117,8 +122,16 @@ __device__ __forceinline__ u32 umed3(u32 a, u32 b, u32 c) {
 
 // The two ratio tests of fine_matching_graph.cc:116-130, evaluated independently of each other as the reference does
 // (a match can be "good" without being in the "all" set when ratio_good > ratio_all).  -1: in neither set.
+// ratio_good < 0 selects the SLAM form (slam_gps.cc:469-477): `if (ratio > th) continue;` with th = ratio_all - a ratio EQUAL
+// to the threshold and a NaN ratio (0 / 0: two exact duplicates of the query) are kept, unlike `ratio < th` above.  The code is
+// then the bare train index, n_good counts the survivors of this test and n_all is left to the prior F / H gates (k_slam_gate).
 __device__ __forceinline__ int32_t ratio_code(float d0, float d1, int id0, float ratio_good, float ratio_all, int* n_all, int* n_good) {
-  const float ratio = d0 / d1;  // fine_matching_graph.cc:118
+  const float ratio = d0 / d1;  // fine_matching_graph.cc:118, slam_gps.cc:470
+  if (ratio_good < 0.f) {
+    if (ratio > ratio_all) return -1;
+    atomicAdd(n_good, 1);
+    return id0;
+  }
   const bool good = ratio < ratio_good, all = ratio < ratio_all;
   if (good) atomicAdd(n_good, 1);
   if (all) atomicAdd(n_all, 1);
@@ -948,8 +961,8 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   msfm_descset* s = new msfm_descset();
   s->ctx = ctx; s->n_images = n_images; s->dim = dim;
-  ctx->children++;
   s->count.assign(n_images, 0);
+  s->kp.assign(n_images, nullptr);
   s->f32.assign(n_images, nullptr); s->bf16.assign(n_images, nullptr); s->norm.assign(n_images, nullptr);
   s->th16.assign(n_images, nullptr); s->qh16.assign(n_images, nullptr); s->n2s.assign(n_images, nullptr); s->n2s_max.assign(n_images, 0.f);
   s->rerr.assign(n_images, nullptr); s->rerr_max.assign(n_images, 0.f);
@@ -960,6 +973,7 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
     delete s;
     return msfm_set_error(ctx, MSFM_E_NOMEM, "descset alloc");
   }
+  ctx->children++;   // only a set that exists counts: a failed create must not keep the context alive for good
   *out = s;
   return MSFM_OK;
 }
@@ -969,6 +983,8 @@ MSFM_API void msfm_descset_destroy(msfm_descset* s) {
   msfm_ctx* ctx = s->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (msfm_match_result* r : s->results) orphan_result(r);   // their codes / counts stay readable, a rerun is refused
+  for (auto p : s->kp) delete p;
   for (auto p : s->f32) delete p;
   for (auto p : s->bf16) delete p;
   for (auto p : s->norm) delete p;
@@ -999,6 +1015,7 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
   // after their stream has drained (common.h)
   HIP_TRY(ctx, hipStreamSynchronize(st));
   s->generation++;
+  delete s->kp[image]; s->kp[image] = nullptr;   // positions belong to the features they were uploaded with
   delete s->f32[image]; delete s->bf16[image]; delete s->norm[image];
   delete s->th16[image]; delete s->qh16[image]; delete s->n2s[image]; delete s->rerr[image];
   s->th16[image] = new DevBuf<unsigned short>(); s->qh16[image] = new DevBuf<unsigned short>(); s->n2s[image] = new DevBuf<float>();
@@ -1069,6 +1086,45 @@ static int ensure_f16_forms(msfm_descset* s) {
   return MSFM_OK;
 }
 
+// The two prior-geometry gates of SLAMGPS::FeatureMatching (slam_gps.cc:478-499) on the survivors of the ratio test.  One
+// thread per query feature; binary64 arithmetic in the reference's order (cv::Mat products = sums from k = 0 without
+// contraction, so every product and sum is rounded on its own).  A rejected match gets code -1, a kept one counts in n_all.
+struct SlamGateTask {
+  const float* kp1;   // train image (id1) positions [.][2]
+  const float* kp2;   // query image (id2) positions
+  int nq, off;
+  double F[9], H[9];  // row-major, Fs[i][j] / Hs[i][j]
+};
+__global__ __launch_bounds__(256) void k_slam_gate(const SlamGateTask* __restrict__ tasks, double th_epipolar, double th_homography,
+                                                    int32_t* __restrict__ code, int* __restrict__ n_all) {
+  const SlamGateTask& t = tasks[blockIdx.y];
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= t.nq) return;
+  const int32_t c = code[t.off + m];
+  if (c < 0) return;
+  const int i0 = c & MSFM_MATCH_ID_MASK;
+  const double x1 = (double)t.kp1[2 * i0], y1 = (double)t.kp1[2 * i0 + 1];
+  const double x2 = (double)t.kp2[2 * m], y2 = (double)t.kp2[2 * m + 1];
+  auto row = [&](const double* A, int r) {   // (A pt1)_r with pt1 = (x1, y1, 1): cv::gemm's inner loop, k = 0, 1, 2
+    return __dadd_rn(__dadd_rn(__dmul_rn(A[3 * r], x1), __dmul_rn(A[3 * r + 1], y1)), __dmul_rn(A[3 * r + 2], 1.0));
+  };
+  // check2 (slam_gps.cc:478-488): distance of pt2 to the epipolar line F pt1
+  const double l0 = row(t.F, 0), l1 = row(t.F, 1), l2 = row(t.F, 2);
+  const double dot = __dadd_rn(__dadd_rn(__dmul_rn(l0, x2), __dmul_rn(l1, y2)), __dmul_rn(l2, 1.0));
+  const double epi = __ddiv_rn(fabs(dot), __dsqrt_rn(__dadd_rn(__dmul_rn(l0, l0), __dmul_rn(l1, l1))));
+  bool keep = !(epi > th_epipolar);
+  if (keep) {
+    // check3 (slam_gps.cc:490-499): transfer distance under the prior homography
+    const double h0 = row(t.H, 0), h1 = row(t.H, 1), h2 = row(t.H, 2);
+    const double sc = __ddiv_rn(1.0, h2);
+    const double dx = __dadd_rn(x2, -__dmul_rn(h0, sc)), dy = __dadd_rn(y2, -__dmul_rn(h1, sc));
+    const double hd = __dsqrt_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+    keep = !(hd > th_homography);
+  }
+  if (keep) atomicAdd(&n_all[blockIdx.y], 1);
+  else code[t.off + m] = -1;
+}
+
 struct msfm_match_result {
   msfm_descset* set;
   msfm_ctx* ctx = nullptr;   // kept separately: the descriptor set may be destroyed before its results
@@ -1091,11 +1147,21 @@ struct msfm_match_result {
   int n_tiles = 0;
   bool exact_path = false;
   unsigned long generation = 0;   // of the descriptor set when the task tables were built
+  // SLAM form (msfm_match_pairs_slam): prior F / H gates behind the ratio test
+  bool slam = false;
+  DevBuf<SlamGateTask> gate_tasks;
+  int gate_max_nq = 0;
+  double th_epipolar = 0, th_homography = 0;
 };
 
+// The set is going away before one of its results: the result keeps what it owns (codes, counts, 2-NN arrays) and its
+// context; everything that would read the set's descriptors (rerun, the slow-path kernels) is refused from now on.
+static void orphan_result(msfm_match_result* R) { R->set = nullptr; }
+
 static int check_generation(const msfm_match_result* R) {
+  if (!R->set) return msfm_set_error(R->ctx, MSFM_E_INVAL, "the descriptor set of this match result has been destroyed");
   if (R->generation != R->set->generation)
-    return msfm_set_error(R->set->ctx, MSFM_E_INVAL, "an image of the descriptor set was uploaded again after this match result was created; "
+    return msfm_set_error(R->ctx, MSFM_E_INVAL, "an image of the descriptor set was uploaded again after this match result was created; "
                                                      "create a new result with msfm_match_pairs");
   return MSFM_OK;
 }
@@ -1138,12 +1204,18 @@ static int launch_match(msfm_match_result* R) {
                        R->ratio_all, R->code.p, R->keep_knn ? R->ids.p : (int*)nullptr, R->keep_knn ? R->sqd.p : (float*)nullptr,
                        R->n_all.p, R->n_good.p);
   }
+  if (R->slam && R->gate_max_nq > 0) {
+    KTimer t(ctx, "slam_prior_gates");
+    hipLaunchKernelGGL(k_slam_gate, dim3(cdiv(R->gate_max_nq, 256), R->n_pairs), dim3(256), 0, st, R->gate_tasks.p, R->th_epipolar,
+                       R->th_homography, R->code.p, R->n_all.p);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return MSFM_OK;
 }
 
-MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, float ratio_good, float ratio_all, int keep_knn,
-                              msfm_match_result** out) {
+// slam != nullptr: the SLAM form - ratio test `> th` (ratio_good < 0 marks it for the kernels), then the prior F / H gates.
+static int match_pairs_impl(msfm_descset* s, const int* pairs, int n_pairs, float ratio_good, float ratio_all, int keep_knn,
+                            const msfm_slam_match_options* slam, const double* Fs, const double* Hs, msfm_match_result** out) {
   if (!s || !out || n_pairs < 0 || (n_pairs > 0 && !pairs)) return MSFM_E_INVAL;
   msfm_ctx* ctx = s->ctx;
   *out = nullptr;
@@ -1152,6 +1224,8 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
     const int a = pairs[2 * p], b = pairs[2 * p + 1];
     if (a < 0 || a >= s->n_images || b < 0 || b >= s->n_images) return msfm_set_error(ctx, MSFM_E_INVAL, "pair %d: image index out of range", p);
     if (s->count[a] < 2) return msfm_set_error(ctx, MSFM_E_INVAL, "pair %d: train image %d has %d < 2 descriptors", p, a, s->count[a]);
+    if (slam && (!s->kp[a] || (s->count[b] > 0 && !s->kp[b])))
+      return msfm_set_error(ctx, MSFM_E_INVAL, "pair %d: the prior F / H gates need the keypoints of both images (msfm_descset_upload_keypoints)", p);
   }
   msfm_match_result* R = new msfm_match_result();
   struct Guard { msfm_match_result* p; msfm_ctx* c; ~Guard() { if (p) { delete p; msfm_ctx_child_released(c); } } } guard{R, ctx};
@@ -1221,15 +1295,65 @@ MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, fl
   HIP_TRY(ctx, R->n_all.alloc(std::max(1, n_pairs))); HIP_TRY(ctx, R->n_good.alloc(std::max(1, n_pairs)));
   HIP_TRY(ctx, R->tile_first.from(tile_first, st));
   if (n_pairs) { HIP_TRY(ctx, R->tasks.from(tasks, st)); HIP_TRY(ctx, R->tasksf.from(tasksf, st)); HIP_TRY(ctx, R->tasks8.from(tasks8, st)); }
+  if (slam) {
+    std::vector<SlamGateTask> gt(n_pairs);
+    for (int p = 0; p < n_pairs; p++) {
+      const int a = pairs[2 * p], b = pairs[2 * p + 1];
+      gt[p].kp1 = s->kp[a]->p; gt[p].kp2 = R->nq[p] ? s->kp[b]->p : nullptr; gt[p].nq = R->nq[p]; gt[p].off = R->out_off[p];
+      for (int k = 0; k < 9; k++) { gt[p].F[k] = Fs[9 * (size_t)p + k]; gt[p].H[k] = Hs[9 * (size_t)p + k]; }
+      R->gate_max_nq = std::max(R->gate_max_nq, R->nq[p]);
+    }
+    R->slam = true;
+    // the reference compares binary64 distances with float thresholds: th_epipolar, and `40 * th_distance` formed in float
+    R->th_epipolar = (double)slam->th_epipolar;
+    R->th_homography = (double)(40.0f * slam->th_distance);
+    if (n_pairs) HIP_TRY(ctx, R->gate_tasks.from(gt, st));
+  }
   HIP_TRY(ctx, hipStreamSynchronize(st));
   MSFM_TRY(launch_match(R));
   guard.p = nullptr;
+  s->results.push_back(R);
   *out = R;
   return MSFM_OK;
 }
 
+MSFM_API int msfm_match_pairs(msfm_descset* s, const int* pairs, int n_pairs, float ratio_good, float ratio_all, int keep_knn,
+                              msfm_match_result** out) {
+  if (s && !(ratio_good >= 0.f)) return msfm_set_error(s->ctx, MSFM_E_INVAL, "ratio_good must be >= 0 (got %g)", (double)ratio_good);
+  return match_pairs_impl(s, pairs, n_pairs, ratio_good, ratio_all, keep_knn, nullptr, nullptr, nullptr, out);
+}
+
+MSFM_API void msfm_slam_match_default_options(msfm_slam_match_options* o) {
+  if (!o) return;
+  o->th_first_second_ratio = 0.80f;   // slam_gps.cc:320
+  o->th_epipolar = 2.0f;              // 2.0 / resize_ratio, :316
+  o->th_distance = 5.0f;              // 5.0 / resize_ratio, :317
+}
+
+MSFM_API int msfm_match_pairs_slam(msfm_descset* s, const int* pairs, int n_pairs, const double* F, const double* H,
+                                   const msfm_slam_match_options* opt, int keep_knn, msfm_match_result** out) {
+  if (!s || !opt || (n_pairs > 0 && (!F || !H))) return MSFM_E_INVAL;
+  return match_pairs_impl(s, pairs, n_pairs, -1.0f, opt->th_first_second_ratio, keep_knn, opt, F, H, out);
+}
+
+MSFM_API int msfm_descset_upload_keypoints(msfm_descset* s, int image, const float* xy, int count) {
+  if (!s || image < 0 || image >= s->n_images || count < 0 || (count > 0 && !xy)) return MSFM_E_INVAL;
+  msfm_ctx* ctx = s->ctx;
+  if (count != s->count[image])
+    return msfm_set_error(ctx, MSFM_E_INVAL, "image %d has %d descriptors, %d keypoints given (upload the descriptors first)", image, s->count[image], count);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // a gate kernel may still be reading the old positions
+  delete s->kp[image];
+  s->kp[image] = new DevBuf<float>();
+  if (count == 0) return MSFM_OK;
+  HIP_TRY(ctx, s->kp[image]->alloc(2 * (size_t)count));
+  HIP_TRY(ctx, s->kp[image]->upload(xy, 2 * (size_t)count, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the caller's buffer is not retained
+  return MSFM_OK;
+}
+
 MSFM_API int msfm_match_pairs_rerun(msfm_descset* s, msfm_match_result* R) {
-  if (!s || !R || R->set != s) return MSFM_E_INVAL;
+  if (!s || !R || R->set != s) return MSFM_E_INVAL;   // (an orphaned result has set == nullptr)
   MSFM_TRY(check_generation(R));
   HIP_TRY(s->ctx, hipSetDevice(s->ctx->device));
   return launch_match(R);
@@ -1237,7 +1361,7 @@ MSFM_API int msfm_match_pairs_rerun(msfm_descset* s, msfm_match_result* R) {
 
 MSFM_API int msfm_match_result_counts(msfm_match_result* R, int* n_all, int* n_good) {
   if (!R) return MSFM_E_INVAL;
-  msfm_ctx* ctx = R->set->ctx;
+  msfm_ctx* ctx = R->ctx;   // (the counts live in the result itself: readable even after the set is gone)
   if (R->n_pairs == 0) return MSFM_OK;
   if (n_all) HIP_TRY(ctx, hipMemcpyAsync(n_all, R->n_all.p, sizeof(int) * R->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
   if (n_good) HIP_TRY(ctx, hipMemcpyAsync(n_good, R->n_good.p, sizeof(int) * R->n_pairs, hipMemcpyDeviceToHost, ctx->stream));
@@ -1247,8 +1371,8 @@ MSFM_API int msfm_match_result_counts(msfm_match_result* R, int* n_all, int* n_g
 
 MSFM_API int msfm_match_result_fetch(msfm_match_result* R, int pair, int32_t* code, int* ids, float* sqdists) {
   if (!R || pair < 0 || pair >= R->n_pairs) return MSFM_E_INVAL;
-  msfm_ctx* ctx = R->set->ctx;
-  MSFM_TRY(check_generation(R));
+  msfm_ctx* ctx = R->ctx;
+  if (R->set) MSFM_TRY(check_generation(R));   // an orphaned result (its set destroyed) still owns its codes and 2-NN arrays
   if ((ids || sqdists) && !R->keep_knn) return msfm_set_error(ctx, MSFM_E_INVAL, "result was created without keep_knn");
   const size_t o = R->out_off[pair], n = R->nq[pair];
   hipStream_t st = ctx->stream;
@@ -1262,7 +1386,7 @@ MSFM_API int msfm_match_result_fetch(msfm_match_result* R, int pair, int32_t* co
 
 MSFM_API int msfm_match_result_stats(msfm_match_result* R, int* n_queries, int* n_slow_path) {
   if (!R) return MSFM_E_INVAL;
-  msfm_ctx* ctx = R->set->ctx;
+  msfm_ctx* ctx = R->ctx;
   int nf = 0;
   if (R->n_flagged.p) {
     HIP_TRY(ctx, hipMemcpyAsync(&nf, R->n_flagged.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1278,6 +1402,10 @@ MSFM_API void msfm_match_result_destroy(msfm_match_result* R) {
   msfm_ctx* ctx = R->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (R->set) {
+    auto& v = R->set->results;
+    v.erase(std::remove(v.begin(), v.end(), R), v.end());
+  }
   delete R;
   msfm_ctx_child_released(ctx);
 }

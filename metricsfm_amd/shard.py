@@ -8,6 +8,8 @@
   counterpart (no collective anywhere in SfM/src).
 * Matching: ordered image pairs are independent (fine_matching_graph.cc:58,87): contiguous,
   cost-balanced slices of the idx1-major pair list, no collective.
+* Triangulation / reprojection: tracks are independent (structure.cc:211-355): contiguous ranges balanced by
+  observation count, cameras replicated, no collective.
 """
 import numpy as np
 
@@ -66,6 +68,35 @@ def shard_pairs(pairs: np.ndarray, rank: int, world: int, counts=None) -> np.nda
     lo = int(np.searchsorted(c, c[-1] * rank / world, side="left")) if rank else 0
     hi = int(np.searchsorted(c, c[-1] * (rank + 1) / world, side="left")) if rank + 1 < world else len(pairs)
     return pairs[lo:hi]
+
+
+def track_ranges(track_off: np.ndarray, world: int):
+    """Contiguous track ranges [lo, hi) per rank, balanced by observation count (triangulation /
+    reprojection are independent per track; the split is by point index range, cameras replicated, no collective)."""
+    track_off = np.asarray(track_off, dtype=np.int64)
+    n = len(track_off) - 1
+    total = int(track_off[-1] - track_off[0]) if n > 0 else 0
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(track_off[1:] - track_off[0], total * r / world, side="left")) if n else 0)
+    cuts.append(n)
+    for r in range(1, world + 1):
+        cuts[r] = min(n, max(cuts[r], cuts[r - 1]))
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def shard_tracks(tracks: A.TrackArrays, rank: int, world: int) -> A.TrackArrays:
+    """The tracks of `rank` for msfm_triangulate_*_batch / msfm_reproject_mse_batch: its contiguous track range with the
+    offsets rebased, every camera.  `.track_range` gives the range; the host concatenates X / mse / ok in rank order."""
+    if world == 1:
+        tracks.track_range = (0, len(tracks.track_off) - 1)
+        return tracks
+    lo, hi = track_ranges(tracks.track_off, world)[rank]
+    o0, o1 = int(tracks.track_off[lo]), int(tracks.track_off[hi])
+    out = A.TrackArrays(tracks.track_off[lo:hi + 1] - o0, tracks.track_cam[o0:o1], tracks.track_xy[o0:o1], tracks.cam_R, tracks.cam_t,
+                        tracks.cam_c, tracks.cam_fk)
+    out.track_range = (lo, hi)
+    return out
 
 
 class _DevPtr:

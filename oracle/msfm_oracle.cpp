@@ -1561,3 +1561,48 @@ ORC_API void orc_ratio_codes(const int* ids, const float* sqd, int n_query, floa
   }
   *n_all = na; *n_good = ng;
 }
+
+// SLAMGPS::FeatureMatching step 2 on one pair (slam_gps.cc:466-503): the three checks behind the 2-NN search, on the arrays
+// FLANN filled.  kp1 / kp2: positions of the features of id1 (train) / id2 (query) as cv::Point2f; F, H: the prior matrices
+// of the pair, row-major.  code[m] = ids[2m] for a match that passes all three checks, -1 otherwise; *n_ratio = survivors
+// of check1 (count - count1), *n_kept = matches[j].size() before the geo-verification (:509).
+// cv::Mat products of doubles are plain sums from k = 0 (every product and every sum rounded on its own, no contraction);
+// the thresholds are floats compared against binary64 distances (`40 * th_distance` is formed in float).
+ORC_API __attribute__((optimize("fp-contract=off"))) void orc_slam_gate(const int* ids, const float* sqd, int n_query, const float* kp1,
+                                                                      const float* kp2, const double* F, const double* H,
+                                                                      float th_first_second_ratio, float th_epipolar, float th_distance,
+                                                                      int32_t* code, int* n_ratio, int* n_kept) {
+  int nr = 0, nk = 0;
+  const float th_h = 40 * th_distance;   // slam_gps.cc:496
+  for (int m = 0; m < n_query; m++) {
+    code[m] = -1;
+    const float ratio = sqd[2 * (size_t)m] / sqd[2 * (size_t)m + 1];   // :467
+    if (ratio > th_first_second_ratio) continue;                        // check1 :470-473
+    nr++;
+    const int i0 = ids[2 * (size_t)m];
+    const double pt1[3] = {(double)kp1[2 * (size_t)i0], (double)kp1[2 * (size_t)i0 + 1], 1.0};   // :476-478
+    const double pt2[3] = {(double)kp2[2 * (size_t)m], (double)kp2[2 * (size_t)m + 1], 1.0};     // :479-481
+    double l2[3], pt22[3];
+    for (int r = 0; r < 3; r++) {                                       // cv::Mat l2 = Fs[i][j] * pt1  :482
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s = s + F[3 * r + k] * pt1[k];
+      l2[r] = s;
+    }
+    double dot = 0.0;
+    for (int k = 0; k < 3; k++) dot = dot + l2[k] * pt2[k];             // l2.dot(pt2)
+    const double epi_dis = std::fabs(dot) / std::sqrt(l2[0] * l2[0] + l2[1] * l2[1]);   // :483 (pow(x, 2) = x * x)
+    if (epi_dis > th_epipolar) continue;                                // check2 :484-487
+    for (int r = 0; r < 3; r++) {                                       // cv::Mat pt22 = Hs[i][j] * pt1  :490
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s = s + H[3 * r + k] * pt1[k];
+      pt22[r] = s;
+    }
+    const double sc = 1.0 / pt22[2];                                    // pt22 *= 1.0 / pt22(2)  :491
+    const double dx = pt2[0] - pt22[0] * sc, dy = pt2[1] - pt22[1] * sc;   // :492-493
+    const double homo_dis = std::sqrt(dx * dx + dy * dy);               // :494
+    if (homo_dis > th_h) continue;                                      // check3 :495-498
+    code[m] = i0;                                                       // matches[j].push_back({id0, m})  :503
+    nk++;
+  }
+  *n_ratio = nr; *n_kept = nk;
+}

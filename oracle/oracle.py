@@ -294,6 +294,23 @@ def ratio_codes(ids, sqd, ratio_good=0.6, ratio_all=0.85):
     return code, na.value, ng.value
 
 
+def slam_gate(ids, sqd, kp1, kp2, F, H, th_first_second_ratio=0.80, th_epipolar=2.0, th_distance=5.0):
+    """The three checks of SLAMGPS::FeatureMatching step 2 (slam_gps.cc:466-503) on one pair.  Returns code [n_query]
+    (train index or -1), the survivors of the ratio check and the number of matches kept."""
+    ids, sqd = np.ascontiguousarray(ids, dtype=np.int32), np.ascontiguousarray(sqd, dtype=np.float32)
+    kp1, kp2 = np.ascontiguousarray(kp1, dtype=np.float32), np.ascontiguousarray(kp2, dtype=np.float32)
+    F, H = np.ascontiguousarray(F, dtype=np.float64).reshape(9), np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+    code = np.zeros(len(ids), dtype=np.int32)
+    nr, nk = C.c_int32(), C.c_int32()
+    f = lib().orc_slam_gate
+    f.restype = None
+    f.argtypes = [A.c_int_p, A.c_float_p, C.c_int, A.c_float_p, A.c_float_p, A.c_double_p, A.c_double_p, C.c_float, C.c_float, C.c_float,
+                  A.c_int_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    f(A.ptr(ids, A.c_int_p), A.ptr(sqd, A.c_float_p), len(ids), A.ptr(kp1, A.c_float_p), A.ptr(kp2, A.c_float_p), A.ptr(F, A.c_double_p),
+      A.ptr(H, A.c_double_p), th_first_second_ratio, th_epipolar, th_distance, A.ptr(code, A.c_int_p), C.byref(nr), C.byref(nk))
+    return code, nr.value, nk.value
+
+
 def epnp_ransac(offsets, pts_w, pts_2d, f, max_iter=200, seed=0x4D53464D50):
     """AbsolutePoseEstimation::AbsolutePoseWithFocalLength (absolute_pose_estimation.cc:42-58) per image of a batch:
     EPNPRansac (absolute_pose_via_epnp.cc:103-139) + Error (:67-103).  Returns R [n,3,3], t [n,3], errors [total],

@@ -228,6 +228,39 @@ def test_ba_full_size_properties(ctx, monkeypatch):
     assert _rel(a0.cam_pose, a.cam_pose) < 1e-7 and _rel(a0.point, a.point) < 1e-7
 
 
+def test_ba_config3_full_size_trajectory_parity(ctx, oracle):
+    """The headline configuration itself (BASELINE config 3: 500 cameras / 200 000 points / 1.2 M observations) against the
+    OpenMP oracle on every core of the box - bit-identical to its 1-thread run (tests/test_oracle.py) - for 12 LM iterations:
+    same accept / reject sequence, costs within 1e-9, parameters within 1e-7 (north_star asks 1e-5)."""
+    sc = scene.config_scene(3)
+    # stopping rules off (negative tolerances never fire): the run would otherwise converge after 9 iterations
+    r, r_ref, _ = check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc),
+                               dict(max_num_iterations=12, num_threads=oracle.host_cores(), function_tolerance=-1.0, gradient_tolerance=-1.0,
+                                    parameter_tolerance=-1.0))
+    assert r["num_iterations"] == 12 and r["num_successful_steps"] >= 8
+    assert r["num_reduced_params"] == 3003 and r["num_residuals"] == 2 * sc.n_obs
+
+
+def test_ba_one_model_per_camera_beyond_the_corner_table(ctx):
+    """use_same_camera = false with thousands of cameras: 3 intrinsics columns per camera put more than 128 blocks behind
+    the leaf level, which the deferred corner update cannot address - the plan must fall back (dense order) when it is
+    chosen, not fail in the middle of the first factorisation."""
+    from metricsfm_amd import capi
+    sc = scene.make_aerial_scene(2750, 30000, seed=77, n_models=2750, rot_sigma=1e-3, trans_sigma=0.02, point_sigma=0.05)
+    ba = ctx.ba(A.BaArrays.from_scene(sc))
+    lay = ba.layout()
+    assert lay["reduced_order"] == 9 * 2750 and lay["n_domains"] <= 1 and lay["n_levels"] == 0
+    r = ba.run(capi.default_options(max_num_iterations=2))
+    ba.close()
+    assert r["num_iterations"] == 2 and r["num_successful_steps"] >= 1 and r["final_cost"] < r["initial_cost"]
+    # the same cameras sharing one CameraModel do get an elimination tree
+    sc1 = scene.make_aerial_scene(2750, 30000, seed=77)
+    ba = ctx.ba(A.BaArrays.from_scene(sc1))
+    lay1 = ba.layout()
+    ba.close()
+    assert lay1["n_domains"] >= 2 and lay1["n_levels"] >= 1
+
+
 def test_ba_domains_with_window_masks(ctx, oracle, monkeypatch):
     """Frozen cameras and frozen points (PartialBundleAdjustment masks, sfm_incremental.cc:917-1014) on a problem large enough
     for the camera-domain order: frozen cameras have no block, observations of frozen points only touch camera diagonals."""

@@ -225,10 +225,18 @@ def test_context_outlives_its_children(oracle):
     rng = np.random.default_rng(1)
     ds = c.descset([np.rint(rng.uniform(0, 255, (64, 128))).astype(np.float32) for _ in range(2)])
     res = ds.match_pairs(np.array([[0, 1]], np.int32))
+    ds2 = c.descset([np.rint(rng.uniform(0, 255, (64, 128))).astype(np.float32) for _ in range(2)])
     c.close()                       # children alive: the library keeps the context
     r = ba.run(capi.default_options(max_num_iterations=3))
     assert r["num_iterations"] == 3
-    ds.close()                      # the set goes before its result
+    na0, ng0 = res.counts()
+    code0, _, _ = res.fetch(0)
+    ds.close()                      # the set goes before its result: the result keeps what it owns ...
+    na1, ng1 = res.counts()
+    code1, _, _ = res.fetch(0)
+    assert (na0 == na1).all() and (ng0 == ng1).all() and (code0 == code1).all() and res.stats()["queries"] == 64
+    assert capi.lib().msfm_match_pairs_rerun(ds2._h, res._h) == A.MSFM_E_INVAL   # ... but cannot run again, with no set at all
+    ds2.close()
     res.close()
     ba.close()                      # last child: the context is released here
 
@@ -281,3 +289,122 @@ def test_float_path_vlfeat_scale_full_tiles(ctx, oracle):
     for p in range(len(pairs)):
         np.testing.assert_array_equal(res2.fetch(p)[0], res.fetch(p)[0])
     np.testing.assert_array_equal(res2.counts()[0], res.counts()[0])
+
+
+def _check_pairs_against_oracle(ctx, oracle, descs, pairs):
+    """ids, distances, ratio codes and the two counts of every pair in `pairs` identical to oracle.knn2 + ratio_codes."""
+    oracle.set_num_threads(oracle.host_cores())
+    try:
+        ds = ctx.descset(descs)
+        res = ds.match_pairs(pairs, 0.6, 0.85, keep_knn=True)
+        na, ng = res.counts()
+        stats = res.stats()
+        n_good = 0
+        for p, (i, j) in enumerate(pairs):
+            code, ids, d = res.fetch(p)
+            ids_r, d_r = oracle.knn2(descs[i], descs[j], fast=True)   # identical to the plain form on integer data (tests/test_oracle.py)
+            code_r, na_r, ng_r = oracle.ratio_codes(ids_r, d_r, 0.6, 0.85)
+            assert np.array_equal(ids, ids_r) and np.array_equal(d, d_r) and np.array_equal(code, code_r), (p, i, j)
+            assert (na[p], ng[p]) == (na_r, ng_r), (p, i, j)
+            n_good += ng_r
+        res.close()
+        ds.close()
+    finally:
+        oracle.set_num_threads(1)
+    return n_good, stats
+
+
+def test_config2_every_pair_matches_the_oracle(ctx, oracle):
+    """BASELINE config 2 in full: all 2 450 ordered pairs of its 50 images x 4096 features (initial_matching_graph.cc:55-63,
+    fine_matching_graph.cc:87-133) - 10 M queries, each compared with the CPU oracle (OpenMP over the queries)."""
+    sc = scene.add_features(scene.config_scene(2), 4096)
+    pairs = scene.all_pairs(sc.n_cams)
+    assert len(pairs) == 2450
+    n_good, stats = _check_pairs_against_oracle(ctx, oracle, sc.desc, pairs)
+    assert stats["slow_path"] == 0 and n_good > 50000
+
+
+def test_config3_pair_sample_matches_the_oracle(ctx, oracle):
+    """A seeded sample of 96 of config 3's 249 500 ordered pairs (500 images x 4096 features), matched as one batch the way
+    bench.py matches the whole list, against the oracle."""
+    sc = scene.config_scene(3)
+    rng = np.random.default_rng(0x4D53464D + 11)
+    all_pairs = scene.all_pairs(sc.n_cams)
+    pairs = all_pairs[np.sort(rng.choice(len(all_pairs), 96, replace=False))]
+    pairs = np.concatenate([pairs, [[0, 1], [1, 0], [498, 499], [499, 0]]]).astype(np.int32)   # neighbours on the flight line: real matches
+    images = sorted(set(pairs.ravel().tolist()))
+    scene.add_features(sc, 4096, images=images)
+    descs = [sc.desc[i] if sc.desc[i] is not None else np.zeros((0, 128), np.float32) for i in range(sc.n_cams)]
+    n_good, stats = _check_pairs_against_oracle(ctx, oracle, descs, pairs)
+    assert stats["slow_path"] == 0 and n_good > 100
+
+
+def _prior_F_H(sc, i, j):
+    """Prior matrices of an image pair from the scene's true geometry: F with x2^T F x1 = 0 on centred pixels and the
+    homography of the ground plane z = 0 - what slam_gps.cc:386-402 estimates from the shared points."""
+    K = lambda c: np.diag([sc.cam_model_gt[sc.cam_model_of_cam[c], 0]] * 2 + [1.0])
+    R1, R2 = scene.angle_axis_to_R(sc.cam_pose_gt[[i, j], :3])
+    t1, t2 = sc.cam_pose_gt[i, 3:], sc.cam_pose_gt[j, 3:]
+    R = R2 @ R1.T
+    t = t2 - R @ t1
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F = np.linalg.inv(K(j)).T @ tx @ R @ np.linalg.inv(K(i))
+    n = R1 @ np.array([0, 0, 1.0])          # plane z = 0 in camera-1 coordinates: n . X = d
+    d = n @ t1
+    H = K(j) @ (R + np.outer(t, n) / d) @ np.linalg.inv(K(i))
+    return F / np.abs(F).max(), H / H[2, 2]
+
+
+def test_match_pairs_slam_gates(ctx, oracle):
+    """msfm_match_pairs_slam = the matching loop of SLAMGPS::FeatureMatching step 2 (slam_gps.cc:455-503): the `>` ratio test
+    and the prior F / H gates, against the oracle on the 2-NN arrays of the same call - codes and both counts identical;
+    ragged image sizes, an empty query image, planted duplicates (0/0 ratios) and a rerun."""
+    from metricsfm_amd import capi
+    sc = scene.add_features(scene.make_aerial_scene(16, 2500, seed=41), 900, images=range(5))
+    descs = [d.copy() for d in sc.desc[:5]]
+    kps = [k.copy() for k in sc.kp_xy[:5]]
+    descs[3], kps[3] = descs[3][:401], kps[3][:401]
+    descs[4], kps[4] = descs[4][:0], kps[4][:0]
+    descs[1][7] = descs[1][5]                                  # two identical train rows ...
+    descs[0][11] = descs[1][5]                                 # ... and a query equal to both: d0 = d1 = 0, ratio NaN
+    pairs = np.array([(i, j) for i in range(4) for j in range(5) if i != j], dtype=np.int32)
+    FH = [_prior_F_H(sc, i, j) for i, j in pairs]
+    F, H = np.array([f for f, _ in FH]), np.array([h for _, h in FH])
+    ds = ctx.descset(descs, keypoints=kps)
+    res = ds.match_pairs_slam(pairs, F, H, keep_knn=True, th_epipolar=2.0, th_distance=5.0)
+    na, ng = res.counts()
+    kept_total = 0
+    for p, (i, j) in enumerate(pairs):
+        code, ids, d = res.fetch(p)
+        if len(descs[j]) == 0:
+            assert len(code) == 0 and na[p] == 0 and ng[p] == 0
+            continue
+        ids_r, d_r = oracle.knn2(descs[i], descs[j])
+        np.testing.assert_array_equal(ids, ids_r)
+        np.testing.assert_array_equal(d, d_r)
+        code_r, nr_r, nk_r = oracle.slam_gate(ids_r, d_r, kps[i], kps[j], F[p], H[p], 0.80, 2.0, 5.0)
+        np.testing.assert_array_equal(code, code_r)
+        assert (ng[p], na[p]) == (nr_r, nk_r), (p, i, j)
+        assert nk_r <= nr_r
+        kept_total += nk_r
+        if (i, j) == (1, 0):
+            assert d_r[11, 0] == 0 and d_r[11, 1] == 0 and ids_r[11].tolist() == [5, 7]   # the NaN ratio passed check1 (`>`)
+    assert kept_total > 200
+    # the survivors are true correspondences of the synthetic scene (the gates use the true geometry)
+    code, _, _ = res.fetch(0)
+    i, j = pairs[0]
+    ok = code >= 0
+    assert ok.sum() > 20 and (sc.feat_point[i][code[ok]] == sc.feat_point[j][np.nonzero(ok)[0]]).mean() > 0.9
+    # the plain ratio test of fine_matching_graph.cc (`<`) keeps fewer: it drops the 0/0 match and anything at equality
+    res.rerun()
+    na2, ng2 = res.counts()
+    np.testing.assert_array_equal(na, na2)
+    np.testing.assert_array_equal(ng, ng2)
+    res.close()
+    # without keypoints the gates cannot run
+    ds2 = ctx.descset(descs)
+    with pytest.raises(capi.MsfmError) as e:
+        ds2.match_pairs_slam(pairs, F, H)
+    assert e.value.code == A.MSFM_E_INVAL
+    ds2.close()
+    ds.close()

@@ -90,3 +90,21 @@ print("ok")
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver starts --gpus 1) spawns its two ranks as child
+    processes and prints rank 0's JSON line; here the ranks share the one GPU of the test box, hence gloo."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "2", "--steps", "4",
+                          "--warmup", "1", "--no-matching", "--no-cpu-baseline", "--verify-pairs", "64", "--pose-images", "32"],
+                         env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["value"] > 0 and r["roofline"]["frac"] > 0
+    assert r["triangulation"]["midpoint"]["tracks"] == 20000

@@ -328,3 +328,49 @@ def test_lm_masks_gps_huber_against_sparse_solver(oracle):
     np.testing.assert_array_equal(arr.cam_pose[cm == 0], sc.cam_pose[cm == 0])
     np.testing.assert_array_equal(arr.cam_model[1], sc.cam_model[1])
     assert np.abs(arr.cam_pose - p).max() < 1e-7 * np.abs(p).max() and np.abs(arr.point - X).max() < 1e-7 * np.abs(X).max()
+
+
+def test_slam_gate_known_answers(oracle):
+    """slam_gps.cc:466-503 on hand-made cases: `ratio > th` keeps equality and 0/0, the epipolar distance of a point to a
+    known line, the homography transfer distance at 40 x th_distance, the order of the three checks."""
+    O = oracle
+    F = np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])      # pure x-translation: l = (0, -1, y1) -> distance |y2 - y1|
+    H = np.eye(3)
+    kp1 = np.array([[10, 20], [30, 40], [50, 60], [70, 80], [1, 2], [3, 4]], np.float32)
+    kp2 = np.array([[300, 20.0], [30, 42.0], [50, 62.5], [70 + 199.0, 80], [1 + 201.0, 2], [3, 4]], np.float32)
+    ids = np.array([[0, 1], [1, 0], [2, 0], [3, 0], [4, 0], [5, 0]], np.int32)
+    d = np.array([[8, 10], [1, 2], [1, 2], [1, 2], [1, 2], [0, 0]], np.float32)
+    code, nr, nk = O.slam_gate(ids, d, kp1, kp2, F, H, 0.8, 2.0, 5.0)
+    # m0: ratio 0.8 == th kept by `>`, epi 0, homography distance 290 > 200 -> rejected by check3
+    # m1: epi 2.0 == th kept, transfer 2 -> kept;  m2: epi 2.5 > 2 rejected;  m3: transfer 199 kept;  m4: 201 rejected
+    # m5: 0/0 = NaN passes check1 (NaN > th is false), distances 0 -> kept
+    assert code.tolist() == [-1, 1, -1, 3, -1, 5] and (nr, nk) == (6, 3)
+    code, nr, nk = O.slam_gate(ids, d, kp1, kp2, F, H, 0.79, 2.0, 5.0)
+    assert nr == 5 and code[0] == -1                 # ratio 0.8 > 0.79
+    # a degenerate epipolar line (F = 0): 0 / 0 = NaN is not > th, the match falls through to the homography check
+    code, _, nk = O.slam_gate(ids, d, kp1, kp2, np.zeros((3, 3)), H, 0.8, 2.0, 5.0)
+    assert code.tolist() == [-1, 1, 2, 3, -1, 5]
+    # general F / H against a numpy evaluation in the same operation order
+    rng = np.random.default_rng(3)
+    F = np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]]) + 1e-7 * rng.normal(size=(3, 3))
+    H = np.eye(3) + 1e-5 * rng.normal(size=(3, 3))
+    kp1 = rng.uniform(-2000, 2000, (500, 2)).astype(np.float32)
+    kp2 = (kp1[::-1] + np.column_stack([rng.uniform(-300, 300, 500), rng.normal(0, 1.5, 500)])).astype(np.float32)
+    ids = np.column_stack([np.arange(500)[::-1], np.zeros(500)]).astype(np.int32)
+    d = np.column_stack([rng.uniform(0, 1, 500), np.ones(500)]).astype(np.float32)
+    code, nr, nk = O.slam_gate(ids, d, kp1, kp2, F, H, 0.8, 2.0, 5.0)
+    want = []
+    for m in range(500):
+        if np.float32(d[m, 0]) / np.float32(d[m, 1]) > np.float32(0.8):
+            want.append(-1); continue
+        p1 = np.array([kp1[ids[m, 0], 0], kp1[ids[m, 0], 1], 1.0], np.float64)
+        p2 = np.array([kp2[m, 0], kp2[m, 1], 1.0], np.float64)
+        l = [(F[r, 0] * p1[0] + F[r, 1] * p1[1]) + F[r, 2] * p1[2] for r in range(3)]
+        epi = abs((l[0] * p2[0] + l[1] * p2[1]) + l[2] * p2[2]) / np.sqrt(l[0] * l[0] + l[1] * l[1])
+        if epi > np.float32(2.0):
+            want.append(-1); continue
+        q = [(H[r, 0] * p1[0] + H[r, 1] * p1[1]) + H[r, 2] * p1[2] for r in range(3)]
+        sc = 1.0 / q[2]
+        dx, dy = p2[0] - q[0] * sc, p2[1] - q[1] * sc
+        want.append(-1 if np.sqrt(dx * dx + dy * dy) > np.float32(40) * np.float32(5.0) else int(ids[m, 0]))
+    assert code.tolist() == want and nk == sum(w >= 0 for w in want) and 0 < nk < nr

@@ -55,6 +55,29 @@ def test_pair_shards():
     assert max(w) < 2.0 * (sum(w) / 3)
 
 
+def test_track_shards():
+    sc = scene.make_aerial_scene(12, 900, seed=6)
+    R, t, c, fk = scene.cameras_for_tracks(sc)
+    tr = A.TrackArrays(sc.track_offsets(), sc.obs_cam, sc.obs_xy, R, t, c, fk)
+    for world in (1, 3, 8):
+        parts = [shard.shard_tracks(tr, r, world) for r in range(world)]
+        assert parts[0].track_range[0] == 0 and parts[-1].track_range[1] == sc.n_points
+        assert all(parts[r].track_range[1] == parts[r + 1].track_range[0] for r in range(world - 1))
+        assert (np.concatenate([p.track_cam for p in parts]) == tr.track_cam).all()
+        assert (np.concatenate([p.track_xy for p in parts]) == tr.track_xy).all()
+        for p in parts:
+            lo, hi = p.track_range
+            assert p.track_off[0] == 0 and (np.diff(p.track_off) == np.diff(tr.track_off[lo:hi + 1])).all()
+            assert p.struct.n_tracks == hi - lo and p.struct.n_cams == sc.n_cams
+        n = np.array([len(p.track_cam) for p in parts])
+        assert n.max() <= n.mean() + 12          # balanced to within one track
+    # degenerate: fewer tracks than ranks, and none at all
+    one = A.TrackArrays(np.array([0, 3], np.int32), sc.obs_cam[:3], sc.obs_xy[:3], R, t, c, fk)
+    assert sum(p.struct.n_tracks for p in (shard.shard_tracks(one, r, 4) for r in range(4))) == 1
+    none = A.TrackArrays(np.array([0], np.int32), sc.obs_cam[:0], sc.obs_xy[:0], R, t, c, fk)
+    assert all(shard.shard_tracks(none, r, 2).struct.n_tracks == 0 for r in range(2))
+
+
 def test_gloo_world2_reduced_system(tmp_path):
     """Two CPU ranks, each assembling the oracle's reduced system on its point shard; the gloo
     all-reduce of [S | rhs] equals the single-rank system (the identity the GPU path relies on)."""
