@@ -370,19 +370,29 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     double* const pub_lo = Ldiag + (size_t)(t0 / NB) * NB * NB;
     double* const pub_out = Dinv + (size_t)(t0 / NB) * 1024;
     const size_t r0 = (size_t)job_row16(jb, own ? rt : 0);
+    // The own rows are read and written as 32 contiguous bytes per lane (one row's 128 bytes across the four lanes lk of a
+    // row): a lane's four doubles of a 16-column block are the columns 4 lk + i, i.e. accumulator register i stands for row
+    // pl(4 i + lk) = 4 lk + i of the transposed tile instead of row 4 i + lk, and step s of a K = 64 product takes the panel
+    // column kc(s) = 16 (s >> 2) + 4 lk + (s & 3).  The permutations cost nothing: they only move the LDS addresses of the
+    // other operand (row pl(lr), column kc).  (Eight-byte accesses in the MFMA's natural order touch sixteen rows with 32
+    // bytes each per instruction: the load phase of a launch took 8.1 k cycles and the stores of the tail 4.3 k that way.)
+    const int plr = 4 * (lr & 3) + (lr >> 2);
     double preg[16];
     d4 T[4];
     if (own) {
       const double* src = M + (r0 + lr) * ld;
       if (upd) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) preg[s] = src[j0 + 4 * s + lk];
+        for (int q = 0; q < 4; q++) {
+          const d4 v = *reinterpret_cast<const d4*>(&src[j0 + 16 * q + 4 * lk]);
+#pragma unroll
+          for (int j = 0; j < 4; j++) preg[4 * q + j] = v[j];
+        }
       }
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) T[jb][i] = src[t0 + 16 * jb + lk + 4 * i];
+      for (int jb = 0; jb < 4; jb++) T[jb] = *reinterpret_cast<const d4*>(&src[t0 + 16 * jb + 4 * lk]);
     }
+#define MSFM_KC(s) (16 * ((s) >> 2) + 4 * lk + ((s) & 3))
     // tiles of the diagonal block this wave forms: (wave, 0) now, then (ta, 1) and (tb, tc):
     // wave 1: (1,1),(2,2)   wave 2: (2,1),(3,2)   wave 3: (3,1),(3,3)
     const int ta = wave, tb = wave == 1 ? 2 : 3, tc = wave == 3 ? 3 : 2;
@@ -405,7 +415,7 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     tile_st(Ls, ta, 1, lr, lk, D1);
     if (own && upd) {
 #pragma unroll
-      for (int s = 0; s < 16; s++) T[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[lr * LDT + 4 * s + lk], preg[s], T[0], 0, 0, 0);
+      for (int s = 0; s < 16; s++) T[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[plr * LDT + MSFM_KC(s)], preg[s], T[0], 0, 0, 0);
     }
     __syncthreads();
     // ---- A1: (h,1) -= L_h0 L_10^T ----
@@ -418,14 +428,14 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     if (own) {
       d4 Y = {0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[lr * DV + lk + 4 * s], T[0][s], Y, 0, 0, 0);
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[plr * DV + 4 * lk + s], T[0][s], Y, 0, 0, 0);
       X[0] = Y;
       if (upd) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(16 + lr) * LDT + 4 * s + lk], preg[s], T[1], 0, 0, 0);
+        for (int s = 0; s < 16; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(16 + plr) * LDT + MSFM_KC(s)], preg[s], T[1], 0, 0, 0);
       }
 #pragma unroll
-      for (int s = 0; s < 4; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(16 + lr) * LDT + lk + 4 * s], X[0][s], T[1], 0, 0, 0);
+      for (int s = 0; s < 4; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(16 + plr) * LDT + 4 * lk + s], X[0][s], T[1], 0, 0, 0);
     }
     if (b == 0) publish_subpanel(Ls, dinv, pub_lo, pub_out, 0, tid - 64, 192);
     __syncthreads();
@@ -437,16 +447,16 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     if (own) {
       d4 Y = {0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(16 + lr) * DV + lk + 4 * s], T[1][s], Y, 0, 0, 0);
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(16 + plr) * DV + 4 * lk + s], T[1][s], Y, 0, 0, 0);
       X[1] = Y;
       if (upd) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(32 + lr) * LDT + 4 * s + lk], preg[s], T[2], 0, 0, 0);
+        for (int s = 0; s < 16; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(32 + plr) * LDT + MSFM_KC(s)], preg[s], T[2], 0, 0, 0);
       }
 #pragma unroll
       for (int i2 = 0; i2 < 2; i2++)
 #pragma unroll
-        for (int s = 0; s < 4; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(32 + lr) * LDT + 16 * i2 + lk + 4 * s], X[i2][s], T[2], 0, 0, 0);
+        for (int s = 0; s < 4; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(32 + plr) * LDT + 16 * i2 + 4 * lk + s], X[i2][s], T[2], 0, 0, 0);
     }
     if (b == 0) publish_subpanel(Ls, dinv, pub_lo, pub_out, 1, tid - 64, 192);
     __syncthreads();
@@ -457,16 +467,16 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     if (own) {
       d4 Y = {0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(32 + lr) * DV + lk + 4 * s], T[2][s], Y, 0, 0, 0);
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(32 + plr) * DV + 4 * lk + s], T[2][s], Y, 0, 0, 0);
       X[2] = Y;
       if (upd) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(48 + lr) * LDT + 4 * s + lk], preg[s], T[3], 0, 0, 0);
+        for (int s = 0; s < 16; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(48 + plr) * LDT + MSFM_KC(s)], preg[s], T[3], 0, 0, 0);
       }
 #pragma unroll
       for (int i2 = 0; i2 < 3; i2++)
 #pragma unroll
-        for (int s = 0; s < 4; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(48 + lr) * LDT + 16 * i2 + lk + 4 * s], X[i2][s], T[3], 0, 0, 0);
+        for (int s = 0; s < 4; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(48 + plr) * LDT + 16 * i2 + 4 * lk + s], X[i2][s], T[3], 0, 0, 0);
     }
     if (b == 0) publish_subpanel(Ls, dinv, pub_lo, pub_out, 2, tid - 64, 192);
     __syncthreads();
@@ -474,14 +484,13 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     if (own) {
       d4 Y = {0, 0, 0, 0};
 #pragma unroll
-      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(48 + lr) * DV + lk + 4 * s], T[3][s], Y, 0, 0, 0);
+      for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(48 + plr) * DV + 4 * lk + s], T[3][s], Y, 0, 0, 0);
       X[3] = Y;
       double* dst = M + (r0 + lr) * ld + t0;
 #pragma unroll
-      for (int jb = 0; jb < 4; jb++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) dst[16 * jb + lk + 4 * i] = X[jb][i];
+      for (int jb = 0; jb < 4; jb++) *reinterpret_cast<d4*>(&dst[16 * jb + 4 * lk]) = X[jb];
     }
+#undef MSFM_KC
   }
   if (b == 0) {
     // the last sub-panel of the diagonal block's factor (the helper waves wrote the other three during the launch)

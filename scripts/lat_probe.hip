@@ -142,9 +142,9 @@ __global__ void k_lat(double* out, long long* cyc, double seed) {
   // 12: independent v_fma_f64 with three distinct VGPR-pair sources (the shape of the potrf dot-product terms)
   {
     double b[8], c[8];
+    TICK(t0);
 #pragma unroll
     for (int k = 0; k < 8; k++) { a[k] = x + k; b[k] = y + 0.5 * k; c[k] = x - k; }
-    TICK(t0);
 #pragma unroll
     for (int i = 0; i < N / 8; i++)
 #pragma unroll
@@ -155,14 +155,30 @@ __global__ void k_lat(double* out, long long* cyc, double seed) {
     slot++;
     // 13: the same with the multiplier in an SGPR pair (uniform value)
     const double us = readlane_f64(y, 3);
-#pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = x - k;
     TICK(t0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { c[k] = x - k; a[k] = x + k; }
 #pragma unroll
     for (int i = 0; i < N / 8; i++)
 #pragma unroll
       for (int k = 0; k < 8; k++) c[k] = fma(a[k], us, c[k]);
     x = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    TICK(t1);
+    if (lane == 0) cyc[slot] = t1 - t0;
+    slot++;
+  }
+  // 13b: independent fmac with one shared VGPR-pair multiplier: c[k] = fma(ns, w[k], c[k])
+  {
+    double w8[8], c8[8];
+    TICK(t0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { w8[k] = y + 0.25 * k; c8[k] = x - k; }
+    const double ns = x * 1e-3;
+#pragma unroll
+    for (int i = 0; i < N / 8; i++)
+#pragma unroll
+      for (int k = 0; k < 8; k++) c8[k] = fma(ns, w8[(k + i) & 7], c8[k]);
+    x = ((c8[0] + c8[1]) + (c8[2] + c8[3])) + ((c8[4] + c8[5]) + (c8[6] + c8[7]));
     TICK(t1);
     if (lane == 0) cyc[slot] = t1 - t0;
     slot++;
@@ -262,10 +278,10 @@ int main() {
   hipMemcpy(ho, out, sizeof ho, hipMemcpyDeviceToHost);
   const char* names[] = {"dep v_fma_f64", "indep v_fma_f64 (8 chains)", "dep v_mul_f64", "dep v_rcp_f64", "indep v_rcp_f64 (8)", "dep cvt+rcp_f32+cvt",
                          "readlane x2 -> fma", "ds_write + bcast ds_read", "dep v_rsq_f64 + add", "dpp mov x2 + add", "dep mfma f64 16x16x4", "indep mfma f64 (4 acc)",
-                         "indep fma, 3 VGPR pairs", "indep fma, SGPR multiplier", "indep readlane pair (+adds)", "bcast ds_read_b128 (+2 adds)", "ds_bpermute x2 + add", "permlane32_swap x2 + add"};
-  const int cnt[] = {N, N, N, N, N, N, N, N, N, N, N / 4, N / 4, N, N, N, N, N, N};
+                         "indep fma, 3 VGPR pairs", "indep fma, SGPR multiplier", "indep fmac, shared multiplier", "indep readlane pair (+adds)", "bcast ds_read_b128 (+2 adds)", "ds_bpermute x2 + add", "permlane32_swap x2 + add"};
+  const int cnt[] = {N, N, N, N, N, N, N, N, N, N, N / 4, N / 4, N, N, N, N, N, N, N};
   long long tot = 0;
-  for (int i = 0; i < 18; i++) { printf("%-28s %8.1f cycles each\n", names[i], (double)h[i] / cnt[i]); tot += h[i]; }
+  for (int i = 0; i < 19; i++) { printf("%-28s %8.1f cycles each\n", names[i], (double)h[i] / cnt[i]); tot += h[i]; }
   printf("kernel %.3f ms for %lld counted cycles -> counter runs at >= %.0f MHz\n", ms, tot, tot / (ms * 1e3));
   double emax = 0, e2max = 0;
   for (int l = 0; l < 64; l++) { emax = fmax(emax, fabs(ho[64 + l])); e2max = fmax(e2max, fabs(ho[128 + l])); }

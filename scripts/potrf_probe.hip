@@ -9,6 +9,9 @@
 #include <vector>
 #define MSFM_POTRF_PROBE 1
 #include "../metricsfm_amd/csrc/chol_potrf16.h"
+#ifndef POTRF
+#define POTRF potrf16_m
+#endif
 
 __global__ __launch_bounds__(256) void k_probe(const double* A /*[64][64]*/, double* Lout /*[64][64]*/, double* Dout /*[64][16]*/, long long* cyc, int* fail) {
   __shared__ double sm[80 + 64 * DV + 64 * LDT];
@@ -22,11 +25,11 @@ __global__ __launch_bounds__(256) void k_probe(const double* A /*[64][64]*/, dou
     long long t0, t1;
     int dummy = lane;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "+v"(dummy) : : "memory");
-    potrf16_t<0>(Ls, dinv, dvec, lane, fail);
+    POTRF<0>(Ls, dinv, dvec, lane, fail);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "+v"(dummy) : : "memory");
     if (lane == 0) cyc[0] = t1 - t0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "+v"(dummy) : : "memory");
-    potrf16_t<2>(Ls, dinv, dvec, lane, fail);
+    POTRF<2>(Ls, dinv, dvec, lane, fail);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "+v"(dummy) : : "memory");
     if (lane == 0) cyc[1] = t1 - t0;
   }
@@ -57,7 +60,7 @@ int main() {
   long long hc[2]; int hf;
   hipMemcpy(hc, dc, 16, hipMemcpyDeviceToHost); hipMemcpy(&hf, df, 4, hipMemcpyDeviceToHost);
   hipMemcpy(L.data(), dL, sizeof(double) * 4096, hipMemcpyDeviceToHost); hipMemcpy(D.data(), dD, sizeof(double) * 1024, hipMemcpyDeviceToHost);
-  printf("potrf16_t<0>: %lld cycles, potrf16_t<2>: %lld cycles (16 pivots each), fail %d\n", hc[0], hc[1], hf);
+  printf("tile 0: %lld cycles, tile 2: %lld cycles (16 pivots each), fail %d\n", hc[0], hc[1], hf);
   for (int t : {0, 2}) {
     // host Cholesky of the tile
     double R[16][16] = {};
