@@ -2992,6 +2992,8 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     // ---- ComputeTrustRegionStep ----
     // (already enqueued with the reduced system; S_FAIL carries both the 3x3 point-block and the
     // Cholesky / finiteness failures, and any of them makes the step invalid)
+    if ((long)ba->h_scal[S_FAIL] >= MSFM_FAIL_SYNC)
+      return msfm_set_error(ctx, MSFM_E_DEVICE, "a bounded in-kernel wait of the back substitution ran out (MSFM_SYNC_TIMEOUT_S)");
     const bool solved = (int)ba->h_scal[S_FAIL] == 0;
     const double mcc = ba->h_scal[S_MCC], cand_cost = ba->h_scal[S_COST], dx2 = ba->h_scal[S_DX2], x2 = ba->h_scal[S_X2];
     it.step_is_valid = solved && (mcc > 0.0);

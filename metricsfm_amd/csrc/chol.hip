@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #define NB 64
+#define MSFM_Z_PENDING 0xFFF85A5A5A5A5A5Aull   // "not solved yet" in the solution vector of k_backsolve_chain
 #define LDT 66  // LDS row stride in doubles: 132 dwords = 4 mod 64 -> conflict-free ds_read_b64 fragments
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -730,13 +731,16 @@ __device__ __forceinline__ void tile_mm(double* Cm, int rc, int cc, const double
 
 __global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ Ldiag, int n, const double* __restrict__ Dinv,
                                                        double* __restrict__ Linv, int nblk, const double* __restrict__ M, int ld,
-                                                       double* __restrict__ w, int npad) {
+                                                       double* __restrict__ w, int npad, unsigned long long* __restrict__ zfill) {
   __shared__ double L[NB * LDT];
   __shared__ double v[NB * LDT];
   __shared__ double t[NB * LDT];
   if ((int)blockIdx.x >= nblk) {
     const int i = ((int)blockIdx.x - nblk) * 256 + (int)threadIdx.x;
-    if (i < npad) w[i] = (i < n) ? M[(size_t)n * ld + i] : 0.0;
+    if (i < npad) {
+      w[i] = (i < n) ? M[(size_t)n * ld + i] : 0.0;
+      if (zfill) zfill[i] = MSFM_Z_PENDING;   // "not solved yet" for k_backsolve_chain
+    }
     return;
   }
   const int blk = blockIdx.x, j0 = blk * NB, tid = threadIdx.x;
@@ -907,6 +911,125 @@ __global__ __launch_bounds__(256) void k_backsolve_pair(const double* __restrict
   if (tid < NB) w[i0 + tid] = wi - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
 }
 
+// ---------------------------------------------------------------------------------------
+// The whole back substitution as ONE launch: one workgroup per 64-column block, workgroup b takes block i = nblk - 1 - b.
+// It keeps w_i in LDS, walks the blocks j > i that couple to it in descending order (the later blocks of its own tree
+// node, its ancestors' blocks, the root chain), takes z_j as soon as the workgroup of block j has published it, subtracts
+// L_ji^T z_j and finally publishes z_i = Linv_i^T w_i.  The arithmetic and its order are those of k_backsolve_step /
+// k_backsolve_pair (bit-identical result); what goes is the chain of twelve dependent launches (config 3: 85 -> 40 us).
+//
+// Hand-off: z is filled with MSFM_Z_PENDING (a NaN payload no arithmetic produces) by k_trinv64_full; a block's 64 values are
+// published by ONE wave with 8-byte agent-scope (sc1) stores and consumed by agent-scope loads polled per value - every
+// double is its own {data, tag} granule, so no flag, fence or ordering between the values is needed.  A workgroup only ever
+// waits for blocks with a HIGHER index, i.e. workgroups with a lower blockIdx; the launch is used only while all of them fit
+// on the chip together (host: nblk <= MSFM_BACKSOLVE_CHAIN_MAX), and every poll loop is bounded: on expiry the failure word
+// gets MSFM_FAIL_SYNC (the host returns MSFM_E_DEVICE) and the value is taken as 0 so that every workgroup still drains.
+// ---------------------------------------------------------------------------------------
+#define MSFM_BACKSOLVE_CHAIN_MAX 224
+struct BackTree {
+  int n_levels;
+  int root_blk;                       // first block of the root chain
+  struct { int K; struct { int b0, b1, leaf_lo, leaf_hi; } node[8]; } level[3];   // block ranges of the nodes
+};
+__global__ __launch_bounds__(256) void k_backsolve_chain(const double* __restrict__ M, int ld, int n, int nblk, BackTree tree,
+                                                          const double* __restrict__ Linv, const double* __restrict__ w,
+                                                          double* __restrict__ z, int* __restrict__ fail, unsigned spin_limit) {
+  __shared__ double part[4][NB];
+  __shared__ double zj[NB], wi[NB];
+  __shared__ int rlo[5], rhi[5], nr;
+  const int tid = threadIdx.x, col = tid & 63, kq = tid >> 6;
+  const int i = nblk - 1 - (int)blockIdx.x, i0 = i * NB;
+  if (tid == 0) {
+    // ranges of coupled later blocks, in the order they are walked (descending block index): root chain, ancestors from
+    // the shallowest to the deepest, then the rest of the own node
+    int c = 0;
+    if (tree.n_levels == 0 || i >= tree.root_blk) {
+      rlo[c] = i + 1; rhi[c] = nblk; c++;
+    } else {
+      int lv = 0, k = 0;
+      for (int l = 0; l < tree.n_levels; l++)
+        for (int q = 0; q < tree.level[l].K; q++)
+          if (i >= tree.level[l].node[q].b0 && i < tree.level[l].node[q].b1) { lv = l; k = q; }
+      const int lo = tree.level[lv].node[k].leaf_lo, hi = tree.level[lv].node[k].leaf_hi;
+      rlo[c] = tree.root_blk; rhi[c] = nblk; c++;
+      for (int h = tree.n_levels - 1; h > lv; h--)
+        for (int q = 0; q < tree.level[h].K; q++)
+          if (tree.level[h].node[q].leaf_lo <= lo && tree.level[h].node[q].leaf_hi >= hi) { rlo[c] = tree.level[h].node[q].b0; rhi[c] = tree.level[h].node[q].b1; c++; }
+      rlo[c] = i + 1; rhi[c] = tree.level[lv].node[k].b1; c++;
+    }
+    nr = c;
+  }
+  if (tid < NB) wi[tid] = w[i0 + tid];
+  // the inverse of the own diagonal block is needed last: fetch it first
+  double lv_[16];
+  {
+    const double* Li = Linv + (size_t)i * NB * NB;
+#pragma unroll
+    for (int k = 0; k < 16; k++) lv_[k] = Li[(16 * kq + k) * NB + col];
+  }
+  __syncthreads();
+  auto fetch = [&](int j, double (&mv)[16]) {
+    const int j0 = j * NB;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int r = j0 + 16 * kq + k;
+      mv[k] = r < n ? M[(size_t)r * ld + i0 + col] : 0.0;
+    }
+  };
+  // flat walk over the ranges with the next block's tile in flight while the current block's z is awaited
+  int ri = 0, j = -1;
+  auto advance = [&]() {   // next (range, block) in walking order, j = -1 when done
+    while (ri < nr) {
+      if (j < 0) j = rhi[ri] - 1; else j--;
+      if (j >= rlo[ri]) return;
+      ri++; j = -1;
+    }
+    j = -1;
+  };
+  advance();
+  double mv[16], mvn[16];
+  if (j >= 0) fetch(j, mv);
+  while (j >= 0) {
+    const int jc = j;
+    advance();
+    if (j >= 0) fetch(j, mvn);
+    if (tid < NB) {
+      // one wave, one value per lane
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(z) + (size_t)jc * NB + tid;
+      unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (v == MSFM_Z_PENDING) {
+        if (++spins > spin_limit) { atomicOr(fail, MSFM_FAIL_SYNC); v = 0ull; break; }
+        __builtin_amdgcn_s_sleep(2);
+        v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      zj[tid] = __longlong_as_double((long long)v);
+    }
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += mv[k] * zj[16 * kq + k];
+    part[kq][col] = acc;
+    __syncthreads();
+    if (tid < NB) wi[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) mv[k] = mvn[k];
+  }
+  // z_i = Linv_i^T w_i
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) s += lv_[k] * wi[16 * kq + k];
+  part[kq][col] = s;
+  __syncthreads();
+  if (tid < NB) {
+    const double zz = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    unsigned long long bits = (unsigned long long)__double_as_longlong(zz);
+    if (bits == MSFM_Z_PENDING) bits = 0x7FF8000000000000ull;   // (cannot come out of arithmetic; keep the protocol safe anyway)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(z) + (size_t)i0 + tid, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // Host driver.  M: npad x npad, row n = rhs.  On return z[0..n) solves S z = rhs.
 // `fail` (device int) is OR-ed with 1 when S is not positive definite.
 // work: npad*16 doubles (16x16 inverses) + npad*64 (full block inverses) + npad*64 (diagonal blocks of L).
@@ -1055,9 +1178,34 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   root_timer.stop();
   {
     KTimer t(ctx, "chol_backsolve");
-    hipLaunchKernelGGL(k_trinv64_full, dim3(cdiv(n, NB) + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, cdiv(n, NB), M, npad, w, npad);
+    const int nblk = cdiv(n, NB);
+    static const bool launches_env = getenv("MSFM_BACKSOLVE_LAUNCHES") != nullptr;   // the round-2 chain of launches, for comparison
+    const bool chain = !launches_env && nblk <= MSFM_BACKSOLVE_CHAIN_MAX;
+    hipLaunchKernelGGL(k_trinv64_full, dim3(nblk + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, nblk, M, npad, w, npad,
+                       chain ? reinterpret_cast<unsigned long long*>(z) : (unsigned long long*)nullptr);
+    if (chain) {
+      BackTree bt;
+      bt.n_levels = n_levels;
+      bt.root_blk = t_first / NB;
+      for (int lv = 0; lv < 3; lv++) {
+        bt.level[lv].K = lv < n_levels ? plan->level[lv].K : 0;
+        for (int k = 0; k < 8; k++) {
+          const bool live = lv < n_levels && k < plan->level[lv].K;
+          const msfm_chol_node nd = live ? plan->level[lv].node[k] : msfm_chol_node{0, 0, 0, 0};
+          bt.level[lv].node[k].b0 = nd.begin / NB; bt.level[lv].node[k].b1 = nd.end / NB;
+          bt.level[lv].node[k].leaf_lo = nd.leaf_lo; bt.level[lv].node[k].leaf_hi = nd.leaf_hi;
+        }
+      }
+      // a poll is an L2 round trip plus s_sleep: ~0.3 us; the bound is MSFM_SYNC_TIMEOUT_S (default 120 s, as for the host's own spin)
+      static const unsigned spin_limit = [] {
+        const char* e = getenv("MSFM_SYNC_TIMEOUT_S");
+        const double v = e ? atof(e) : 120.0;
+        return (unsigned)std::min(4.0e9, std::max(1.0e4, (v > 0 ? v : 120.0) * 3.0e6));
+      }();
+      hipLaunchKernelGGL(k_backsolve_chain, dim3(nblk), dim3(256), 0, s, M, npad, n, nblk, bt, Linv, w, z, fail, spin_limit);
+    }
     const int first_dense = t_first / NB;
-    for (int jb = cdiv(n, NB) - 1; jb >= first_dense;) {  // root chain (or everything): couples to every block before it
+    for (int jb = nblk - 1; !chain && jb >= first_dense;) {  // root chain (or everything): couples to every block before it
       BackJobs bj;
       bj.count = 1;
       if (jb - 1 >= first_dense) {   // blocks jb and jb-1 together
@@ -1070,7 +1218,7 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
         jb -= 1;
       }
     }
-    for (int lv = n_levels - 1; lv >= 0; lv--) {
+    for (int lv = n_levels - 1; !chain && lv >= 0; lv--) {
       // Blocks P_k - 1 - 2l and P_k - 2 - 2l of every node of the level in one launch (a node's last odd block alone).  A
       // block couples to the earlier blocks of its own node and to its descendants in the lower levels (contiguous in
       // every level: tree order) - one job per range, all of them recomputing z for themselves; siblings never touch the

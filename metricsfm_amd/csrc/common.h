@@ -160,6 +160,9 @@ static inline void par_ranges(size_t n, int nt, F&& fn, size_t grain = 4096) {  
 // dense chain.  n_levels = 0: plain dense order.  A node's descendants in a lower level are the nodes whose leaf interval
 // lies inside its own (tree order inside every level makes them contiguous).
 // corners: scratch for the deferred separator x separator updates, `nsplit` buffers of ldc x ldc doubles.
+// bits of the device-side failure word of a solve: 1 = reduced system not positive definite, 2 = a 3x3 point block, 4 = non-finite step;
+// MSFM_FAIL_SYNC = a bounded in-kernel wait ran out (the host turns it into MSFM_E_DEVICE)
+#define MSFM_FAIL_SYNC (1 << 20)
 #define MSFM_CORNER_MAX_BLOCKS 128   // 64-column blocks behind the leaf level that k_corner_syrk's range table holds
 struct msfm_chol_node { int begin, end, leaf_lo, leaf_hi; };
 struct msfm_chol_level { int K = 0; msfm_chol_node node[8]; int begin = 0, b0 = 0; };
