@@ -306,6 +306,27 @@ def main():
         except Exception:
             pass
 
+    # matrix-pipe utilisation from the SQ counter passes (scripts/mfma_util.sh -> profiles/r03_mfma_util.json): attached to the
+    # rooflines of the MFMA kernels, with a note when the counters were collected with other kernel sources
+    util = {}
+    try:
+        util = json.load(open(os.path.join(ROOT, "profiles", "r03_mfma_util.json")))
+    except Exception:
+        pass
+
+    def attach_util(rl, key):
+        u = util.get(key)
+        if not rl or not u:
+            return
+        for k in ("mfma_busy", "valu_busy", "valu_per_mfma"):
+            if k in u:
+                rl[k] = u[k]
+        rl["mfma_busy_source"] = "profiles/r03_mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))" + (
+            "" if util.get("_kernel_source_hash") == kernel_source_hash() else "; collected with other kernel sources (%s)" % util.get("_kernel_source_hash"))
+
+    attach_util(rooflines.get("chol_panel_mfma"), "ba")
+    if roofline.get("kernel") == "chol_panel_mfma":
+        attach_util(roofline, "ba")
     out = dict(metric="BA iterations/sec", value=it_s, unit="iterations/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=1e3 * ba_s / args.steps, higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
@@ -372,12 +393,14 @@ def main():
 
         m_int = run_matching(descs, "integer SIFT-like in [0,255] stored as float32 (exact int8 MFMA path)", max(1, args.match_steps))
         m_int["feature_gen_s"] = feat_s
+        attach_util(m_int["roofline"], "knn_i8")
         out["mmatches_per_sec"] = m_int["value"]
         out["matching"] = m_int
         # the reference's extractors hand over non-integral floats (feature_extractor_vl_sift.cpp:202: 512.0F * x, never cast):
         # the same descriptors unit-normalised and scaled by 512
         fdescs = [(512.0 * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32) for d in descs]
         out["matching_float"] = run_matching(fdescs, "non-integral floats, 512 * unit-norm (VLFeat convention; certified shortlist + exact re-rank)", 1)
+        attach_util(out["matching_float"]["roofline"], "knn_f16")
         del fdescs
 
     # ------------------------------------------------------------------ triangulation / reprojection leg (A4, A5, A11)
