@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the triangulation / verification / pose-initialiser legs")
     ap.add_argument("--verify-pairs", type=int, default=2048, help="image pairs in the geometric-verification leg")
     ap.add_argument("--pose-images", type=int, default=1024, help="images / pairs in the pose-initialiser leg")
+    ap.add_argument("--chain-images", type=int, default=96, help="images in the resident-chain leg (all their ordered pairs)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend for N>1 (default nccl = RCCL)")
     args = ap.parse_args()
 
@@ -436,6 +437,82 @@ def main():
         out["triangulation"] = dict(note="host arrays in, host arrays out (PCIe inclusive wall time; kernel time from HIP events); th_error 7 px, "
                                          "th_angle 3 deg (sfm_incremental.cc:780-784); tracks split over %d rank(s) by shard.shard_tracks, times are the "
                                          "maximum over ranks, `accepted` is rank 0's range" % world, **legs)
+
+    # ------------------------------------------------------------------ resident chain: codes -> verification -> tracks -> points -> BA problem
+    if not args.no_extras and not args.no_matching and not win and rank == 0 and descs is not None:
+        from metricsfm_amd import matchfiles
+        n_ci = min(args.chain_images, len(descs))
+        kps = [np.ascontiguousarray(sc.kp_xy[i], np.float32) for i in range(n_ci)]
+        cds = ctx.descset(descs[:n_ci], keypoints=kps)
+        cpairs = scene.all_pairs(n_ci)
+        cres = cds.match_pairs(cpairs, 0.6, 0.85)
+        Rc, tc, cc, fkc = scene.cameras_for_tracks(sc)
+        Rc, tc, cc, fkc = Rc[:n_ci], tc[:n_ci], cc[:n_ci], fkc[:n_ci]
+        ctx.synchronize()
+
+        def run_chain():
+            t0 = time.perf_counter()
+            ch = capi.Chain(cres)
+            n_m, okc, _ = ch.verify(3.0)
+            t1 = time.perf_counter()
+            nt, no = ch.build_tracks()
+            t2 = time.perf_counter()
+            nacc = ch.triangulate(Rc, tc, cc, fkc, 7.0, np.deg2rad(3.0))
+            t3 = time.perf_counter()
+            cba = ch.ba_create(sc.cam_pose[:n_ci], sc.cam_model, sc.cam_model_of_cam[:n_ci], min_views=3, weight_ge3=1.0)
+            ctx.synchronize()
+            t4 = time.perf_counter()
+            out_ = dict(verify_ms=1e3 * (t1 - t0), tracks_ms=1e3 * (t2 - t1), triangulate_ms=1e3 * (t3 - t2), ba_create_ms=1e3 * (t4 - t3), total_ms=1e3 * (t4 - t0),
+                        pairs_ok=int(okc.sum()), matches=int(n_m.sum()), tracks=nt, observations=no, accepted=nacc, ba_points=len(cba.track_of_point), ba_observations=cba.n_obs)
+            cba.close(); ch.close()
+            return out_
+
+        def run_host():
+            t0 = time.perf_counter()
+            good_l, all_l = [], []
+            for p in range(len(cpairs)):
+                code, _, _ = cres.fetch(p)
+                g, a = matchfiles.codes_to_matches(code)
+                good_l.append(g); all_l.append(a)
+            off_g = np.concatenate([[0], np.cumsum([len(g) for g in good_l])]).astype(np.int32)
+            off_a = np.concatenate([[0], np.cumsum([len(a) for a in all_l])]).astype(np.int32)
+            g1 = np.concatenate([kps[i][g[:, 0]] for (i, j), g in zip(cpairs, good_l)]); g2 = np.concatenate([kps[j][g[:, 1]] for (i, j), g in zip(cpairs, good_l)])
+            a1 = np.concatenate([kps[i][a[:, 0]] for (i, j), a in zip(cpairs, all_l)]); a2 = np.concatenate([kps[j][a[:, 1]] for (i, j), a in zip(cpairs, all_l)])
+            Fh, _, _, okh = ctx.fundamental_ransac(off_g, g1, g2)
+            in_a = ctx.epipolar_filter_batch(off_a, a1, a2, Fh, okh, 3.0)
+            fin = [all_l[p][in_a[off_a[p]:off_a[p + 1]] != 0] if okh[p] else np.zeros((0, 2), np.int32) for p in range(len(cpairs))]
+            t1 = time.perf_counter()
+            moff = np.concatenate([[0], np.cumsum([len(m) for m in fin])]).astype(np.int32)
+            flat = (np.array([len(k) for k in kps], np.int32), A.as_c(cpairs, np.int32), moff, A.as_c(np.concatenate(fin).reshape(-1, 2), np.int32))
+            off, img, feat = ctx.build_tracks(None, None, None, flat=flat)
+            t2 = time.perf_counter()
+            xy = np.empty((len(img), 2))
+            for i in range(n_ci):
+                sel = img == i
+                xy[sel] = kps[i][feat[sel]]
+            Xh, _, tokh = ctx.triangulate_midpoint(A.TrackArrays(off, img, xy, Rc, tc, cc, fkc), 7.0, np.deg2rad(3.0))
+            t3 = time.perf_counter()
+            keep = (tokh != 0) & (np.diff(off) >= 3)
+            obs_sel = np.repeat(keep, np.diff(off))
+            arrays = A.BaArrays(sc.cam_pose[:n_ci].copy(), sc.cam_model.copy(), sc.cam_model_of_cam[:n_ci], Xh[keep].copy(), img[obs_sel],
+                                np.repeat(np.cumsum(keep) - 1, np.diff(off))[obs_sel].astype(np.int32), xy[obs_sel], np.ones(int(keep.sum())))
+            hba = ctx.ba(arrays)
+            ctx.synchronize()
+            t4 = time.perf_counter()
+            hba.close()
+            return dict(verify_ms=1e3 * (t1 - t0), tracks_ms=1e3 * (t2 - t1), triangulate_ms=1e3 * (t3 - t2), ba_create_ms=1e3 * (t4 - t3), total_ms=1e3 * (t4 - t0))
+
+        run_chain()   # untimed first pass (kernel code, pool blocks)
+        ch_t = run_chain()
+        host_t = run_host()
+        out["resident_chain"] = dict(images=n_ci, pairs=int(len(cpairs)), feats_per_image=args.feats, device=ch_t, host_arrays=host_t,
+                                     speedup=host_t["total_ms"] / ch_t["total_ms"],
+                                     note="match codes -> GeoVerificationFundamental + filter -> track building -> midpoint triangulation -> msfm_ba_create, "
+                                          "once with every intermediate result resident (msfm_chain_*) and once through the host-array entry points on the "
+                                          "fetched results of each stage (numpy gathers included: they stand for the reference's per-pair loops); results identical "
+                                          "(tests/test_gpu_chain.py)")
+        cres.close(); cds.close()
+        log("resident chain leg done")
 
     # ------------------------------------------------------------------ geometric-verification leg
     if not args.no_extras and rank == 0:

@@ -410,6 +410,44 @@ int msfm_track_set_fetch(const msfm_track_set* set, int* track_off /*[n_tracks+1
 void msfm_track_set_destroy(msfm_track_set* set);
 
 /* ======================================================================================
+ *  The same chain with every intermediate result resident on the GPU
+ * ====================================================================================== */
+/* match codes -> geometric verification -> track building -> triangulation -> bundle adjustment without a host round trip
+ * in between: the hand-over the reference makes through std::vector / std::map objects per pair and per point
+ * (fine_matching_graph.cc:116-186 -> slam_gps.cc:557-648 -> optimizer.cc:59-133; incremental form
+ * sfm_incremental.cc:755-915).  Each step runs the kernels of its host-array counterpart on device buffers and gives
+ * the same result bit for bit; between the descriptor / keypoint upload and msfm_ba_download_params only a few integers
+ * per image pair and the cameras cross PCIe.  Image index = camera index.
+ *   msfm_chain_create       takes the codes of a msfm_match_pairs result (not the SLAM form) whose descriptor set holds the
+ *                           keypoints of every image involved (msfm_descset_upload_keypoints)
+ *   msfm_chain_verify       per pair: GeoVerificationFundamental on matches_good (msfm_fundamental_ransac_batch, pair p of the
+ *                           list = pair p of the sampler), then, if it succeeded, the closed-form filter with th_filter (3.0)
+ *                           on matches_all; a pair keeps the surviving matches_all entries, a failed pair none
+ *                           (fine_matching_graph.cc:138-153, :182-186)
+ *   msfm_chain_build_tracks msfm_tracks_build_device on those matches, pairs in the order of the match result
+ *   msfm_chain_triangulate  msfm_triangulate_midpoint_batch on every track (X starts at 0), observations from the keypoints
+ *   msfm_chain_ba_create    msfm_ba_create on the tracks with ok = 1 and >= min_views observations (slam_gps.cc:638-648:
+ *                           3), gather order and weights of optimizer.cc:59-129 (2 views -> 1.0, more -> weight_ge3);
+ *                           cameras / intrinsics from the caller (host), every block mutable.  The msfm_ba is the caller's.
+ * The fetch functions copy a stage's result to the host (tests, file writers); none is needed to go on. */
+typedef struct msfm_chain msfm_chain;
+int msfm_chain_create(msfm_match_result* res, msfm_chain** out);
+int msfm_chain_verify(msfm_chain* chain, msfm_match_result* res, const msfm_fransac_options* opt, double th_filter);
+int msfm_chain_matches(msfm_chain* chain, int* n_matches /*[n_pairs]*/, uint8_t* ok /*[n_pairs]*/, double* F /*[n_pairs][9]*/);
+int msfm_chain_fetch_matches(msfm_chain* chain, int pair, int* matches /*[n_matches[pair]][2]*/);
+int msfm_chain_build_tracks(msfm_chain* chain, int* n_tracks, int* n_observations);
+int msfm_chain_fetch_tracks(msfm_chain* chain, int* track_off, int* obs_image, int* obs_feature);
+int msfm_chain_triangulate(msfm_chain* chain, int n_cams, const double* cam_R, const double* cam_t, const double* cam_c,
+                           const double* cam_fk, double th_error, double th_angle, int* n_accepted);
+int msfm_chain_fetch_points(msfm_chain* chain, double* X /*[n_tracks][3]*/, double* mse, uint8_t* ok);
+int msfm_chain_ba_create(msfm_chain* chain, int n_cams, int n_models, double* cam_pose, double* cam_model,
+                         const int32_t* cam_model_of_cam, int min_views, double weight_ge3, msfm_ba** out, int* n_points,
+                         int* n_observations);
+/* track index of every point of the bundle adjustment (to put the adjusted points back) */
+int msfm_chain_fetch_point_tracks(msfm_chain* chain, int* track_of_point /*[n_points]*/);
+void msfm_chain_destroy(msfm_chain* chain);
+
+/* ======================================================================================
  *  Pose initialisers ahead of each bundle adjustment  
  * ====================================================================================== */
 /* AbsolutePoseEstimation::AbsolutePoseWithFocalLength (SfM/src/orientation/absolute_pose_estimation.cc:42-58, called

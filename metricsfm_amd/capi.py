@@ -20,6 +20,9 @@ SYMBOLS = [
     "msfm_knn2_f32", "msfm_descset_create", "msfm_descset_upload", "msfm_descset_count", "msfm_descset_destroy",
     "msfm_match_pairs", "msfm_match_result_counts", "msfm_match_result_fetch", "msfm_match_result_stats", "msfm_match_result_destroy",
     "msfm_match_pairs_rerun", "msfm_descset_upload_keypoints", "msfm_slam_match_default_options", "msfm_match_pairs_slam",
+    "msfm_chain_create", "msfm_chain_verify", "msfm_chain_matches", "msfm_chain_fetch_matches", "msfm_chain_build_tracks",
+    "msfm_chain_fetch_tracks", "msfm_chain_triangulate", "msfm_chain_fetch_points", "msfm_chain_ba_create", "msfm_chain_fetch_point_tracks",
+    "msfm_chain_destroy",
     "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
     "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ba_get_layout", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
@@ -106,6 +109,18 @@ def lib():
     L.msfm_track_set_fetch.argtypes = [vp, A.c_int_p, A.c_int_p, A.c_int_p]
     L.msfm_track_set_destroy.argtypes = [vp]
     L.msfm_track_set_destroy.restype = None
+    L.msfm_chain_create.argtypes = [vp, C.POINTER(vp)]
+    L.msfm_chain_verify.argtypes = [vp, vp, C.POINTER(A.FransacOptions), d]
+    L.msfm_chain_matches.argtypes = [vp, A.c_int_p, A.c_u8_p, A.c_double_p]
+    L.msfm_chain_fetch_matches.argtypes = [vp, i, A.c_int_p]
+    L.msfm_chain_build_tracks.argtypes = [vp, A.c_int_p, A.c_int_p]
+    L.msfm_chain_fetch_tracks.argtypes = [vp, A.c_int_p, A.c_int_p, A.c_int_p]
+    L.msfm_chain_triangulate.argtypes = [vp, i, A.c_double_p, A.c_double_p, A.c_double_p, A.c_double_p, d, d, A.c_int_p]
+    L.msfm_chain_fetch_points.argtypes = [vp, A.c_double_p, A.c_double_p, A.c_u8_p]
+    L.msfm_chain_ba_create.argtypes = [vp, i, i, A.c_double_p, A.c_double_p, A.c_int_p, i, d, C.POINTER(vp), A.c_int_p, A.c_int_p]
+    L.msfm_chain_fetch_point_tracks.argtypes = [vp, A.c_int_p]
+    L.msfm_chain_destroy.argtypes = [vp]
+    L.msfm_chain_destroy.restype = None
     _lib = L
     return L
 
@@ -483,6 +498,87 @@ class MatchResult:
     def close(self):
         if self._h:
             lib().msfm_match_result_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Chain:
+    """msfm_chain: match codes -> verification -> tracks -> triangulation -> bundle adjustment, everything resident
+    (include/msfm.h).  Built from a MatchResult whose DescSet holds the keypoints."""
+
+    def __init__(self, res):
+        self.ctx, self.res = res.ctx, res
+        self.n_pairs = len(res.pairs)
+        self._h = C.c_void_p()
+        self.ctx.check(lib().msfm_chain_create(res._h, C.byref(self._h)))
+
+    def verify(self, th_filter=3.0, **opts):
+        o = fransac_options(**opts)
+        self.ctx.check(lib().msfm_chain_verify(self._h, self.res._h, C.byref(o), th_filter))
+        n = np.zeros(max(1, self.n_pairs), np.int32)
+        ok = np.zeros(max(1, self.n_pairs), np.uint8)
+        F = np.zeros((max(1, self.n_pairs), 3, 3))
+        self.ctx.check(lib().msfm_chain_matches(self._h, A.ptr(n, A.c_int_p), A.ptr(ok, A.c_u8_p), A.ptr(F, A.c_double_p)))
+        self.n_matches = n[:self.n_pairs]
+        return self.n_matches, ok[:self.n_pairs], F[:self.n_pairs]
+
+    def fetch_matches(self, pair):
+        m = np.zeros((int(self.n_matches[pair]), 2), np.int32)
+        self.ctx.check(lib().msfm_chain_fetch_matches(self._h, pair, A.ptr(m, A.c_int_p)))
+        return m
+
+    def build_tracks(self):
+        nt, no = C.c_int32(), C.c_int32()
+        self.ctx.check(lib().msfm_chain_build_tracks(self._h, C.byref(nt), C.byref(no)))
+        self.n_tracks, self.n_obs = nt.value, no.value
+        return self.n_tracks, self.n_obs
+
+    def fetch_tracks(self):
+        off = np.zeros(self.n_tracks + 1, np.int32)
+        img, feat = np.zeros(max(1, self.n_obs), np.int32), np.zeros(max(1, self.n_obs), np.int32)
+        self.ctx.check(lib().msfm_chain_fetch_tracks(self._h, A.ptr(off, A.c_int_p), A.ptr(img, A.c_int_p), A.ptr(feat, A.c_int_p)))
+        return off, img[:self.n_obs], feat[:self.n_obs]
+
+    def triangulate(self, R, t, c, fk, th_error, th_angle):
+        R, t, c, fk = (A.as_c(np.asarray(x, dtype=np.float64), np.float64) for x in (R, t, c, fk))
+        n = C.c_int32()
+        self.ctx.check(lib().msfm_chain_triangulate(self._h, len(t), A.ptr(R, A.c_double_p), A.ptr(t, A.c_double_p), A.ptr(c, A.c_double_p),
+                                                    A.ptr(fk, A.c_double_p), th_error, th_angle, C.byref(n)))
+        return n.value
+
+    def fetch_points(self):
+        X, mse, ok = np.zeros((max(1, self.n_tracks), 3)), np.zeros(max(1, self.n_tracks)), np.zeros(max(1, self.n_tracks), np.uint8)
+        self.ctx.check(lib().msfm_chain_fetch_points(self._h, A.ptr(X, A.c_double_p), A.ptr(mse, A.c_double_p), A.ptr(ok, A.c_u8_p)))
+        return X[:self.n_tracks], mse[:self.n_tracks], ok[:self.n_tracks]
+
+    def ba_create(self, cam_pose, cam_model, cam_model_of_cam, min_views=3, weight_ge3=1.0):
+        """msfm_chain_ba_create: returns a BaResident on the accepted tracks (its `.arrays` hold only the camera side: the
+        points live on the device; `download()` returns them in `track_of_point` order)."""
+        cam_pose, cam_model = A.as_c(np.array(cam_pose, dtype=np.float64), np.float64), A.as_c(np.array(cam_model, dtype=np.float64), np.float64)
+        moc = A.as_c(np.asarray(cam_model_of_cam, dtype=np.int32), np.int32)
+        h, npt, nob = C.c_void_p(), C.c_int32(), C.c_int32()
+        self.ctx.check(lib().msfm_chain_ba_create(self._h, len(cam_pose), len(cam_model), A.ptr(cam_pose, A.c_double_p), A.ptr(cam_model, A.c_double_p),
+                                                  A.ptr(moc, A.c_int_p), min_views, weight_ge3, C.byref(h), C.byref(npt), C.byref(nob)))
+        top = np.zeros(npt.value, np.int32)
+        self.ctx.check(lib().msfm_chain_fetch_point_tracks(self._h, A.ptr(top, A.c_int_p)))
+
+        class _Shapes:   # what BaResident.download needs to size its buffers
+            pass
+        sh = _Shapes()
+        sh.cam_pose, sh.cam_model, sh.point = cam_pose, cam_model, np.zeros((npt.value, 3))
+        ba = BaResident.__new__(BaResident)
+        ba.ctx, ba.arrays, ba._h = self.ctx, sh, h
+        ba.track_of_point, ba.n_obs = top, nob.value
+        return ba
+
+    def close(self):
+        if self._h:
+            lib().msfm_chain_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -1795,9 +1795,14 @@ static int build_pairs_device(msfm_ctx* ctx, msfm_ba* ba, PairJobs& J, int nout,
 }
 
 // Everything msfm_ba_create needs between the caller's arrays and the allocation of the work buffers, on the device.
-static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba* ba, const std::function<void(const char*)>& lap) {
+static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba* ba, const std::function<void(const char*)>& lap,
+                                    bool bulk_on_device) {
   using namespace devsetup;
   hipStream_t s = ctx->stream;
+  // bulk arrays that are already resident (msfm_chain_ba_create) are copied device to device
+  auto bulk = [&](void* dst, const void* src, size_t bytes) {
+    return hipMemcpyAsync(dst, src, bytes, bulk_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+  };
   const int Nc = ba->Nc = P->n_cams, Nm = ba->Nm = P->n_models, Np = ba->Np = P->n_points, No = P->n_obs;
   DevBuf<char> tmp;
   // ---- the caller's arrays (the only bulk PCIe traffic of the set-up) ----
@@ -1807,13 +1812,14 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
   DTRY(d_obs_cam.alloc((size_t)std::max(1, No))); DTRY(d_obs_pt.alloc((size_t)std::max(1, No))); DTRY(d_obs_xy.alloc(2 * (size_t)std::max(1, No)));
   DTRY(d_model_of_cam.alloc(Nc));
   if (No) {
-    DTRY(d_obs_cam.upload(P->obs_cam, No, s)); DTRY(d_obs_pt.upload(P->obs_pt, No, s)); DTRY(d_obs_xy.upload(P->obs_xy, 2 * (size_t)No, s));
+    DTRY(bulk(d_obs_cam.p, P->obs_cam, sizeof(int) * (size_t)No)); DTRY(bulk(d_obs_pt.p, P->obs_pt, sizeof(int) * (size_t)No));
+    DTRY(bulk(d_obs_xy.p, P->obs_xy, sizeof(double) * 2 * (size_t)No));
   }
   DTRY(d_model_of_cam.upload(P->cam_model_of_cam, Nc, s));
-  if (P->pt_weight && Np) { DTRY(d_ptw.alloc(Np)); DTRY(d_ptw.upload(P->pt_weight, Np, s)); }
+  if (P->pt_weight && Np) { DTRY(d_ptw.alloc(Np)); DTRY(bulk(d_ptw.p, P->pt_weight, sizeof(double) * (size_t)Np)); }
   if (P->cam_mutable) { DTRY(d_cam_mut.alloc(Nc)); DTRY(d_cam_mut.upload(P->cam_mutable, Nc, s)); }
   if (P->model_mutable) { DTRY(d_model_mut.alloc(Nm)); DTRY(d_model_mut.upload(P->model_mutable, Nm, s)); }
-  if (P->pt_mutable && Np) { DTRY(d_pt_mut.alloc(Np)); DTRY(d_pt_mut.upload(P->pt_mutable, Np, s)); }
+  if (P->pt_mutable && Np) { DTRY(d_pt_mut.alloc(Np)); DTRY(bulk(d_pt_mut.p, P->pt_mutable, (size_t)Np)); }
   // ---- validation, block usage, observations per point ----
   DevBuf<uint8_t> d_cu, d_mu, d_pu;
   DevBuf<int> d_cnt, d_run_first, d_err;
@@ -2420,7 +2426,9 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
   return MSFM_OK;
 }
 
-MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** out) {
+MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** out) { return ba_create_impl(ctx, P, false, out); }
+
+int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device, msfm_ba** out) {
   if (!ctx || !P || !out) return MSFM_E_INVAL;
   *out = nullptr;
   struct ExitLap {   // declared first, destroyed last: the time to the very end of the call, host vectors released
@@ -2452,7 +2460,8 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   {
     const char* e = getenv("MSFM_CREATE_HOST");
     const bool on_host = e && atoi(e) != 0;
-    MSFM_TRY(on_host ? create_structures_host(ctx, P, ba, lap) : create_structures_device(ctx, P, ba, lap));
+    if (on_host && bulk_on_device) return msfm_set_error(ctx, MSFM_E_INVAL, "MSFM_CREATE_HOST=1 needs the problem arrays in host memory");
+    MSFM_TRY(on_host ? create_structures_host(ctx, P, ba, lap) : create_structures_device(ctx, P, ba, lap, bulk_on_device));
   }
   const int Nc = ba->Nc, Nm = ba->Nm, Np = ba->Np, ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb, A = ba->A, NCR = ba->NCR, NPM = ba->NPM;
   if (ctx->world > 1 && ncb > 0 && ncb <= 4096) {
@@ -2524,7 +2533,7 @@ MSFM_API int msfm_ba_create(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba** o
   HIP_TRY(ctx, hipMemsetAsync(ba->Tu.p, 0, sizeof(double) * std::max<size_t>(1, 6 * (size_t)NCR), s));
   HIP_TRY(ctx, hipMemcpyAsync(ba->cam.p, P->cam_pose, sizeof(double) * 6 * (size_t)Nc, hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemcpyAsync(ba->model.p, P->cam_model, sizeof(double) * 3 * (size_t)Nm, hipMemcpyHostToDevice, s));
-  if (Np) HIP_TRY(ctx, hipMemcpyAsync(ba->pt.p, P->point, sizeof(double) * 3 * (size_t)Np, hipMemcpyHostToDevice, s));
+  if (Np) HIP_TRY(ctx, hipMemcpyAsync(ba->pt.p, P->point, sizeof(double) * 3 * (size_t)Np, bulk_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
   lap("done");
   ba->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

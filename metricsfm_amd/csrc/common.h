@@ -153,6 +153,46 @@ static inline void par_ranges(size_t n, int nt, F&& fn, size_t grain = 4096) {  
   for (auto& x : th) x.join();
 }
 
+// ---- device-array cores shared with chain.hip (the resident chain from match codes to a bundle adjustment) ----
+struct msfm_fransac_options;
+int geo_fransac_dev(msfm_ctx* ctx, int n_pairs, const int* h_offsets, const int* d_off, const float* d1, const float* d2,
+                    const msfm_fransac_options* opt, double* dF, uint8_t* d_in, int* d_nin, uint8_t* d_ok);
+int geo_epipolar_batch_dev(msfm_ctx* ctx, int total, const int* d_pair_of, const float* d1, const float* d2, const double* dF,
+                           const uint8_t* d_ok, double th, uint8_t* d_in);
+struct msfm_track_dev {   // CSR tracks on the device: observations of a track in ascending image order
+  DevBuf<int> off, img, feat;
+  int n_tracks = 0, n_obs = 0;
+};
+// What chain.hip needs of a match result and its descriptor set (both defined in knn.hip)
+struct msfm_match_result;
+struct MatchView {
+  msfm_ctx* ctx;
+  int n_images, n_pairs;
+  long total_q;
+  const int* pairs;              // host [n_pairs][2]
+  const int* out_off;            // host [n_pairs]: first code of the pair
+  const int* nq;                 // host [n_pairs]: query features of the pair
+  const int32_t* code;           // device [total_q]
+  const int* n_all; const int* n_good;   // device [n_pairs]
+  std::vector<int> count;        // features per image
+  std::vector<const float*> kp;  // device [count][2] per image, nullptr: no keypoints uploaded
+  bool slam;
+};
+int match_result_view(msfm_match_result* R, MatchView* out);   // MSFM_E_INVAL when the result is stale or orphaned
+
+struct TrackPtrs {   // tri.hip: CSR tracks + cameras as the reference keeps them, device pointers
+  int n_tracks;
+  const int *off, *cam;
+  const double *xy, *R, *t, *c, *fk;
+};
+int tri_midpoint_dev(msfm_ctx* ctx, const TrackPtrs& T, double th_error, double th_angle, double* dX, double* dmse, uint8_t* dok);
+struct msfm_ba_problem;
+struct msfm_ba;
+// msfm_ba_create with the bulk arrays of the problem (obs_cam, obs_pt, obs_xy, point, pt_weight, pt_mutable) in DEVICE memory
+int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device, msfm_ba** out);
+int tracks_build_dev(msfm_ctx* ctx, int n_images, const std::vector<int>& feat_off, const int* d_nf, const int* d_fo, int n_pairs,
+                     const int* d_pair, const int* d_moff, const int* d_match, int M, msfm_track_dev* out);
+
 // Elimination structure of the reduced system (chol.hip): a nested-dissection tree of the camera graph laid out level
 // by level.  Level 0 holds the leaf domains, level 1 the deepest separators, ... ; the nodes of one level are mutually
 // uncoupled (their panel chains share launches), each is 64-aligned (identity padding inside) and couples only to its own

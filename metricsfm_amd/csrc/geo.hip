@@ -368,6 +368,58 @@ MSFM_API void msfm_fransac_default_options(msfm_fransac_options* o) {
   o->seed = 0x4D53464D46ull;
 }
 
+// The verification of a batch of pairs on points that are already resident: d1 / d2 hold the pairs' matches back to back,
+// h_offsets (host) and d_off (device) delimit them; results stay on the device.  msfm_fundamental_ransac_batch is this
+// between an upload and a download, msfm_chain_verify (chain.hip) calls it on points gathered from the match codes.
+int geo_fransac_dev(msfm_ctx* ctx, int n_pairs, const int* offsets, const int* d_off, const float* d1, const float* d2,
+                    const msfm_fransac_options* opt, double* dF, uint8_t* d_in, int* d_nin, uint8_t* d_ok) {
+  hipStream_t s = ctx->stream;
+  const int total = offsets[n_pairs];
+  const int H = opt->max_iterations;
+  // R[g] per pair (N + 1 entries each)
+  std::vector<int> tab((size_t)total + n_pairs);
+  par_ranges((size_t)n_pairs, host_threads(), [&](int, size_t p0, size_t p1) {   // (N + 1) log / pow evaluations per pair
+    for (size_t p = p0; p < p1; p++) {
+      const int o = offsets[p], N = offsets[p + 1] - o;
+      int* R = tab.data() + o + p;
+      for (int g = 0; g <= N; g++) R[g] = N > 0 ? geo_update_num_iters(opt->confidence, (double)(N - g) / N, 7, H) : H;
+    }
+  }, 16);
+  DevBuf<int> d_tab, d_counts;
+  HIP_TRY(ctx, d_tab.from(tab, s));
+  HIP_TRY(ctx, d_counts.alloc((size_t)n_pairs * H * 3));
+  const double th2 = opt->threshold * opt->threshold;
+  // Most pairs stop after a few dozen samples (cvRANSACUpdateNumIters): score the first H1 samples of every pair,
+  // replay them, and run the remaining H - H1 samples only for the pairs whose budget is still open.
+  const int H1 = std::min(H, 128);
+  DevBuf<uint8_t> d_need;
+  HIP_TRY(ctx, d_need.alloc(n_pairs));
+  auto score = [&](int h0, int h1, const uint8_t* need) {
+    KTimer t(ctx, "geo_fransac_score");
+    for (int p0 = 0; p0 < n_pairs; p0 += 32768) {  // grid.y limit
+      const int np = std::min(32768, n_pairs - p0);
+      hipLaunchKernelGGL(k_fransac_score, dim3(cdiv(h1 - h0, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, H, h0, h1, p0, d_off,
+                         reinterpret_cast<const float2*>(d1), reinterpret_cast<const float2*>(d2), opt->seed, th2,
+                         opt->min_points, need, d_counts.p);
+    }
+  };
+  auto select = [&](int hscan, int pass) {
+    KTimer t(ctx, "geo_fransac_select");
+    hipLaunchKernelGGL(k_fransac_select, dim3(n_pairs), dim3(GEO_WAVE), 0, s, H, hscan, pass, d_need.p, d_off,
+                       reinterpret_cast<const float2*>(d1), reinterpret_cast<const float2*>(d2), opt->seed, th2, opt->min_points,
+                       opt->min_inliers, d_counts.p, d_tab.p, dF, d_in, d_nin, d_ok);
+  };
+  score(0, H1, nullptr);
+  select(H1, 1);
+  if (H1 < H) {
+    score(H1, H, d_need.p);
+    select(H, 2);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(s));   // the tables and counters above are released on return
+  return MSFM_OK;
+}
+
 MSFM_API int msfm_fundamental_ransac_batch(msfm_ctx* ctx, int n_pairs, const int* offsets, const float* pt1, const float* pt2,
                                            const msfm_fransac_options* opt, double* F, uint8_t* inlier, int* n_inliers, uint8_t* ok) {
   if (!ctx || n_pairs < 0 || !offsets || !opt || !F || !n_inliers || !ok) return MSFM_E_INVAL;
@@ -380,65 +432,38 @@ MSFM_API int msfm_fundamental_ransac_batch(msfm_ctx* ctx, int n_pairs, const int
   if (total > 0 && (!pt1 || !pt2 || !inlier)) return MSFM_E_INVAL;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const int H = opt->max_iterations;
-  // R[g] per pair (N + 1 entries each)
-  std::vector<int> tab((size_t)total + n_pairs);
-  par_ranges((size_t)n_pairs, host_threads(), [&](int, size_t p0, size_t p1) {   // (N + 1) log / pow evaluations per pair
-    for (size_t p = p0; p < p1; p++) {
-      const int o = offsets[p], N = offsets[p + 1] - o;
-      int* R = tab.data() + o + p;
-      for (int g = 0; g <= N; g++) R[g] = N > 0 ? geo_update_num_iters(opt->confidence, (double)(N - g) / N, 7, H) : H;
-    }
-  }, 16);
-  DevBuf<int> d_off, d_tab, d_counts, d_nin;
+  DevBuf<int> d_off, d_nin;
   DevBuf<float> d1, d2;
   DevBuf<double> dF;
   DevBuf<uint8_t> d_in, d_ok;
   HIP_TRY(ctx, d_off.alloc((size_t)n_pairs + 1));
   HIP_TRY(ctx, d_off.upload(offsets, (size_t)n_pairs + 1, s));
-  HIP_TRY(ctx, d_tab.from(tab, s));
   HIP_TRY(ctx, d1.alloc(2 * (size_t)std::max(1, total)));
   HIP_TRY(ctx, d2.alloc(2 * (size_t)std::max(1, total)));
   HIP_TRY(ctx, d1.upload(pt1, 2 * (size_t)total, s));
   HIP_TRY(ctx, d2.upload(pt2, 2 * (size_t)total, s));
-  HIP_TRY(ctx, d_counts.alloc((size_t)n_pairs * H * 3));
   HIP_TRY(ctx, dF.alloc((size_t)n_pairs * 9));
   HIP_TRY(ctx, d_in.alloc((size_t)std::max(1, total)));
   HIP_TRY(ctx, d_nin.alloc(n_pairs));
   HIP_TRY(ctx, d_ok.alloc(n_pairs));
-  const double th2 = opt->threshold * opt->threshold;
-  // Most pairs stop after a few dozen samples (cvRANSACUpdateNumIters): score the first H1 samples of every pair,
-  // replay them, and run the remaining H - H1 samples only for the pairs whose budget is still open.
-  const int H1 = std::min(H, 128);
-  DevBuf<uint8_t> d_need;
-  HIP_TRY(ctx, d_need.alloc(n_pairs));
-  auto score = [&](int h0, int h1, const uint8_t* need) {
-    KTimer t(ctx, "geo_fransac_score");
-    for (int p0 = 0; p0 < n_pairs; p0 += 32768) {  // grid.y limit
-      const int np = std::min(32768, n_pairs - p0);
-      hipLaunchKernelGGL(k_fransac_score, dim3(cdiv(h1 - h0, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, H, h0, h1, p0, d_off.p,
-                         reinterpret_cast<const float2*>(d1.p), reinterpret_cast<const float2*>(d2.p), opt->seed, th2,
-                         opt->min_points, need, d_counts.p);
-    }
-  };
-  auto select = [&](int hscan, int pass) {
-    KTimer t(ctx, "geo_fransac_select");
-    hipLaunchKernelGGL(k_fransac_select, dim3(n_pairs), dim3(GEO_WAVE), 0, s, H, hscan, pass, d_need.p, d_off.p,
-                       reinterpret_cast<const float2*>(d1.p), reinterpret_cast<const float2*>(d2.p), opt->seed, th2, opt->min_points,
-                       opt->min_inliers, d_counts.p, d_tab.p, dF.p, d_in.p, d_nin.p, d_ok.p);
-  };
-  score(0, H1, nullptr);
-  select(H1, 1);
-  if (H1 < H) {
-    score(H1, H, d_need.p);
-    select(H, 2);
-  }
-  HIP_TRY(ctx, hipGetLastError());
+  MSFM_TRY(geo_fransac_dev(ctx, n_pairs, offsets, d_off.p, d1.p, d2.p, opt, dF.p, d_in.p, d_nin.p, d_ok.p));
   HIP_TRY(ctx, hipMemcpyAsync(F, dF.p, sizeof(double) * 9 * (size_t)n_pairs, hipMemcpyDeviceToHost, s));
   if (total) HIP_TRY(ctx, hipMemcpyAsync(inlier, d_in.p, (size_t)total, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(n_inliers, d_nin.p, sizeof(int) * (size_t)n_pairs, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(ok, d_ok.p, (size_t)n_pairs, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  return MSFM_OK;
+}
+
+// The closed-form filter of a batch on resident points (pair_of[e] = pair of match e): msfm_epipolar_filter_batch without its
+// transfers; msfm_chain_verify calls it on the "all" sets gathered from the match codes.
+int geo_epipolar_batch_dev(msfm_ctx* ctx, int total, const int* d_pair_of, const float* d1, const float* d2, const double* dF,
+                           const uint8_t* d_ok, double th, uint8_t* d_in) {
+  if (total == 0) return MSFM_OK;
+  KTimer t(ctx, "geo_epipolar_filter");
+  hipLaunchKernelGGL(k_epipolar_batch, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, total, d_pair_of, reinterpret_cast<const float2*>(d1),
+                     reinterpret_cast<const float2*>(d2), dF, d_ok, th, d_in);
+  HIP_TRY(ctx, hipGetLastError());
   return MSFM_OK;
 }
 

@@ -1352,6 +1352,20 @@ MSFM_API int msfm_descset_upload_keypoints(msfm_descset* s, int image, const flo
   return MSFM_OK;
 }
 
+int match_result_view(msfm_match_result* R, MatchView* v) {
+  if (!R || !v) return MSFM_E_INVAL;
+  MSFM_TRY(check_generation(R));
+  const msfm_descset* s = R->set;
+  v->ctx = R->ctx; v->n_images = s->n_images; v->n_pairs = R->n_pairs; v->total_q = R->total_q;
+  v->pairs = R->pairs.data(); v->out_off = R->out_off.data(); v->nq = R->nq.data();
+  v->code = R->code.p; v->n_all = R->n_all.p; v->n_good = R->n_good.p;
+  v->count = s->count;
+  v->kp.assign(s->n_images, nullptr);
+  for (int i = 0; i < s->n_images; i++) if (s->kp[i]) v->kp[i] = s->kp[i]->p;
+  v->slam = R->slam;
+  return MSFM_OK;
+}
+
 MSFM_API int msfm_match_pairs_rerun(msfm_descset* s, msfm_match_result* R) {
   if (!s || !R || R->set != s) return MSFM_E_INVAL;   // (an orphaned result has set == nullptr)
   MSFM_TRY(check_generation(R));

@@ -203,9 +203,76 @@ static hipError_t scan_excl(const int* in, int* out, size_t n, hipStream_t s, De
 
 }  // namespace trk
 
+// The association on match lists that are already resident (d_pair [n_pairs][2], d_moff [n_pairs+1], d_match [M][2]; the
+// per-image feature counts and their prefix sums also on the host: O(images)).  The CSR tracks stay on the device.
+// msfm_tracks_build_device is this between an upload and a download; msfm_chain_build_tracks (chain.hip) calls it on the
+// verified matches it holds.
+int tracks_build_dev(msfm_ctx* ctx, int n_images, const std::vector<int>& feat_off, const int* d_nf, const int* d_fo, int n_pairs,
+                     const int* d_pair, const int* d_moff, const int* d_match, int M, msfm_track_dev* out) {
+  using namespace trk;
+  hipStream_t s = ctx->stream;
+  out->n_tracks = 0; out->n_obs = 0;
+  if (M == 0) {
+    HIP_TRY(ctx, out->off.alloc(1));
+    HIP_TRY(ctx, hipMemsetAsync(out->off.p, 0, sizeof(int), s));
+    return MSFM_OK;
+  }
+  const int NF = feat_off[n_images];
+#define TTRY(e) HIP_TRY(ctx, (e))
+  DevBuf<int> ga, gb, ia, ib, first, parent, is_new, new_before, point_of, err, val, val_s, head, slot;
+  DevBuf<unsigned long long> key, key_s;
+  DevBuf<char> tmp;
+  TTRY(ga.alloc(M)); TTRY(gb.alloc(M)); TTRY(ia.alloc(M)); TTRY(ib.alloc(M));
+  TTRY(first.alloc(std::max(1, NF))); TTRY(parent.alloc(std::max(1, NF))); TTRY(point_of.alloc(std::max(1, NF)));
+  TTRY(is_new.alloc((size_t)M + 1)); TTRY(new_before.alloc((size_t)M + 1)); TTRY(err.alloc(1));
+  const int big = 0x7fffffff;
+  TTRY(hipMemcpyAsync(err.p, &big, sizeof(int), hipMemcpyHostToDevice, s));
+  TTRY(hipMemsetAsync(is_new.p + M, 0, sizeof(int), s));
+  if (NF) hipLaunchKernelGGL(k_iota_parent, dim3(cdiv(NF, 256)), dim3(256), 0, s, NF, parent.p, first.p);
+  hipLaunchKernelGGL(k_first, dim3(cdiv(M, 256)), dim3(256), 0, s, M, n_pairs, n_images, d_moff, d_pair, d_match, d_nf, d_fo, ga.p, gb.p, ia.p, ib.p,
+                     first.p, err.p);
+  int bad = big;
+  TTRY(hipMemcpyAsync(&bad, err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  TTRY(hipStreamSynchronize(s));
+  if (bad != big) return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_tracks_build_device: match %d names a feature outside its image", bad);
+  hipLaunchKernelGGL(k_parent, dim3(cdiv(M, 256)), dim3(256), 0, s, M, ga.p, gb.p, first.p, parent.p, is_new.p);
+  TTRY(scan_excl(is_new.p, new_before.p, (size_t)M + 1, s, tmp));
+  hipLaunchKernelGGL(k_root, dim3(cdiv(NF, 256)), dim3(256), 0, s, NF, parent.p, first.p, new_before.p, point_of.p);
+  int n_tracks = 0;
+  TTRY(hipMemcpyAsync(&n_tracks, new_before.p + M, sizeof(int), hipMemcpyDeviceToHost, s));
+  TTRY(hipStreamSynchronize(s));
+  const long E = (long)M + n_tracks;
+  TTRY(key.alloc(E)); TTRY(key_s.alloc(E)); TTRY(val.alloc(E)); TTRY(val_s.alloc(E)); TTRY(head.alloc(E + 1)); TTRY(slot.alloc(E + 1));
+  hipLaunchKernelGGL(k_events, dim3(cdiv(M, 256)), dim3(256), 0, s, M, n_images, ga.p, gb.p, ia.p, ib.p, d_match, first.p, new_before.p, point_of.p, key.p,
+                     val.p);
+  {
+    // stable: within one (point, image) the earliest match stays first
+    int bits = 1;
+    while (bits < 64 && ((unsigned long long)n_tracks * (unsigned long long)std::max(1, n_images)) >> bits) bits++;
+    size_t bytes = 0;
+    TTRY(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, val.p, val_s.p, (size_t)E, 0, bits, s));
+    if (tmp.n < bytes) TTRY(tmp.alloc(bytes));
+    TTRY(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, val.p, val_s.p, (size_t)E, 0, bits, s));
+  }
+  TTRY(hipMemsetAsync(head.p + E, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_heads, dim3(cdiv(E, 256)), dim3(256), 0, s, E, key_s.p, head.p);
+  TTRY(scan_excl(head.p, slot.p, (size_t)E + 1, s, tmp));
+  int n_obs = 0;
+  TTRY(hipMemcpyAsync(&n_obs, slot.p + E, sizeof(int), hipMemcpyDeviceToHost, s));
+  TTRY(hipStreamSynchronize(s));
+  TTRY(out->off.alloc((size_t)n_tracks + 1)); TTRY(out->img.alloc(std::max(1, n_obs))); TTRY(out->feat.alloc(std::max(1, n_obs)));
+  hipLaunchKernelGGL(k_compact, dim3(cdiv(E, 256)), dim3(256), 0, s, E, n_images, key_s.p, val_s.p, head.p, slot.p, out->img.p, out->feat.p, out->off.p);
+  TTRY(hipMemcpyAsync(out->off.p + n_tracks, &n_obs, sizeof(int), hipMemcpyHostToDevice, s));
+  TTRY(hipStreamSynchronize(s));   // the scratch above is released on return
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "msfm_tracks_build_device: %s", hipGetErrorString(le));
+#undef TTRY
+  out->n_tracks = n_tracks; out->n_obs = n_obs;
+  return MSFM_OK;
+}
+
 MSFM_API int msfm_tracks_build_device(msfm_ctx* ctx, int n_images, const int* n_features, int n_pairs, const int* pair_img,
                                       const int* match_off, const int* matches, msfm_track_set** out) {
-  using namespace trk;
   if (!ctx) return MSFM_E_INVAL;
   if (n_images < 0 || n_pairs < 0 || !out || (n_images && !n_features) || (n_pairs && (!pair_img || !match_off)))
     return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_tracks_build_device: null argument");
@@ -231,65 +298,21 @@ MSFM_API int msfm_tracks_build_device(msfm_ctx* ctx, int n_images, const int* n_
   std::unique_ptr<msfm_track_set> guard(S);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const int NF = feat_off[n_images];
-#define TTRY(e) HIP_TRY(ctx, (e))
-  DevBuf<int> d_nf, d_fo, d_pair, d_moff, d_match, ga, gb, ia, ib, first, parent, is_new, new_before, point_of, err, val, val_s, head, slot, d_off, d_img, d_feat;
-  DevBuf<unsigned long long> key, key_s;
-  DevBuf<char> tmp;
-  TTRY(d_nf.alloc(n_images)); TTRY(d_nf.upload(n_features, n_images, s));
-  TTRY(d_fo.from(feat_off, s));
-  TTRY(d_pair.alloc(2 * (size_t)n_pairs)); TTRY(d_pair.upload(pair_img, 2 * (size_t)n_pairs, s));
-  TTRY(d_moff.alloc((size_t)n_pairs + 1)); TTRY(d_moff.upload(match_off, (size_t)n_pairs + 1, s));
-  TTRY(d_match.alloc(2 * (size_t)M)); TTRY(d_match.upload(matches, 2 * (size_t)M, s));
-  TTRY(ga.alloc(M)); TTRY(gb.alloc(M)); TTRY(ia.alloc(M)); TTRY(ib.alloc(M));
-  TTRY(first.alloc(std::max(1, NF))); TTRY(parent.alloc(std::max(1, NF))); TTRY(point_of.alloc(std::max(1, NF)));
-  TTRY(is_new.alloc((size_t)M + 1)); TTRY(new_before.alloc((size_t)M + 1)); TTRY(err.alloc(1));
-  const int big = 0x7fffffff;
-  TTRY(hipMemcpyAsync(err.p, &big, sizeof(int), hipMemcpyHostToDevice, s));
-  TTRY(hipMemsetAsync(is_new.p + M, 0, sizeof(int), s));
-  if (NF) hipLaunchKernelGGL(k_iota_parent, dim3(cdiv(NF, 256)), dim3(256), 0, s, NF, parent.p, first.p);
-  hipLaunchKernelGGL(k_first, dim3(cdiv(M, 256)), dim3(256), 0, s, M, n_pairs, n_images, d_moff.p, d_pair.p, d_match.p, d_nf.p, d_fo.p, ga.p, gb.p, ia.p, ib.p,
-                     first.p, err.p);
-  int bad = big;
-  TTRY(hipMemcpyAsync(&bad, err.p, sizeof(int), hipMemcpyDeviceToHost, s));
-  TTRY(hipStreamSynchronize(s));
-  if (bad != big) return msfm_set_error(ctx, MSFM_E_INVAL, "msfm_tracks_build_device: match %d names a feature outside its image", bad);
-  hipLaunchKernelGGL(k_parent, dim3(cdiv(M, 256)), dim3(256), 0, s, M, ga.p, gb.p, first.p, parent.p, is_new.p);
-  TTRY(scan_excl(is_new.p, new_before.p, (size_t)M + 1, s, tmp));
-  hipLaunchKernelGGL(k_root, dim3(cdiv(NF, 256)), dim3(256), 0, s, NF, parent.p, first.p, new_before.p, point_of.p);
-  int n_tracks = 0;
-  TTRY(hipMemcpyAsync(&n_tracks, new_before.p + M, sizeof(int), hipMemcpyDeviceToHost, s));
-  TTRY(hipStreamSynchronize(s));
-  const long E = (long)M + n_tracks;
-  TTRY(key.alloc(E)); TTRY(key_s.alloc(E)); TTRY(val.alloc(E)); TTRY(val_s.alloc(E)); TTRY(head.alloc(E + 1)); TTRY(slot.alloc(E + 1));
-  hipLaunchKernelGGL(k_events, dim3(cdiv(M, 256)), dim3(256), 0, s, M, n_images, ga.p, gb.p, ia.p, ib.p, d_match.p, first.p, new_before.p, point_of.p, key.p,
-                     val.p);
-  {
-    // stable: within one (point, image) the earliest match stays first
-    int bits = 1;
-    while (bits < 64 && ((unsigned long long)n_tracks * (unsigned long long)std::max(1, n_images)) >> bits) bits++;
-    size_t bytes = 0;
-    TTRY(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, val.p, val_s.p, (size_t)E, 0, bits, s));
-    if (tmp.n < bytes) TTRY(tmp.alloc(bytes));
-    TTRY(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, val.p, val_s.p, (size_t)E, 0, bits, s));
+  DevBuf<int> d_nf, d_fo, d_pair, d_moff, d_match;
+  HIP_TRY(ctx, d_nf.alloc(n_images)); HIP_TRY(ctx, d_nf.upload(n_features, n_images, s));
+  HIP_TRY(ctx, d_fo.from(feat_off, s));
+  HIP_TRY(ctx, d_pair.alloc(2 * (size_t)n_pairs)); HIP_TRY(ctx, d_pair.upload(pair_img, 2 * (size_t)n_pairs, s));
+  HIP_TRY(ctx, d_moff.alloc((size_t)n_pairs + 1)); HIP_TRY(ctx, d_moff.upload(match_off, (size_t)n_pairs + 1, s));
+  HIP_TRY(ctx, d_match.alloc(2 * (size_t)M)); HIP_TRY(ctx, d_match.upload(matches, 2 * (size_t)M, s));
+  msfm_track_dev D;
+  MSFM_TRY(tracks_build_dev(ctx, n_images, feat_off, d_nf.p, d_fo.p, n_pairs, d_pair.p, d_moff.p, d_match.p, M, &D));
+  S->off.resize((size_t)D.n_tracks + 1); S->img.resize(D.n_obs); S->feat.resize(D.n_obs);
+  HIP_TRY(ctx, hipMemcpyAsync(S->off.data(), D.off.p, sizeof(int) * ((size_t)D.n_tracks + 1), hipMemcpyDeviceToHost, s));
+  if (D.n_obs) {
+    HIP_TRY(ctx, hipMemcpyAsync(S->img.data(), D.img.p, sizeof(int) * (size_t)D.n_obs, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(S->feat.data(), D.feat.p, sizeof(int) * (size_t)D.n_obs, hipMemcpyDeviceToHost, s));
   }
-  TTRY(hipMemsetAsync(head.p + E, 0, sizeof(int), s));
-  hipLaunchKernelGGL(k_heads, dim3(cdiv(E, 256)), dim3(256), 0, s, E, key_s.p, head.p);
-  TTRY(scan_excl(head.p, slot.p, (size_t)E + 1, s, tmp));
-  int n_obs = 0;
-  TTRY(hipMemcpyAsync(&n_obs, slot.p + E, sizeof(int), hipMemcpyDeviceToHost, s));
-  TTRY(hipStreamSynchronize(s));
-  TTRY(d_off.alloc((size_t)n_tracks + 1)); TTRY(d_img.alloc(n_obs)); TTRY(d_feat.alloc(n_obs));
-  hipLaunchKernelGGL(k_compact, dim3(cdiv(E, 256)), dim3(256), 0, s, E, n_images, key_s.p, val_s.p, head.p, slot.p, d_img.p, d_feat.p, d_off.p);
-  TTRY(hipMemcpyAsync(d_off.p + n_tracks, &n_obs, sizeof(int), hipMemcpyHostToDevice, s));
-  S->off.resize((size_t)n_tracks + 1); S->img.resize(n_obs); S->feat.resize(n_obs);
-  TTRY(hipMemcpyAsync(S->off.data(), d_off.p, sizeof(int) * ((size_t)n_tracks + 1), hipMemcpyDeviceToHost, s));
-  TTRY(hipMemcpyAsync(S->img.data(), d_img.p, sizeof(int) * (size_t)n_obs, hipMemcpyDeviceToHost, s));
-  TTRY(hipMemcpyAsync(S->feat.data(), d_feat.p, sizeof(int) * (size_t)n_obs, hipMemcpyDeviceToHost, s));
-  TTRY(hipStreamSynchronize(s));
-  hipError_t le = hipGetLastError();
-  if (le != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "msfm_tracks_build_device: %s", hipGetErrorString(le));
-#undef TTRY
+  HIP_TRY(ctx, hipStreamSynchronize(s));
   *out = guard.release();
   return MSFM_OK;
 }

@@ -4,11 +4,6 @@
 // GeoVerification::GeoVerificationFundamental (closed form) SfM/src/utils/geo_verification.cc:60-79.
 #include "common.h"
 
-struct TrackPtrs {
-  int n_tracks;
-  const int *off, *cam;
-  const double *xy, *R, *t, *c, *fk;
-};
 
 // structure.cc:267-300
 __device__ double track_mse(const TrackPtrs& T, int b, int e, const double* X) {
@@ -286,6 +281,16 @@ static int triangulate(msfm_ctx* ctx, const msfm_tracks* T, double th_error, dou
   HIP_TRY(ctx, hipMemcpyAsync(mse, dm.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipMemcpyAsync(ok, dok.p, (size_t)n, hipMemcpyDeviceToHost, s));
   HIP_TRY(ctx, hipStreamSynchronize(s));
+  return MSFM_OK;
+}
+
+// Point3D::Trianglate2 + Reprojection + the angle gate on tracks that are already resident (all pointers device memory);
+// X is in/out.  msfm_chain_triangulate (chain.hip) calls it on the tracks it built.
+int tri_midpoint_dev(msfm_ctx* ctx, const TrackPtrs& T, double th_error, double th_angle, double* dX, double* dmse, uint8_t* dok) {
+  if (T.n_tracks == 0) return MSFM_OK;
+  KTimer t(ctx, "tri_midpoint");
+  hipLaunchKernelGGL(k_tri_midpoint, dim3(cdiv(T.n_tracks, 256)), dim3(256), 0, ctx->stream, T, th_error, cos(th_angle), dX, dmse, dok);
+  HIP_TRY(ctx, hipGetLastError());
   return MSFM_OK;
 }
 
