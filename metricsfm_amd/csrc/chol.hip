@@ -233,6 +233,16 @@ __device__ __forceinline__ void potrf16_v2(double* Ls, double* dinv, double* dve
   }
 }
 
+// A sub-panel of the system's last block that holds padding columns only: nothing to factor (potrf16_v2 would walk sixteen
+// pivots d = 1), the block of the inverse is the identity.
+template <int JB>
+__device__ __forceinline__ void potrf16_skip(double* dinv, int lane) {
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) dinv[(16 * JB + r) * DV + lane] = lane == r ? 1.0 : 0.0;
+  }
+}
+
 // acc += sum_{s < NS} A_s B_s with A[m][k] = -X[(ra + m) * LDT + k0 + 4 s + k], B[k][n] = Y[(rb + n) * LDT + k0 + 4 s + k]
 template <int NS>
 __device__ __forceinline__ d4 mm_nt_neg(const double* X, int ra, const double* Y, int rb, int k0, int lr, int lk, d4 acc) {
@@ -349,17 +359,20 @@ __device__ __forceinline__ void panel_col0(double* __restrict__ M, int ld, const
     MSFM_PROBE(3);
     __syncthreads();  // A1
     MSFM_PROBE(4);
-    potrf16_v2<1, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+    if (FULL || 16 < ncol) potrf16_v2<1, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+    else potrf16_skip<1>(dinv, lane);   // nothing but padding from here on (last block of the system)
     __syncthreads();
     MSFM_PROBE(5);
     __syncthreads();  // A2
     MSFM_PROBE(6);
-    potrf16_v2<2, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+    if (FULL || 32 < ncol) potrf16_v2<2, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+    else potrf16_skip<2>(dinv, lane);   // nothing but padding from here on (last block of the system)
     __syncthreads();
     MSFM_PROBE(7);
     __syncthreads();  // A3
     MSFM_PROBE(8);
-    potrf16_v2<3, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+    if (FULL || 48 < ncol) potrf16_v2<3, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+    else potrf16_skip<3>(dinv, lane);   // nothing but padding from here on (last block of the system)
     __syncthreads();
     MSFM_PROBE(9);
   } else {
