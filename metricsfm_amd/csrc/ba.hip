@@ -2692,8 +2692,11 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
       hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, sp, ba->cc.n_chunks, ba->cc.ch_start.p,
                          ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
   };
-  static const bool no_overlap = getenv("MSFM_NO_OVERLAP") != nullptr;
-  const bool forked = mode == 0 && !ctx->profile && !no_overlap;
+  // Round 3: measured again at config 3 over 40 iterations, the fork gives nothing (1.277 ms per iteration with it, 1.255-1.273
+  // without: the pair kernels fill the chip by themselves, the per-camera sums beside them only take bandwidth away), so the
+  // plain order is the default and MSFM_OVERLAP=1 brings the second stream back for comparison.
+  static const bool overlap = getenv("MSFM_OVERLAP") != nullptr;
+  const bool forked = mode == 0 && !ctx->profile && overlap;
   if (forked) {
     if (!ctx->stream2) {
       HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
