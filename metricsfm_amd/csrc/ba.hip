@@ -1064,6 +1064,7 @@ struct msfm_ba {
   msfm_chol_plan plan;
   DevBuf<int> cb_off, padcol;
   DevBuf<double> zsys, corners;
+  int zflip = 0;   // which half of zsys the next solve writes (the other half is being marked "pending" meanwhile)
   int A = 0, AE = 0, NCR = 0, NPM = 0;
   bool has_gps = false;
   double gps_weight = 0;
@@ -2500,7 +2501,7 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
   AL(ptL, 6 * (size_t)npb); AL(ptg, 3 * (size_t)npb);
   AL(f_partial, (size_t)ba->n_fchunks * PSTRIDE); AL(camftf, (size_t)ncb * PSTRIDE); AL(modelsum, 12 * (size_t)nmb);
-  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad + 8); AL(zsys, ba->npad + 8);
+  AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad + 8); AL(zsys, 2 * ((size_t)ba->npad + 8));   /* two solution buffers that alternate from solve to solve (k_backsolve_chain) */
   AL(g_r, 3 * (size_t)ncb); AL(g_J, 3 * (size_t)ncb);
   ba->nblk_obs = cdiv(As, 256);
   ba->nblk_pt = cdiv(std::max(1, npb), 32);  // 8 lanes per point
@@ -2510,6 +2511,8 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   AL(scal, S_N); AL(sloc, S_N);
   HIP_TRY(ctx, ba->fail.alloc(4));
 #undef AL
+  // the first solve's solution buffer starts out "pending"; from then on every solve marks the other one (k_backsolve_chain)
+  MSFM_TRY(msfm_chol_fill_pending(ctx, ba->zsys.p, ba->npad));
   {
     // every device buffer a kernel may dereference must exist before the first launch
     const void* must[] = {ba->cam.p, ba->model.p, ba->pt.p, ba->cam_c.p, ba->model_c.p, ba->pt_c.p, ba->lin_r.p, ba->lin_Jc.p,
@@ -2861,9 +2864,14 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
   hipStream_t s = ctx->stream;
   const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
   const bool lead = ctx->rank == 0;
+  const double* zsolved = ba->zsys.p;
   if (ba->nred > 0) {
-    MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, ba->zsys.p, ba->fail.p,
-                                    ba->plan.n_levels > 0 ? &ba->plan : nullptr));
+    double* const zcur = ba->zsys.p + (size_t)ba->zflip * (ba->npad + 8);
+    double* const znext = ba->zsys.p + (size_t)(ba->zflip ^ 1) * (ba->npad + 8);
+    ba->zflip ^= 1;
+    MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, zcur, ba->fail.p,
+                                    ba->plan.n_levels > 0 ? &ba->plan : nullptr, znext));
+    zsolved = zcur;
   }
   {
     KTimer t(ctx, "ba_backsub");
@@ -2872,7 +2880,7 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
     const double wrep = lead ? 1.0 : 0.0;
     // partial2 = |dx|^2 partials, partial3 = |x|^2 partials, partial = model cost partials
     if (ba->nred > 0) {
-      hipLaunchKernelGGL(k_update_params, dim3(nbu), dim3(256), 0, s, ncb, nmb, ba->cb_cam.p, ba->mb_model.p, ba->cb_off.p, ba->mo, ba->zsys.p,
+      hipLaunchKernelGGL(k_update_params, dim3(nbu), dim3(256), 0, s, ncb, nmb, ba->cb_cam.p, ba->mb_model.p, ba->cb_off.p, ba->mo, zsolved,
                          ba->scale_c.p, ba->scale_m.p, ba->cam.p, ba->cam_c.p, ba->model.p, ba->model_c.p, ba->z.p, ba->fail.p,
                          ba->partial2.p + off, ba->partial3.p + off, wrep);
       off += nbu;

@@ -742,21 +742,11 @@ __device__ __forceinline__ void tile_mm(double* Cm, int rc, int cc, const double
   for (int i = 0; i < 4; i++) Cm[(rc + lk + 4 * i) * LDT + cc + lr] = acc[i];
 }
 
-__global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ Ldiag, int n, const double* __restrict__ Dinv,
-                                                       double* __restrict__ Linv, int nblk, const double* __restrict__ M, int ld,
-                                                       double* __restrict__ w, int npad, unsigned long long* __restrict__ zfill) {
-  __shared__ double L[NB * LDT];
-  __shared__ double v[NB * LDT];
-  __shared__ double t[NB * LDT];
-  if ((int)blockIdx.x >= nblk) {
-    const int i = ((int)blockIdx.x - nblk) * 256 + (int)threadIdx.x;
-    if (i < npad) {
-      w[i] = (i < n) ? M[(size_t)n * ld + i] : 0.0;
-      if (zfill) zfill[i] = MSFM_Z_PENDING;   // "not solved yet" for k_backsolve_chain
-    }
-    return;
-  }
-  const int blk = blockIdx.x, j0 = blk * NB, tid = threadIdx.x;
+// The full inverse of the 64 x 64 diagonal block `blk` of the factor in v (LDS, stride LDT), by all 256 threads of a
+// workgroup; L and t are scratch of the same size.
+__device__ __forceinline__ void trinv64_block(const double* __restrict__ Ldiag, const double* __restrict__ Dinv, int blk, int n, double* L, double* v,
+                                              double* t) {
+  const int j0 = blk * NB, tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   const int ncol = min(NB, n - j0);
   for (int e = tid; e < NB * NB; e += 256) {
@@ -785,8 +775,25 @@ __global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__
     tile_mm<32>(v, 32 + 16 * tr, 16 * tc, v, 32 + 16 * tr, 32, t, 32, 16 * tc, true, lr, lk);
   }
   __syncthreads();
-  double* out = Linv + (size_t)blk * NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) out[e] = v[(e >> 6) * LDT + (e & 63)];
+}
+
+__global__ __launch_bounds__(256) void k_trinv64_full(const double* __restrict__ Ldiag, int n, const double* __restrict__ Dinv,
+                                                       double* __restrict__ Linv, int nblk, const double* __restrict__ M, int ld,
+                                                       double* __restrict__ w, int npad, unsigned long long* __restrict__ zfill) {
+  __shared__ double L[NB * LDT];
+  __shared__ double v[NB * LDT];
+  __shared__ double t[NB * LDT];
+  if ((int)blockIdx.x >= nblk) {
+    const int i = ((int)blockIdx.x - nblk) * 256 + (int)threadIdx.x;
+    if (i < npad) {
+      w[i] = (i < n) ? M[(size_t)n * ld + i] : 0.0;
+      if (zfill) zfill[i] = MSFM_Z_PENDING;   // "not solved yet" for k_backsolve_chain
+    }
+    return;
+  }
+  trinv64_block(Ldiag, Dinv, (int)blockIdx.x, n, L, v, t);
+  double* out = Linv + (size_t)blockIdx.x * NB * NB;
+  for (int e = threadIdx.x; e < NB * NB; e += 256) out[e] = v[(e >> 6) * LDT + (e & 63)];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -945,11 +952,13 @@ struct BackTree {
   struct { int K; struct { int b0, b1, leaf_lo, leaf_hi; } node[8]; } level[3];   // block ranges of the nodes
 };
 __global__ __launch_bounds__(256) void k_backsolve_chain(const double* __restrict__ M, int ld, int n, int nblk, BackTree tree,
-                                                          const double* __restrict__ Linv, const double* __restrict__ w,
-                                                          double* __restrict__ z, int* __restrict__ fail, unsigned spin_limit) {
+                                                          const double* __restrict__ Ldiag, const double* __restrict__ Dinv,
+                                                          double* __restrict__ z, unsigned long long* __restrict__ z_next,
+                                                          int* __restrict__ fail, unsigned spin_limit) {
   __shared__ double part[4][NB];
   __shared__ double zj[NB], wi[NB];
   __shared__ int rlo[5], rhi[5], nr;
+  __shared__ double Lb[NB * LDT], Vb[NB * LDT], Tb[NB * LDT];   // the block's own 64 x 64 inverse is formed here (Vb), not by a launch before
   const int tid = threadIdx.x, col = tid & 63, kq = tid >> 6;
   const int i = nblk - 1 - (int)blockIdx.x, i0 = i * NB;
   if (tid == 0) {
@@ -972,13 +981,9 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(const double* __restric
     }
     nr = c;
   }
-  if (tid < NB) wi[tid] = w[i0 + tid];
-  // the inverse of the own diagonal block is needed last: fetch it first
-  double lv_[16];
-  {
-    const double* Li = Linv + (size_t)i * NB * NB;
-#pragma unroll
-    for (int k = 0; k < 16; k++) lv_[k] = Li[(16 * kq + k) * NB + col];
+  if (tid < NB) {
+    wi[tid] = (i0 + tid < n) ? M[(size_t)n * ld + i0 + tid] : 0.0;   // the eliminated right-hand side: row n of the factor
+    if (z_next) z_next[i0 + tid] = MSFM_Z_PENDING;                     // the other solution buffer is ready for the next solve
   }
   __syncthreads();
   auto fetch = [&](int j, double (&mv)[16]) {
@@ -1002,6 +1007,9 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(const double* __restric
   advance();
   double mv[16], mvn[16];
   if (j >= 0) fetch(j, mv);
+  // the own block's inverse while the first tile is in flight (and, for all but the last block, while z of the later
+  // blocks is still being produced): what k_trinv64_full did in a launch of its own on the critical path
+  trinv64_block(Ldiag, Dinv, i, n, Lb, Vb, Tb);
   while (j >= 0) {
     const int jc = j;
     advance();
@@ -1032,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_backsolve_chain(const double* __restric
   // z_i = Linv_i^T w_i
   double s = 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) s += lv_[k] * wi[16 * kq + k];
+  for (int k = 0; k < 16; k++) s += Vb[(16 * kq + k) * LDT + col] * wi[16 * kq + k];
   part[kq][col] = s;
   __syncthreads();
   if (tid < NB) {
@@ -1070,8 +1078,23 @@ static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /
   return jb;
 }
 
+__global__ __launch_bounds__(256) void k_fill_pending(int n, unsigned long long* __restrict__ z) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) z[i] = MSFM_Z_PENDING;
+}
+int msfm_chol_fill_pending(msfm_ctx* ctx, double* z, int npad) {
+  hipLaunchKernelGGL(k_fill_pending, dim3(cdiv(npad, 256)), dim3(256), 0, ctx->stream, npad, reinterpret_cast<unsigned long long*>(z));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "fill: %s", hipGetErrorString(e));
+  return MSFM_OK;
+}
+
+// z_next (optional): a second solution buffer of npad doubles.  With it the caller promises that `z` already holds
+// MSFM_Z_PENDING everywhere (msfm_chol_fill_pending once, afterwards the previous call's z_next) and gets z_next back in that
+// state - the two buffers alternate from solve to solve and no fill launch sits on the critical path.  Without it the
+// function fills z itself first.
 int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z, int* fail,
-                           const msfm_chol_plan* plan) {
+                           const msfm_chol_plan* plan, double* z_next) {
   if (!M || !work || !w || !z || !fail || npad % NB != 0 || n < 1 || n + 1 > npad)
     return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad workspace (null buffer or size)");
   hipStream_t s = ctx->stream;
@@ -1194,9 +1217,10 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     const int nblk = cdiv(n, NB);
     static const bool launches_env = getenv("MSFM_BACKSOLVE_LAUNCHES") != nullptr;   // the round-2 chain of launches, for comparison
     const bool chain = !launches_env && nblk <= MSFM_BACKSOLVE_CHAIN_MAX;
-    hipLaunchKernelGGL(k_trinv64_full, dim3(nblk + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, nblk, M, npad, w, npad,
-                       chain ? reinterpret_cast<unsigned long long*>(z) : (unsigned long long*)nullptr);
+    if (!chain) hipLaunchKernelGGL(k_trinv64_full, dim3(nblk + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, nblk, M, npad, w, npad,
+                                   (unsigned long long*)nullptr);
     if (chain) {
+      if (!z_next) MSFM_TRY(msfm_chol_fill_pending(ctx, z, npad));
       BackTree bt;
       bt.n_levels = n_levels;
       bt.root_blk = t_first / NB;
@@ -1215,7 +1239,10 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
         const double v = e ? atof(e) : 120.0;
         return (unsigned)std::min(4.0e9, std::max(1.0e4, (v > 0 ? v : 120.0) * 3.0e6));
       }();
-      hipLaunchKernelGGL(k_backsolve_chain, dim3(nblk), dim3(256), 0, s, M, npad, n, nblk, bt, Linv, w, z, fail, spin_limit);
+      hipLaunchKernelGGL(k_backsolve_chain, dim3(nblk), dim3(256), 0, s, M, npad, n, nblk, bt, Ldiag, Dinv, z,
+                         reinterpret_cast<unsigned long long*>(z_next), fail, spin_limit);
+    } else if (z_next) {
+      MSFM_TRY(msfm_chol_fill_pending(ctx, z_next, npad));   // keep the caller's alternation intact on the launch-chain path
     }
     const int first_dense = t_first / NB;
     for (int jb = nblk - 1; !chain && jb >= first_dense;) {  // root chain (or everything): couples to every block before it

@@ -213,4 +213,5 @@ struct msfm_chol_plan {
   int ldc = 0;
 };
 int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z, int* fail,
-                           const msfm_chol_plan* plan);
+                           const msfm_chol_plan* plan, double* z_next = nullptr);
+int msfm_chol_fill_pending(msfm_ctx* ctx, double* z, int npad);   // "not solved yet" marks of k_backsolve_chain
