@@ -1883,7 +1883,7 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
   ba->npad = 64 * cdiv(ba->nsys + 1, 64);
   if (ba->plan.n_levels > 0) {
     ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.level[0].b0, 64);
-    DTRY(ba->corners.alloc((size_t)4 * ba->plan.ldc * ba->plan.ldc));   // up to four K-splits of the corner update
+    DTRY(ba->corners.alloc((size_t)8 * ba->plan.ldc * ba->plan.ldc));   // up to eight K-splits of the corner update (MSFM_CORNER_SPLIT_MAX)
     ba->plan.corners = ba->corners.p;
   }
   ba->gps_weight = P->gps_weight;
@@ -2171,7 +2171,7 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
   ba->npad = 64 * cdiv(ba->nsys + 1, 64);
   if (ba->plan.n_levels > 0) {
     ba->plan.ldc = 64 * cdiv(ba->nsys + 1 - ba->plan.level[0].b0, 64);
-    HIP_TRY(ctx, ba->corners.alloc((size_t)4 * ba->plan.ldc * ba->plan.ldc));   // up to four K-splits of the corner update
+    HIP_TRY(ctx, ba->corners.alloc((size_t)8 * ba->plan.ldc * ba->plan.ldc));   // up to eight K-splits of the corner update (MSFM_CORNER_SPLIT_MAX)
     ba->plan.corners = ba->corners.p;
   }
   ba->has_gps = P->gps_xyz != nullptr;

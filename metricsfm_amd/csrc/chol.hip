@@ -639,21 +639,33 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
 // grid = lower 64x64 tiles of the separator square x nsplit; the next panel's tiles are fetched during the MFMAs.
 // Only panels of leaves / nodes under BOTH blocks' tree nodes contribute (everything else is structurally zero):
 // blk_plo / blk_phi give, per 64-row block of the square, the panel range of the level that lies under its node.
+// K-split per tile (round 3): a tile under the root receives every panel of the level, a tile under a deep separator only
+// its own subtree's - with one split count for all tiles the root x root workgroups walked twice as many panels as the rest
+// and set the launch's length (config 3, level 0: 11 panel products against 5-6).  Now tile (I, J) is cut into
+// ceil(panels / target) pieces, at most MSFM_CORNER_SPLIT_MAX; the grid holds MSFM_CORNER_SPLIT_MAX workgroups per tile and
+// the surplus ones leave at once (a thousand empty workgroups start and end within a microsecond).
+#define MSFM_CORNER_SPLIT_MAX 8
 struct CornerRanges { short plo[MSFM_CORNER_MAX_BLOCKS], phi[MSFM_CORNER_MAX_BLOCKS]; };
-__global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ M, int ld, int b0, int nsplit,
+__host__ __device__ __forceinline__ int corner_splits(int panels, int target) {
+  const int s = (panels + target - 1) / target;
+  return s < 1 ? 1 : (s > MSFM_CORNER_SPLIT_MAX ? MSFM_CORNER_SPLIT_MAX : s);
+}
+__global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ M, int ld, int b0, int target, int smax,
                                                       double* __restrict__ corners, int ldc, CornerRanges R) {
   __shared__ double sm[2 * 64 * LDT];
   double* As = sm;
   double* Bs = sm + 64 * LDT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lk = lane >> 4;
-  const int tile = blockIdx.x / nsplit, r = blockIdx.x % nsplit;
+  const int tile = blockIdx.x / smax, r = blockIdx.x % smax;
   int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
   while (I * (I + 1) / 2 > tile) I--;
   while ((I + 1) * (I + 2) / 2 <= tile) I++;
   const int J = tile - I * (I + 1) / 2;
   const int ri = b0 + 64 * I, rj = b0 + 64 * J;
   const int p_begin = max((int)R.plo[I], (int)R.plo[J]), np = min((int)R.phi[I], (int)R.phi[J]);
+  const int nsplit = corner_splits(np - p_begin, target);
+  if (r >= nsplit) return;
   d4 acc00 = {0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
   d2 va[8], vb[8];
   auto fetch = [&](int p) {
@@ -692,7 +704,7 @@ __global__ __launch_bounds__(256) void k_corner_syrk(const double* __restrict__ 
 
 // M[b0.., b0..] += sum_k corner_k (lower 64x64 tiles of the separator square), after the domain chains
 __global__ __launch_bounds__(256) void k_merge_corners(double* __restrict__ M, int ld, int b0, int nB64, const double* __restrict__ corners,
-                                                        int ldc, int ncorner) {
+                                                        int ldc, int target, CornerRanges R) {
   // 4 workgroups per lower 64x64 tile, 4 elements per thread, all loads issued before the sums
   const int tile = blockIdx.x >> 2, part = blockIdx.x & 3;
   int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
@@ -700,6 +712,7 @@ __global__ __launch_bounds__(256) void k_merge_corners(double* __restrict__ M, i
   while ((I + 1) * (I + 2) / 2 <= tile) I++;
   const int J = tile - I * (I + 1) / 2;
   (void)nB64;
+  const int ncorner = corner_splits(min((int)R.phi[I], (int)R.phi[J]) - max((int)R.plo[I], (int)R.plo[J]), target);
   double v[4][8];
 #pragma unroll
   for (int u = 0; u < 4; u++) {
@@ -1187,10 +1200,28 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
             if (L.node[q].leaf_lo >= lo && L.node[q].leaf_hi <= hi) { if (!any) plo = L.node[q].begin / NB; phi = L.node[q].end / NB; any = true; }
           R.plo[I] = (short)plo; R.phi[I] = (short)phi;
         }
-        // K-split so that the workgroups (two fit on a CU) cover the chip once: 1 / 2 / 3 / 4 splits measured 94 / 82 / 58 / 71 us at C3
-        const int nsplit = std::max(1, std::min(4, 512 / std::max(1, ntile)));
-        hipLaunchKernelGGL(k_corner_syrk, dim3(ntile * nsplit), dim3(256), 0, s, M, npad, sb, nsplit, plan->corners, ldc, R);
-        hipLaunchKernelGGL(k_merge_corners, dim3(4 * ntile), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, nsplit);
+        // panels per workgroup: the smallest count with which the pieces (two workgroups fit on a CU) cover the chip about once
+        int target = 1, smax = 1;
+        for (;; target++) {
+          long wgs = 0;
+          smax = 1;
+          for (int I = 0; I < nB64; I++)
+            for (int J = 0; J <= I; J++) {
+              const int sp = corner_splits(std::min((int)R.phi[I], (int)R.phi[J]) - std::max((int)R.plo[I], (int)R.plo[J]), target);
+              wgs += sp;
+              smax = std::max(smax, sp);
+            }
+          if (wgs <= 560 || target >= 64) break;
+        }
+        static const int target_env = getenv("MSFM_CORNER_TARGET") ? atoi(getenv("MSFM_CORNER_TARGET")) : 0;
+        if (target_env > 0) {
+          target = target_env; smax = 1;
+          for (int I = 0; I < nB64; I++)
+            for (int J = 0; J <= I; J++)
+              smax = std::max(smax, corner_splits(std::min((int)R.phi[I], (int)R.phi[J]) - std::max((int)R.plo[I], (int)R.plo[J]), target));
+        }
+        hipLaunchKernelGGL(k_corner_syrk, dim3(ntile * smax), dim3(256), 0, s, M, npad, sb, target, smax, plan->corners, ldc, R);
+        hipLaunchKernelGGL(k_merge_corners, dim3(4 * ntile), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, target, R);
       }
       t_first = sb;
     }
