@@ -439,7 +439,7 @@ def main():
                                          "maximum over ranks, `accepted` is rank 0's range" % world, **legs)
 
     # ------------------------------------------------------------------ resident chain: codes -> verification -> tracks -> points -> BA problem
-    if not args.no_extras and not args.no_matching and not win and rank == 0 and descs is not None:
+    if not args.no_extras and not args.no_matching and not win and rank == 0 and descs is not None and args.chain_images > 1:
         from metricsfm_amd import matchfiles
         n_ci = min(args.chain_images, len(descs))
         kps = [np.ascontiguousarray(sc.kp_xy[i], np.float32) for i in range(n_ci)]
@@ -537,7 +537,7 @@ def main():
         v1 = np.concatenate([tv[p % 64][0] for p in range(n_vp)])
         v2 = np.concatenate([tv[p % 64][1] for p in range(n_vp)])
         voff = (np.arange(n_vp + 1) * n_vm).astype(np.int32)
-        ctx.fundamental_ransac(voff[:9], v1[:8 * n_vm], v2[:8 * n_vm])   # warm-up
+        ctx.fundamental_ransac(voff, v1, v2)   # untimed first call at full size (kernel code, device blocks of the call's sizes)
         ctx.profile(True)
         ctx.profile_reset()
         t0 = time.perf_counter()
@@ -586,8 +586,8 @@ def main():
         ra = np.concatenate([rl[p % 64][0] for p in range(n_img)])
         rb = np.concatenate([rl[p % 64][1] for p in range(n_img)])
         poff = (np.arange(n_img + 1) * n_corr).astype(np.int32)
-        ctx.epnp_ransac(poff[:9], pX[:8 * n_corr], px[:8 * n_corr], 4800.0)      # warm-up
-        ctx.relpose_5pt(poff[:9], ra[:8 * n_corr], rb[:8 * n_corr], 4800.0, 4800.0)
+        ctx.epnp_ransac(poff, pX, px, 4800.0)      # untimed first calls at full size
+        ctx.relpose_5pt(poff, ra, rb, 4800.0, 4800.0)
         ctx.profile(True)
         ctx.profile_reset()
         t0 = time.perf_counter()

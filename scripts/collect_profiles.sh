@@ -23,4 +23,7 @@ python3 bench.py --config 5 --window --steps 20 --warmup 3 > $O/bench_c5_window.
 echo "config 5 window done"
 python3 scripts/extra_bench.py --c5 > $O/extra.json 2> $O/extra.err
 echo "extra done"
+# matrix-pipe utilisation of the three MFMA kernels (SQ counter passes; writes gpurun_out/mfma/r03_mfma_util.json)
+bash scripts/mfma_util.sh > $O/mfma_util.log 2>&1 || echo "mfma_util failed"
+echo "mfma util done"
 find $O -name "*kernel_stats.csv" | head -3
