@@ -267,6 +267,10 @@ struct PointPtrs {
   int store_rows;      // first pass at this linearisation point: also write the camera-major rows (k_ftf) and the cost
   double* cost_partial;
   int* fail;
+  // FoldTables (all nullptr: every product goes through the pair lists)
+  const int *fold_wg, *fold_ovf_off, *fold_wg_slot_first, *fold_slot_ent_first, *fold_slot_rank;
+  const unsigned* fold_ent;
+  double* fold_partial;
 };
 
 // (8-lane groups; after the first two steps the four lanes of a quad hold the same value, so adding lane 7 - i is adding lane i ^ 4)
@@ -276,7 +280,10 @@ struct PointPtrs {
 // (obs_linearize: the row data is read coalesced, the parameters come from cache), the per-point sums are 3-step
 // reductions inside the 8-lane group, and every lane then finishes its own observation's T = (Jc^T Jp) L^-T.
 // 256 threads = 32 points.  Tracks of up to 8 views keep their rows in registers; longer ones linearise them again.
-__device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restrict__ gmax_partial, double* sh, double* park) {
+#define FOLD_OVF 51   // second-round records (rows 8..15 of a point) a workgroup can park beside the 256 first-round ones
+#define FOLD_NREC (256 + FOLD_OVF)   // records of 2 x 10 doubles (two 16-byte aligned halves of 9) in the 48 KB row park
+#define FOLD_ENT_CAP 1024   // entries of one pass of 64 slots staged in LDS (more: read from memory)
+__device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restrict__ gmax_partial, double* sh, double* park, unsigned* ent_s) {
   const int tid = threadIdx.x, sub = tid & 7;
   const int pb = blockIdx.x * 32 + (tid >> 3);
   const bool act = pb < P.npb;
@@ -353,60 +360,6 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
     }
   }
   if (P.mode != 1) {
-    // camera entries: T = (Jc^T Jp) L^-T (one 144-byte record per observation, camera-major), T.u
-    // Stores: neighbouring lanes hold the observations of ONE point - eight different cameras, eight far-apart addresses,
-    // one 8-byte write request per lane and component (21.6 M at C3).  The lanes of a wave therefore trade records first,
-    // (point q, observation s) -> lane 8 s + q: now neighbouring lanes hold the same observation slot of consecutive
-    // points, which sit at consecutive positions of one camera wherever the points share their cameras, and the stores
-    // of a quad merge (k_point 0.229 -> 0.223 ms at C3; a record-major T was also measured: the same here, but k_pairs
-    // 0.28 -> 0.49 ms).
-    const int wl = tid & 63, tsrc = ((wl & 7) << 3) | (wl >> 3);
-    for (int rd = 0; __any(f + rd < l); rd += 8) {
-      const int i = f + rd + sub;
-      int cp = -1;
-      if (i < l) cp = P.B.o_cpos[i];
-      double T[18], tu[6];
-#pragma unroll
-      for (int k = 0; k < 18; k++) T[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) tu[k] = 0.0;
-      if (cp >= 0) {
-        double jcs[12], jms[6], jps[6];
-        if (!single) { double r0, r1; obs_linearize(P.B, i, r0, r1, jcs, jms, jps); }
-        else {
-#pragma unroll
-          for (int k = 0; k < 12; k++) jcs[k] = park[k * 256 + tid];
-#pragma unroll
-          for (int k = 0; k < 6; k++) jps[k] = park[(18 + k) * 256 + tid];
-        }
-        const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-          const double ja = jcs[a], jb = jcs[6 + a];
-          const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
-          const double t0 = w0 * i00;
-          const double t1 = (w1 - l10 * t0) * i11;
-          const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
-          T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
-          tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
-        }
-      }
-      const int cpt = __shfl(cp, tsrc, 64);
-#pragma unroll
-      for (int k = 0; k < 18; k++) T[k] = __shfl(T[k], tsrc, 64);
-#pragma unroll
-      for (int k = 0; k < 6; k++) tu[k] = __shfl(tu[k], tsrc, 64);
-      if (cpt >= 0) {
-        double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cpt);
-#pragma unroll
-        for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
-        // component-major (T[k][position], positions camera-major): records of consecutive points of a camera are
-        // neighbours in every component plane, so these stores and the pair kernel's loads coalesce over the runs of
-        // points that share their cameras
-#pragma unroll
-        for (int k = 0; k < 18; k++) P.T[(size_t)k * P.NCR + cpt] = T[k];
-      }
-    }
     // (point, intrinsics-block) entries: Tm = (sum Jm^T Jp) L^-T
     const int e0 = act ? P.pm_first[pb] : 0, e1 = act ? P.pm_first[pb + 1] : 0;
     for (int e = e0; e < e1; e++) {
@@ -448,6 +401,134 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
         }
       }
     }
+    // camera entries: T = (Jc^T Jp) L^-T (one 144-byte record per observation, camera-major), T.u
+    // Stores: neighbouring lanes hold the observations of ONE point - eight different cameras, eight far-apart addresses,
+    // one 8-byte write request per lane and component (21.6 M at C3).  The lanes of a wave therefore trade records first,
+    // (point q, observation s) -> lane 8 s + q: now neighbouring lanes hold the same observation slot of consecutive
+    // points, which sit at consecutive positions of one camera wherever the points share their cameras, and the stores
+    // of a quad merge (k_point 0.229 -> 0.223 ms at C3; a record-major T was also measured: the same here, but k_pairs
+    // 0.28 -> 0.49 ms).
+    // Round 3 (FoldTables): in a folding workgroup every record also stays in LDS - the lane's own park column for the first
+    // round (its row data is consumed by then; the intrinsics entries above are done), a record-major overflow area in the
+    // last six component planes for the second round - and the camera x camera products are formed from there below.
+    const int wl = tid & 63, tsrc = ((wl & 7) << 3) | (wl >> 3);
+    const bool fold = P.fold_wg != nullptr && P.fold_wg[blockIdx.x] != 0;
+    auto round = [&](int rd, double (&Tk)[18], int& cpk) {
+      const int i = f + rd + sub;
+      int cp = -1;
+      if (i < l) cp = P.B.o_cpos[i];
+      double T[18], tu[6];
+#pragma unroll
+      for (int k = 0; k < 18; k++) T[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) tu[k] = 0.0;
+      if (cp >= 0) {
+        double jcs[12], jms[6], jps[6];
+        if (!single) { double r0, r1; obs_linearize(P.B, i, r0, r1, jcs, jms, jps); }
+        else {
+#pragma unroll
+          for (int k = 0; k < 12; k++) jcs[k] = park[k * 256 + tid];
+#pragma unroll
+          for (int k = 0; k < 6; k++) jps[k] = park[(18 + k) * 256 + tid];
+        }
+        const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          const double ja = jcs[a], jb = jcs[6 + a];
+          const double w0 = ja * a0 + jb * b0, w1 = ja * a1 + jb * b1, w2 = ja * a2 + jb * b2;
+          const double t0 = w0 * i00;
+          const double t1 = (w1 - l10 * t0) * i11;
+          const double t2 = (w2 - l20 * t0 - l21 * t1) * i22;
+          T[a * 3 + 0] = t0; T[a * 3 + 1] = t1; T[a * 3 + 2] = t2;
+          tu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+        }
+      }
+      cpk = cp;
+#pragma unroll
+      for (int k = 0; k < 18; k++) Tk[k] = T[k];
+      const int cpt = __shfl(cp, tsrc, 64);
+#pragma unroll
+      for (int k = 0; k < 18; k++) T[k] = __shfl(T[k], tsrc, 64);
+#pragma unroll
+      for (int k = 0; k < 6; k++) tu[k] = __shfl(tu[k], tsrc, 64);
+      if (cpt >= 0) {
+        double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cpt);
+#pragma unroll
+        for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
+        // component-major (T[k][position], positions camera-major): records of consecutive points of a camera are
+        // neighbours in every component plane, so these stores and the pair kernel's loads coalesce over the runs of
+        // points that share their cameras
+#pragma unroll
+        for (int k = 0; k < 18; k++) P.T[(size_t)k * P.NCR + cpt] = T[k];
+      }
+    };
+    // records in LDS: two halves (rows 0..2 and 3..5 of the 6 x 3 record) of 10 doubles each, record-major, so that a slot
+    // thread fetches its nine values with four 16-byte reads and one 8-byte read
+    double* const H0 = park;
+    double* const H1 = park + FOLD_NREC * 10;
+    auto rec_st = [&](int rec, const double (&Tk)[18]) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) { H0[rec * 10 + k] = Tk[k]; H1[rec * 10 + k] = Tk[9 + k]; }
+    };
+    {
+      double Tk[18];
+      int cpk;
+      round(0, Tk, cpk);
+      if (fold) {
+        __syncthreads();   // every lane has consumed its parked row data: the park becomes the record store
+        if (cpk >= 0) rec_st(tid, Tk);
+      }
+      for (int rd = 8; __any(f + rd < l); rd += 8) {
+        round(rd, Tk, cpk);
+        if (fold && cpk >= 0) rec_st(256 + P.fold_ovf_off[pb] + (rd - 8) + sub, Tk);
+      }
+    }
+    if (fold) {
+      __syncthreads();
+      // four threads per slot, nine entries of the 6 x 6 product each; the entries of a slot in point order
+      const int q = tid & 3, ra = 3 * (q >> 1), rb = 3 * (q & 1);
+      const int s0 = P.fold_wg_slot_first[blockIdx.x], s1 = P.fold_wg_slot_first[blockIdx.x + 1];
+      auto rec_ld = [&](int rec, int c0, double (&t)[9]) {   // components c0 .. c0 + 8 = rows c0 / 3 .. c0 / 3 + 2 of the record
+        const double* o = (c0 ? H1 : H0) + rec * 10;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+          const double2 v = *reinterpret_cast<const double2*>(o + 2 * k2);
+          t[2 * k2] = v.x; t[2 * k2 + 1] = v.y;
+        }
+        t[8] = o[8];
+      };
+      for (int sb = s0; sb < s1; sb += 64) {
+        // the entries of this pass's slots are one contiguous range of the list: staged in LDS by all threads, so that the
+        // slot loops below do not sit behind a global load per entry
+        const int eb = P.fold_slot_ent_first[sb], ee = P.fold_slot_ent_first[min(sb + 64, s1)];
+        __syncthreads();   // (the previous pass is done with ent_s)
+        for (int e = eb + tid; e < min(ee, eb + FOLD_ENT_CAP); e += 256) ent_s[e - eb] = P.fold_ent[e];
+        __syncthreads();
+        const int sl = sb + (tid >> 2);
+        if (sl < s1) {
+          double acc[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) acc[k] = 0.0;
+          const int e0 = P.fold_slot_ent_first[sl], e1 = P.fold_slot_ent_first[sl + 1];
+          for (int e = e0; e < e1; e++) {
+            const unsigned pr = e - eb < FOLD_ENT_CAP ? ent_s[e - eb] : P.fold_ent[e];
+            double ti[9], tj[9];
+            rec_ld((int)(pr & 0xffffu), 3 * ra, ti);
+            rec_ld((int)(pr >> 16), 3 * rb, tj);
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+              for (int c = 0; c < 3; c++)
+                acc[a * 3 + c] += ti[a * 3] * tj[c * 3] + ti[a * 3 + 1] * tj[c * 3 + 1] + ti[a * 3 + 2] * tj[c * 3 + 2];
+          }
+          double* out = P.fold_partial + (size_t)P.fold_slot_rank[sl] * 36;
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) out[(ra + a) * 6 + rb + c] = acc[a * 3 + c];
+        }
+      }
+    }
   }
   if (P.store_rows) {
     const double tc = block_sum256(cost, sh);
@@ -461,7 +542,8 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_point(PointPtrs P, double* __restrict__ gmax_partial) {
   __shared__ double sh[4];
   __shared__ double park[24 * 256];
-  k_point_body(P, gmax_partial, sh, park);
+  __shared__ unsigned ent_s[FOLD_ENT_CAP];
+  k_point_body(P, gmax_partial, sh, park, ent_s);
 }
 
 // --------------------------------------------------------------------------------------
@@ -670,7 +752,8 @@ template <int DA, int DB, bool WITH_U>
 __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
                                                 const int* __restrict__ pa, const int* __restrict__ pb,
                                                 const double* __restrict__ TA, const double* __restrict__ TB,
-                                                const double* __restrict__ UA, size_t plane, double* __restrict__ partial) {
+                                                const double* __restrict__ UA, size_t plane, double* __restrict__ partial,
+                                                const int* __restrict__ live = nullptr) {
   constexpr int NOUT = DA * DB + (WITH_U ? DA : 0);
   // XCD-aware chunk order: workgroups b, b+8, ... share an XCD (and its L2), so hand each XCD a
   // contiguous range of chunks — chunks are sorted by (row camera, col camera), a contiguous range
@@ -678,13 +761,15 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
   const int nwg = gridDim.x, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
   const int qn = nwg >> 3, rm = nwg & 7;
   const int swz = (xcd < rm ? xcd * (qn + 1) : rm * (qn + 1) + (xcd - rm) * qn) + loc;
-  const int chunk = swz * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (chunk >= nchunk) return;
+  const int cidx = swz * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (cidx >= nchunk) return;
+  const int chunk = live ? live[cidx] : cidx;   // (FoldTables: only the chunks that still hold a live entry are visited)
   double acc[NOUT];
 #pragma unroll
   for (int k = 0; k < NOUT; k++) acc[k] = 0.0;
   for (int e = ch_start[chunk] + lane; e < ch_end[chunk]; e += 64) {
     const int ia = pa[e], ib = pb[e];
+    if (ia < 0) continue;   // formed inside k_point (FoldTables)
     double ta[DA * 3], tb[DB * 3];
     // 6-row records (camera blocks) live component-major, T[k][position] with `plane` positions per component;
     // 3-row records (intrinsics entries) are small contiguous records
@@ -741,13 +826,28 @@ __global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int
 // camera-camera blocks: 64 threads (36 used) per block.
 __device__ __forceinline__ void asm_cc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                        const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                       const int* __restrict__ blk_fold_first, const double* __restrict__ fold_partial,
                                        const double* __restrict__ camftf, const double* __restrict__ diag_c,
                                        double radius, const int* __restrict__ cb_off, double* __restrict__ M, int ld, int lead) {
   const int t = threadIdx.x;
   if (t >= 36) return;
   const int rb = blk_row[b], cbk = blk_col[b];
   double s = 0.0;
-  for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 36 + t];
+  if (blk_chunk_first)   // (nullptr: every entry was folded into k_point, the gather kernel did not run)
+    for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 36 + t];
+  if (blk_fold_first) {   // the products formed inside k_point: one partial per (workgroup, block), in workgroup order
+    // four running sums (slots sl, sl + 1, sl + 2, sl + 3 mod 4) keep four loads in flight; combined in a fixed order
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    const int f0 = blk_fold_first[b], f1 = blk_fold_first[b + 1];
+    int sl = f0;
+    for (; sl + 3 < f1; sl += 4) {
+      const double v0 = fold_partial[(size_t)sl * 36 + t], v1 = fold_partial[(size_t)(sl + 1) * 36 + t];
+      const double v2 = fold_partial[(size_t)(sl + 2) * 36 + t], v3 = fold_partial[(size_t)(sl + 3) * 36 + t];
+      q0 += v0; q1 += v1; q2 += v2; q3 += v3;
+    }
+    for (; sl < f1; sl++) q0 += fold_partial[(size_t)sl * 36 + t];
+    s += (q0 + q1) + (q2 + q3);
+  }
   double v = -s;
   const int a = t / 6, c = t % 6;
   if (rb == cbk && lead) {
@@ -823,6 +923,8 @@ __device__ __forceinline__ void asm_rhs_cam(int i, int ncb, const double* __rest
 struct AsmArgs {
   int n_cc, n_mc, n_mm, n_rhs, n_padcol;   // n_padcol > 0 only on a single rank (with several, the padding follows the exchange)
   const int* padcol;
+  const int* cc_fold_first;
+  const double* cc_fold_partial;
   const int *cc_row, *cc_col, *cc_first, *mc_row, *mc_col, *mc_first, *mm_row, *mm_col, *mm_first, *cb_mb, *cb_off;
   const double *cc_partial, *mc_partial, *mm_partial, *camftf, *diag_c, *modelsum, *diag_m;
   double radius;
@@ -831,7 +933,7 @@ struct AsmArgs {
 };
 __global__ __launch_bounds__(64) void k_asm_all(AsmArgs a) {
   int b = blockIdx.x;
-  if (b < a.n_cc) { asm_cc(b, a.cc_row, a.cc_col, a.cc_first, a.cc_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead); return; }
+  if (b < a.n_cc) { asm_cc(b, a.cc_row, a.cc_col, a.cc_first, a.cc_partial, a.cc_fold_first, a.cc_fold_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead); return; }
   b -= a.n_cc;
   if (b < a.n_mc) { asm_mc(b, a.mc_row, a.mc_col, a.mc_first, a.mc_partial, a.camftf, a.cb_mb, a.cb_off, a.mo, a.M, a.ld, a.lead); return; }
   b -= a.n_mc;
@@ -1048,6 +1150,24 @@ __global__ __launch_bounds__(256) void k_pack_blocks(int nblk, const int* __rest
 // =======================================================================================
 // Host side
 // =======================================================================================
+// Camera x camera Schur products formed where the T records are produced (round 3).  A k_point workgroup holds the records of
+// its 32 points in LDS; the entries (record i, record j) of those points are sorted by block at create time, every distinct
+// block of a workgroup is a SLOT, four threads sum a slot's 6 x 6 products in point order and write ONE partial per slot
+// (config 3: 268 k slots = 77 MB instead of 4.8 M entry pairs = 1.3 GB of gathered T records).  The assembly adds a
+// block's slot partials (ranked by block) to its chunk partials.  Workgroups whose records do not fit (a point with more
+// than 16 rows, more than FOLD_OVF second-round records) keep the gather path: their entries stay live in the pair list,
+// the others are marked (pa < 0) and skipped by k_pairs.
+struct FoldTables {
+  bool on = false;
+  bool all = false;   // every entry of the camera x camera list is folded: k_pairs<6,6> and its chunk partials are not needed at all
+  int n_live = 0;     // chunks of the camera x camera list that still hold a live entry (the others' partials stay zero)
+  DevBuf<int> live_chunk;
+  int n_wg = 0, n_slots = 0, n_entries = 0;
+  DevBuf<int> wg_fold, ovf_off, wg_slot_first, slot_ent_first, slot_rank, blk_fold_first;
+  DevBuf<unsigned> ent;
+  DevBuf<double> partial;
+};
+
 struct PairJobs {
   int n_pairs = 0, n_chunks = 0, n_blocks = 0;
   DevBuf<int> pa, pb, ch_start, ch_end, blk_row, blk_col, blk_chunk_first;
@@ -1085,6 +1205,7 @@ struct msfm_ba {
   DevBuf<double> f_partial, camftf, modelsum;
   DevBuf<int> mcam_first, mcam;
   PairJobs cc, mc, mm;
+  FoldTables fold;
   DevBuf<double> M, Linv, w, z;
   DevBuf<double> gps, g_r, g_J;
   DevBuf<double> partial, partial2, partial3, gmax_buf, scal, sloc;
@@ -1795,6 +1916,205 @@ static int build_pairs_device(msfm_ctx* ctx, msfm_ba* ba, PairJobs& J, int nout,
   return MSFM_OK;
 }
 
+// ---- fold tables (FoldTables above), built from the resident index structures whichever way those were made ----
+namespace devsetup {
+__global__ __launch_bounds__(256) void k_fold_wg(int npb, int n_wg, const int* __restrict__ pt_first, int* __restrict__ ovf_off, int* __restrict__ wg_fold) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_wg) return;
+  int ovf = 0, ok = 1;
+  for (int pb = 32 * w; pb < min(npb, 32 * w + 32); pb++) {
+    const int k = pt_first[pb + 1] - pt_first[pb];
+    ovf_off[pb] = ovf;
+    if (k > 16) ok = 0;
+    ovf += max(0, k - 8);
+  }
+  wg_fold[w] = ok && ovf <= FOLD_OVF;
+}
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_fold_entries(int npb, int ncb, const int* __restrict__ pt_first, const int* __restrict__ o_cb,
+                                                       const int* __restrict__ o_cpos, const int* __restrict__ wg_fold, const int* __restrict__ ovf_off,
+                                                       int* __restrict__ count, const int* __restrict__ offset, unsigned long long* __restrict__ key,
+                                                       unsigned* __restrict__ val) {
+  const int pb = blockIdx.x * 256 + threadIdx.x;
+  if (pb >= npb) return;
+  int n = 0;
+  if (wg_fold[pb >> 5]) {
+    const int f = pt_first[pb], l = pt_first[pb + 1], w = pb >> 5, base = EMIT ? offset[pb] : 0;
+    auto rec = [&](int i) { const int r = i - f; return r < 8 ? ((pb & 31) << 3) + r : 256 + ovf_off[pb] + (r - 8); };
+    for (int i = f; i < l; i++) {
+      if (o_cpos[i] < 0) continue;
+      for (int j = f; j < l; j++) {
+        if (o_cpos[j] < 0 || o_cb[i] < o_cb[j]) continue;
+        if (EMIT) {
+          key[base + n] = ((unsigned long long)w << 32) | (unsigned)(o_cb[i] * ncb + o_cb[j]);
+          val[base + n] = (unsigned)rec(i) | ((unsigned)rec(j) << 16);
+        }
+        n++;
+      }
+    }
+  }
+  if (!EMIT) count[pb] = n;
+}
+__global__ __launch_bounds__(256) void k_fold_heads(int E, const unsigned long long* __restrict__ key, int* __restrict__ head) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < E) head[e] = (e == 0 || key[e] != key[e - 1]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_fold_slots(int E, const unsigned long long* __restrict__ key, const int* __restrict__ head, const int* __restrict__ slot_of,
+                                                     int* __restrict__ slot_ent_first, unsigned long long* __restrict__ slot_key2, int* __restrict__ slot_id) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E || !head[e]) return;
+  const int sl = slot_of[e];
+  slot_ent_first[sl] = e;
+  slot_key2[sl] = (key[e] << 32) | (key[e] >> 32);   // block key major, workgroup minor: the order of the partials
+  slot_id[sl] = sl;
+}
+// first slot of every workgroup: slots are sorted by (workgroup, block)
+__global__ __launch_bounds__(256) void k_fold_wg_first(int n_wg, int n_slots, const unsigned long long* __restrict__ slot_key2, int* __restrict__ wg_slot_first) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w > n_wg) return;
+  int lo = 0, hi = n_slots;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)(slot_key2[mid] & 0xffffffffull) < w) lo = mid + 1; else hi = mid;
+  }
+  wg_slot_first[w] = lo;
+}
+__global__ __launch_bounds__(256) void k_fold_rank(int n_slots, const int* __restrict__ sorted_id, int* __restrict__ rank) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < n_slots) rank[sorted_id[r]] = r;
+}
+// first partial of every camera x camera block (the blocks are numbered in key order)
+__global__ __launch_bounds__(256) void k_fold_blk_first(int n_blocks, int n_slots, int ncb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                         const unsigned long long* __restrict__ sorted_key2, int* __restrict__ blk_fold_first) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b > n_blocks) return;
+  if (b == n_blocks) { blk_fold_first[b] = n_slots; return; }
+  const unsigned long long k = (unsigned long long)(unsigned)(blk_row[b] * ncb + blk_col[b]) << 32;
+  int lo = 0, hi = n_slots;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sorted_key2[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  blk_fold_first[b] = lo;
+}
+__global__ __launch_bounds__(256) void k_fold_mark_cpos(int npb, const int* __restrict__ pt_first, const int* __restrict__ o_cpos, const int* __restrict__ wg_fold,
+                                                         uint8_t* __restrict__ folded) {
+  const int pb = blockIdx.x * 256 + threadIdx.x;
+  if (pb >= npb || !wg_fold[pb >> 5]) return;
+  for (int i = pt_first[pb]; i < pt_first[pb + 1]; i++) if (o_cpos[i] >= 0) folded[o_cpos[i]] = 1;
+}
+__global__ __launch_bounds__(256) void k_fold_live_flags(int nch, const int* __restrict__ ch_start, const int* __restrict__ ch_end, const int* __restrict__ pa,
+                                                          int* __restrict__ flag) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nch) return;
+  int any = 0;
+  for (int e = ch_start[c]; e < ch_end[c] && !any; e++) any = pa[e] >= 0;
+  flag[c] = any;
+}
+__global__ __launch_bounds__(256) void k_fold_live_list(int nch, const int* __restrict__ flag, const int* __restrict__ pos, int* __restrict__ live) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < nch && flag[c]) live[pos[c]] = c;
+}
+__global__ __launch_bounds__(256) void k_fold_mark_pairs(int n, const uint8_t* __restrict__ folded, int* __restrict__ pa) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n && pa[e] >= 0 && folded[pa[e]]) pa[e] = ~pa[e];   // (both records of an entry belong to one point)
+}
+}  // namespace devsetup
+
+static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
+  using namespace devsetup;
+  FoldTables& F = ba->fold;
+  F.on = false;
+  static const bool off = getenv("MSFM_NO_FOLD") != nullptr;
+  const int npb = ba->npb, ncb = ba->ncb;
+  // (small problems keep the gather path: their pair list fits the caches anyway and the tables would only lengthen the set-up;
+  //  MSFM_FOLD_MIN overrides the threshold, e.g. 0 to fold everything in a test)
+  static const long fold_min = getenv("MSFM_FOLD_MIN") ? atol(getenv("MSFM_FOLD_MIN")) : 262144;
+  if (off || npb == 0 || ncb == 0 || ba->cc.n_pairs == 0 || ba->cc.n_pairs < fold_min || (long)ncb * ncb > 0x7fffffffL) return MSFM_OK;
+  hipStream_t s = ctx->stream;
+  DevBuf<char> tmp;
+  const int n_wg = cdiv(npb, 32);
+  F.n_wg = n_wg;
+  DTRY(F.wg_fold.alloc(n_wg)); DTRY(F.ovf_off.alloc(npb));
+  hipLaunchKernelGGL(k_fold_wg, dim3(cdiv(n_wg, 256)), dim3(256), 0, s, npb, n_wg, ba->pt_first.p, F.ovf_off.p, F.wg_fold.p);
+  DevBuf<int> count, offset;
+  DTRY(count.alloc((size_t)npb + 1)); DTRY(offset.alloc((size_t)npb + 1));
+  DTRY(hipMemsetAsync(count.p, 0, sizeof(int) * ((size_t)npb + 1), s));
+  hipLaunchKernelGGL((k_fold_entries<false>), dim3(cdiv(npb, 256)), dim3(256), 0, s, npb, ncb, ba->pt_first.p, ba->o_cb.p, ba->o_cpos.p, F.wg_fold.p,
+                     F.ovf_off.p, count.p, (const int*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr);
+  DTRY(excl_scan(count.p, offset.p, (size_t)npb + 1, s, tmp));
+  int E = 0;
+  DTRY(hipMemcpyAsync(&E, offset.p + npb, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  if (E <= 0) return MSFM_OK;
+  DevBuf<unsigned long long> key, key_s, slot_key2, slot_key2_s;
+  DevBuf<unsigned> val;
+  DevBuf<int> head, slot_of, slot_id, slot_id_s;
+  DTRY(key.alloc(E)); DTRY(key_s.alloc(E)); DTRY(val.alloc(E)); DTRY(F.ent.alloc(E));
+  hipLaunchKernelGGL((k_fold_entries<true>), dim3(cdiv(npb, 256)), dim3(256), 0, s, npb, ncb, ba->pt_first.p, ba->o_cb.p, ba->o_cpos.p, F.wg_fold.p,
+                     F.ovf_off.p, (int*)nullptr, offset.p, key.p, val.p);
+  {
+    size_t bytes = 0;
+    const int bits = 32 + bits_for(std::max(2, n_wg));
+    DTRY(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, val.p, F.ent.p, (size_t)E, 0, bits, s));
+    if (tmp.n < bytes) DTRY(tmp.alloc(bytes));
+    DTRY(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, val.p, F.ent.p, (size_t)E, 0, bits, s));   // stable: point order inside a slot
+  }
+  DTRY(head.alloc((size_t)E + 1)); DTRY(slot_of.alloc((size_t)E + 1));
+  DTRY(hipMemsetAsync(head.p + E, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_fold_heads, dim3(cdiv(E, 256)), dim3(256), 0, s, E, key_s.p, head.p);
+  DTRY(excl_scan(head.p, slot_of.p, (size_t)E + 1, s, tmp));
+  int NS = 0;
+  DTRY(hipMemcpyAsync(&NS, slot_of.p + E, sizeof(int), hipMemcpyDeviceToHost, s));
+  DTRY(hipStreamSynchronize(s));
+  DTRY(F.slot_ent_first.alloc((size_t)NS + 1)); DTRY(slot_key2.alloc(NS)); DTRY(slot_key2_s.alloc(NS)); DTRY(slot_id.alloc(NS)); DTRY(slot_id_s.alloc(NS));
+  hipLaunchKernelGGL(k_fold_slots, dim3(cdiv(E, 256)), dim3(256), 0, s, E, key_s.p, head.p, slot_of.p, F.slot_ent_first.p, slot_key2.p, slot_id.p);
+  DTRY(hipMemcpyAsync(F.slot_ent_first.p + NS, &E, sizeof(int), hipMemcpyHostToDevice, s));
+  DTRY(F.wg_slot_first.alloc((size_t)n_wg + 1));
+  hipLaunchKernelGGL(k_fold_wg_first, dim3(cdiv(n_wg + 1, 256)), dim3(256), 0, s, n_wg, NS, slot_key2.p, F.wg_slot_first.p);
+  {
+    size_t bytes = 0;
+    DTRY(rocprim::radix_sort_pairs(nullptr, bytes, slot_key2.p, slot_key2_s.p, slot_id.p, slot_id_s.p, (size_t)NS, 0, 64, s));
+    if (tmp.n < bytes) DTRY(tmp.alloc(bytes));
+    DTRY(rocprim::radix_sort_pairs(tmp.p, bytes, slot_key2.p, slot_key2_s.p, slot_id.p, slot_id_s.p, (size_t)NS, 0, 64, s));
+  }
+  DTRY(F.slot_rank.alloc(NS));
+  hipLaunchKernelGGL(k_fold_rank, dim3(cdiv(NS, 256)), dim3(256), 0, s, NS, slot_id_s.p, F.slot_rank.p);
+  DTRY(F.blk_fold_first.alloc((size_t)ba->cc.n_blocks + 1));
+  hipLaunchKernelGGL(k_fold_blk_first, dim3(cdiv(ba->cc.n_blocks + 1, 256)), dim3(256), 0, s, ba->cc.n_blocks, NS, ncb, ba->cc.blk_row.p, ba->cc.blk_col.p,
+                     slot_key2_s.p, F.blk_fold_first.p);
+  // the same entries leave the gather path
+  DevBuf<uint8_t> folded;
+  DTRY(folded.alloc((size_t)std::max(1, ba->NCR)));
+  DTRY(hipMemsetAsync(folded.p, 0, (size_t)std::max(1, ba->NCR), s));
+  hipLaunchKernelGGL(k_fold_mark_cpos, dim3(cdiv(npb, 256)), dim3(256), 0, s, npb, ba->pt_first.p, ba->o_cpos.p, F.wg_fold.p, folded.p);
+  hipLaunchKernelGGL(k_fold_mark_pairs, dim3(cdiv(ba->cc.n_pairs, 256)), dim3(256), 0, s, ba->cc.n_pairs, folded.p, ba->cc.pa.p);
+  DTRY(F.partial.alloc((size_t)NS * 36));
+  // chunks that keep a live entry: the gather kernel visits only those, the partials of the others are zero for good
+  {
+    DevBuf<int> lf, lpos;
+    const int nch = ba->cc.n_chunks;
+    DTRY(lf.alloc((size_t)nch + 1)); DTRY(lpos.alloc((size_t)nch + 1));
+    DTRY(hipMemsetAsync(lf.p + nch, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_fold_live_flags, dim3(cdiv(std::max(1, nch), 256)), dim3(256), 0, s, nch, ba->cc.ch_start.p, ba->cc.ch_end.p, ba->cc.pa.p, lf.p);
+    DTRY(excl_scan(lf.p, lpos.p, (size_t)nch + 1, s, tmp));
+    DTRY(hipMemcpyAsync(&F.n_live, lpos.p + nch, sizeof(int), hipMemcpyDeviceToHost, s));
+    DTRY(hipStreamSynchronize(s));
+    DTRY(F.live_chunk.alloc((size_t)std::max(1, F.n_live)));
+    hipLaunchKernelGGL(k_fold_live_list, dim3(cdiv(std::max(1, nch), 256)), dim3(256), 0, s, nch, lf.p, lpos.p, F.live_chunk.p);
+    DTRY(hipMemsetAsync(ba->cc.partial.p, 0, sizeof(double) * 36 * (size_t)std::max(1, nch), s));
+    DTRY(hipStreamSynchronize(s));
+  }
+  DTRY(hipGetLastError());
+  DTRY(hipStreamSynchronize(s));   // the temporaries above go back to the pool
+  F.n_slots = NS; F.n_entries = E;
+  F.on = true;
+  F.all = E == ba->cc.n_pairs;
+  if (getenv("MSFM_VERBOSE") && ctx->rank == 0)
+    fprintf(stderr, "msfm: fold tables: %d workgroups, %d slots (%.1f MB of partials), %d of %d entries folded\n", n_wg, NS, NS * 288e-6, E, ba->cc.n_pairs);
+  return MSFM_OK;
+}
+
 // Everything msfm_ba_create needs between the caller's arrays and the allocation of the work buffers, on the device.
 static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_ba* ba, const std::function<void(const char*)>& lap,
                                     bool bulk_on_device) {
@@ -2463,6 +2783,8 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
     const bool on_host = e && atoi(e) != 0;
     if (on_host && bulk_on_device) return msfm_set_error(ctx, MSFM_E_INVAL, "MSFM_CREATE_HOST=1 needs the problem arrays in host memory");
     MSFM_TRY(on_host ? create_structures_host(ctx, P, ba, lap) : create_structures_device(ctx, P, ba, lap, bulk_on_device));
+    MSFM_TRY(build_fold_device(ctx, ba));   // from the resident structures: the same tables whichever way those were built
+    lap("fold tables");
   }
   const int Nc = ba->Nc, Nm = ba->Nm, Np = ba->Np, ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb, A = ba->A, NCR = ba->NCR, NPM = ba->NPM;
   if (ctx->world > 1 && ncb > 0 && ncb <= 4096) {
@@ -2675,6 +2997,9 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     Q.radius = radius; Q.dmin = opt->min_lm_diagonal; Q.dmax = opt->max_lm_diagonal;
     Q.reuse_diag = reuse_diag; Q.mode = mode; Q.fail = ba->fail.p;
     Q.store_rows = store_rows ? 1 : 0; Q.cost_partial = ba->partial.p;
+    const FoldTables& F = ba->fold;
+    Q.fold_wg = F.on ? F.wg_fold.p : nullptr; Q.fold_ovf_off = F.ovf_off.p; Q.fold_wg_slot_first = F.wg_slot_first.p;
+    Q.fold_slot_ent_first = F.slot_ent_first.p; Q.fold_slot_rank = F.slot_rank.p; Q.fold_ent = F.ent.p; Q.fold_partial = F.partial.p;
     hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, s, Q, ba->gmax_buf.p);
   }
   // The Schur pair products read only what k_point wrote (T, Tm, Tmu) and write their own partials; the per-camera sums
@@ -2691,7 +3016,12 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     if (ba->mm.n_chunks)
       hipLaunchKernelGGL((k_pairs<3, 3, true>), dim3(cdiv(ba->mm.n_chunks, 4)), dim3(256), 0, sp, ba->mm.n_chunks, ba->mm.ch_start.p,
                          ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, (size_t)0, ba->mm.partial.p);
-    if (ba->cc.n_chunks)
+    if (ba->fold.on) {
+      if (ba->fold.n_live)
+        hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->fold.n_live, 4)), dim3(256), 0, sp, ba->fold.n_live, ba->cc.ch_start.p,
+                           ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR),
+                           ba->cc.partial.p, ba->fold.live_chunk.p);
+    } else if (ba->cc.n_chunks)
       hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, sp, ba->cc.n_chunks, ba->cc.ch_start.p,
                          ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
   };
@@ -2782,7 +3112,8 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     }
     AsmArgs aa;
     aa.n_cc = ba->cc.n_blocks; aa.n_mc = ba->mc.n_blocks; aa.n_mm = ba->mm.n_blocks; aa.n_rhs = cdiv(6 * ncb, 64);
-    aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
+    aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = (ba->fold.on && ba->fold.all) ? nullptr : ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
+    aa.cc_fold_first = ba->fold.on ? ba->fold.blk_fold_first.p : nullptr; aa.cc_fold_partial = ba->fold.partial.p;
     aa.mc_row = ba->mc.blk_row.p; aa.mc_col = ba->mc.blk_col.p; aa.mc_first = ba->mc.blk_chunk_first.p; aa.mc_partial = ba->mc.partial.p;
     aa.mm_row = ba->mm.blk_row.p; aa.mm_col = ba->mm.blk_col.p; aa.mm_first = ba->mm.blk_chunk_first.p; aa.mm_partial = ba->mm.partial.p;
     aa.cb_mb = ba->cb_mb.p; aa.cb_off = ba->cb_off.p; aa.camftf = ba->camftf.p; aa.diag_c = ba->diag_c.p; aa.modelsum = ba->modelsum.p;

@@ -261,6 +261,41 @@ def test_ba_one_model_per_camera_beyond_the_corner_table(ctx):
     assert lay1["n_domains"] >= 2 and lay1["n_levels"] >= 1
 
 
+def test_ba_folded_schur_products_match_the_oracle_and_the_gather_path(oracle):
+    """The camera x camera Schur products formed inside k_point (FoldTables, ba.hip) instead of by the gather kernel: forced on
+    for small problems (MSFM_FOLD_MIN=0) - long tracks that need the second-round record area, frozen cameras / points, several
+    intrinsics blocks, GPS rows - each against the oracle, and against the gather path (MSFM_NO_FOLD=1) to rounding."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from metricsfm_amd import _abi as A, capi, scene\n"
+            "from oracle import oracle as O\n"
+            "ctx = capi.Context(0)\n"
+            "out = []\n"
+            "def run(sc, **kw):\n"
+            "    a, r = A.BaArrays.from_scene(sc, **kw), A.BaArrays.from_scene(sc, **kw)\n"
+            "    g = ctx.ba_solve(a, capi.default_options(max_num_iterations=10)); o = O.ba_solve(r, O.default_options(max_num_iterations=10))\n"
+            "    assert g['num_iterations'] == o['num_iterations'] and (g['iterations']['step_is_successful'] == o['iterations']['step_is_successful']).all()\n"
+            "    np.testing.assert_allclose(g['iterations']['cost'], o['iterations']['cost'], rtol=1e-9)\n"
+            "    assert np.abs(a.cam_pose - r.cam_pose).max() <= 1e-7 * np.abs(r.cam_pose).max() and np.abs(a.point - r.point).max() <= 1e-7 * np.abs(r.point).max()\n"
+            "    out.append([float(c) for c in g['iterations']['cost']])\n"
+            "run(scene.make_aerial_scene(60, 5000, seed=71))\n"
+            "sc = scene.make_ring_scene(14, 900, seed=72)           # every point seen by all 14 cameras: second-round records\n"
+            "run(sc)\n"
+            "sc = scene.make_aerial_scene(40, 4000, seed=73, n_models=5, gps_sigma=0.5)\n"
+            "rng = np.random.default_rng(3); cm = (np.arange(40) %% 6 != 0).astype(np.uint8); pm = (rng.random(4000) > 0.15).astype(np.uint8)\n"
+            "run(sc, cam_mutable=cm, pt_mutable=pm, gps_xyz=sc.gps_xyz, gps_weight=50.0)\n"
+            "print(repr(out))\n") % ROOT
+    outs = {}
+    for name, env in (("fold", dict(MSFM_FOLD_MIN="0")), ("gather", dict(MSFM_NO_FOLD="1"))):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = eval(r.stdout.strip().splitlines()[-1])
+    for a, b in zip(outs["fold"], outs["gather"]):
+        np.testing.assert_allclose(a, b, rtol=1e-8)   # (the two paths sum in different orders: equal only to rounding; both
+                                                      #  already matched the oracle to 1e-9 above, rejected trial steps included)
+
+
 def test_ba_domains_with_window_masks(ctx, oracle, monkeypatch):
     """Frozen cameras and frozen points (PartialBundleAdjustment masks, sfm_incremental.cc:917-1014) on a problem large enough
     for the camera-domain order: frozen cameras have no block, observations of frozen points only touch camera diagonals."""
