@@ -256,6 +256,11 @@ __global__ __launch_bounds__(1024) void k_reduce(ReduceJobs J, double* __restric
 // --------------------------------------------------------------------------------------
 // k_point: the eliminated points.  mode 0: full; mode 1: raw squared column norms only.
 // --------------------------------------------------------------------------------------
+// One pass of a folding workgroup (FoldTables below): `words` 32-bit words at fold_stream + off - the headers of n_slots slots
+// (first entry relative to the entry area | count << 16; padded to a multiple of four words), then the slots' entries
+// (record_i | record_j << 16) - which one wave instruction per 256 words copies straight into LDS.  slot0: the first slot's
+// index in workgroup-major numbering (for its rank); n_diag: how many of the pass's slots (its first ones) are camera-diagonal.
+struct FoldPass { int off, words, slot0, n_slots, n_diag, pad0, pad1, pad2; };
 struct PointPtrs {
   BaPtrs B;            // row data, parameters and scales the rows are linearised with
   int npb, NCR;
@@ -267,10 +272,12 @@ struct PointPtrs {
   int store_rows;      // first pass at this linearisation point: also write the camera-major rows (k_ftf) and the cost
   double* cost_partial;
   int* fail;
-  // FoldTables (all nullptr: every product goes through the pair lists)
-  const int *fold_wg, *fold_ovf_off, *fold_wg_slot_first, *fold_slot_ent_first, *fold_slot_rank;
-  const unsigned* fold_ent;
+  // FoldTables (fold_wg nullptr: every product goes through the pair lists)
+  const int *fold_wg, *fold_ovf_off, *fold_wg_pass_first, *fold_slot_rank;
+  const FoldPass* fold_pass;
+  const unsigned* fold_stream;
   double* fold_partial;
+  double* fold_mc_partial;   // intrinsics x camera products of the same workgroups (one intrinsics block only; nullptr: gather path)
 };
 
 // (8-lane groups; after the first two steps the four lanes of a quad hold the same value, so adding lane 7 - i is adding lane i ^ 4)
@@ -282,11 +289,35 @@ struct PointPtrs {
 // 256 threads = 32 points.  Tracks of up to 8 views keep their rows in registers; longer ones linearise them again.
 #define FOLD_OVF 51   // second-round records (rows 8..15 of a point) a workgroup can park beside the 256 first-round ones
 #define FOLD_NREC (256 + FOLD_OVF)   // records of 2 x 10 doubles (two 16-byte aligned halves of 9) in the 48 KB row park
-#define FOLD_ENT_CAP 1024   // entries of one pass of 64 slots staged in LDS (more: read from memory)
+#define FOLD_WORDS 1024      // words (slot headers + entries) of one pass, staged in LDS
+#define FOLD_PASS_SLOTS 128  // slots of one pass at most: four threads per slot, two rounds
+#ifdef MSFM_FOLD_STAMPS
+// developer build only (make CXXFLAGS+=-DMSFM_FOLD_STAMPS): clock stamps of wave 0 of every folding workgroup
+__device__ long long g_fold_stamps[8192][8];
+#define FSTAMP(i) do { if (fold && tid == 0 && blockIdx.x < 8192) g_fold_stamps[blockIdx.x][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FSTAMP(i) do {} while (0)
+#endif
 __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restrict__ gmax_partial, double* sh, double* park, unsigned* ent_s) {
   const int tid = threadIdx.x, sub = tid & 7;
   const int pb = blockIdx.x * 32 + (tid >> 3);
   const bool act = pb < P.npb;
+  // FoldTables: the slot headers and entries of the workgroup's first pass start on their way into LDS now (one
+  // global_load_lds_dwordx4 per wave and 256 words; nothing waits for them before the fold phase at the end)
+  const bool fold = P.fold_wg != nullptr && P.mode != 1 && P.fold_wg[blockIdx.x] != 0;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto stage = [&](int off, int words) {
+    if (256 * wv < words)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(P.fold_stream + (size_t)off + 256 * wv + 4 * (tid & 63)),
+                                       (__attribute__((address_space(3))) void*)(ent_s + 256 * wv), 16, 0, 0);
+  };
+  int fp0 = 0, fp1 = 0;
+  if (fold) {
+    fp0 = __builtin_amdgcn_readfirstlane(P.fold_wg_pass_first[blockIdx.x]);
+    fp1 = __builtin_amdgcn_readfirstlane(P.fold_wg_pass_first[blockIdx.x + 1]);
+    stage(__builtin_amdgcn_readfirstlane(P.fold_pass[fp0].off), __builtin_amdgcn_readfirstlane(P.fold_pass[fp0].words));
+  }
+  FSTAMP(0);
   int f = 0, l = 0;
   if (act) { f = P.pt_first[pb]; l = P.pt_first[pb + 1]; }
   const bool single = (l - f) <= 8;
@@ -314,8 +345,10 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
       g0 += a0 * r0 + b0 * r1; g1 += a1 * r0 + b1 * r1; g2 += a2 * r0 + b2 * r1;
     }
   }
+  FSTAMP(1);
   GROUP_SUM(V00) GROUP_SUM(V10) GROUP_SUM(V11) GROUP_SUM(V20) GROUP_SUM(V21) GROUP_SUM(V22)
   GROUP_SUM(g0) GROUP_SUM(g1) GROUP_SUM(g2)
+
   double gmax = 0.0;
   double l00 = 1, l10 = 0, l11 = 1, l20 = 0, l21 = 0, l22 = 1, i00 = 1, i11 = 1, i22 = 1, u0 = 0, u1 = 0, u2 = 0;
   if (act) {
@@ -359,48 +392,8 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
       }
     }
   }
+  FSTAMP(2);
   if (P.mode != 1) {
-    // (point, intrinsics-block) entries: Tm = (sum Jm^T Jp) L^-T
-    const int e0 = act ? P.pm_first[pb] : 0, e1 = act ? P.pm_first[pb + 1] : 0;
-    for (int e = e0; e < e1; e++) {
-      const int mb = P.pm_mb[e];
-      double W[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) W[k] = 0.0;
-      for (int base = f; base < l; base += 8) {
-        const int i = base + sub;
-        if (i < l && P.B.o_mb[i] == mb) {
-          double jcs[12], jms[6], jps[6];
-          if (!single) { double r0, r1; obs_linearize(P.B, i, r0, r1, jcs, jms, jps); }
-          else {
-#pragma unroll
-            for (int k = 0; k < 6; k++) { jms[k] = park[(12 + k) * 256 + tid]; jps[k] = park[(18 + k) * 256 + tid]; }
-          }
-          const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
-#pragma unroll
-          for (int a = 0; a < 3; a++) {
-            const double ja = jms[a], jb = jms[3 + a];
-            W[a * 3 + 0] += ja * a0 + jb * b0;
-            W[a * 3 + 1] += ja * a1 + jb * b1;
-            W[a * 3 + 2] += ja * a2 + jb * b2;
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 9; k++) GROUP_SUM(W[k])
-      if (sub == 0) {
-        double* Tm = P.Tm + 9 * (size_t)e;
-        double* Tmu = P.Tmu + 3 * (size_t)e;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          const double t0 = W[a * 3] * i00;
-          const double t1 = (W[a * 3 + 1] - l10 * t0) * i11;
-          const double t2 = (W[a * 3 + 2] - l20 * t0 - l21 * t1) * i22;
-          Tm[a * 3 + 0] = t0; Tm[a * 3 + 1] = t1; Tm[a * 3 + 2] = t2;
-          Tmu[a] = t0 * u0 + t1 * u1 + t2 * u2;
-        }
-      }
-    }
     // camera entries: T = (Jc^T Jp) L^-T (one 144-byte record per observation, camera-major), T.u
     // Stores: neighbouring lanes hold the observations of ONE point - eight different cameras, eight far-apart addresses,
     // one 8-byte write request per lane and component (21.6 M at C3).  The lanes of a wave therefore trade records first,
@@ -408,11 +401,9 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
     // points, which sit at consecutive positions of one camera wherever the points share their cameras, and the stores
     // of a quad merge (k_point 0.229 -> 0.223 ms at C3; a record-major T was also measured: the same here, but k_pairs
     // 0.28 -> 0.49 ms).
-    // Round 3 (FoldTables): in a folding workgroup every record also stays in LDS - the lane's own park column for the first
-    // round (its row data is consumed by then; the intrinsics entries above are done), a record-major overflow area in the
-    // last six component planes for the second round - and the camera x camera products are formed from there below.
+    // Round 3 (FoldTables): in a folding workgroup every record also stays in LDS (record-major, where the parked rows were,
+    // once every lane is done with those) and the camera x camera products are formed from there below.
     const int wl = tid & 63, tsrc = ((wl & 7) << 3) | (wl >> 3);
-    const bool fold = P.fold_wg != nullptr && P.fold_wg[blockIdx.x] != 0;
     auto round = [&](int rd, double (&Tk)[18], int& cpk) {
       const int i = f + rd + sub;
       int cp = -1;
@@ -473,61 +464,185 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
     {
       double Tk[18];
       int cpk;
+      FSTAMP(3);
       round(0, Tk, cpk);
+      FSTAMP(4);
+      // (point, intrinsics-block) entries: Tm = (sum Jm^T Jp) L^-T.  After the first round and after the park has turned into
+      // the record store, so that the lane that forms Tm can put it beside the records (its first entry's: with one intrinsics
+      // block that is the only one; a point without an entry leaves zeros): the lane's Jm and Jp rows cross the barrier in
+      // registers, and what the section asks from memory (three dependent loads) is on its way during the barrier.
+      int pe0 = 0, pe1 = 0, my_mb = -2;
+      if (act) {
+        pe0 = P.pm_first[pb]; pe1 = P.pm_first[pb + 1];
+        if (f + sub < l) my_mb = P.B.o_mb[f + sub];   // (the lane's row of the first round)
+      }
+      double pjm[6], pjp[6];
+      if (single) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pjm[k] = park[(12 + k) * 256 + tid]; pjp[k] = park[(18 + k) * 256 + tid]; }
+      }
+      const int mb_first = pe0 < pe1 ? P.pm_mb[pe0] : -1;
       if (fold) {
         __syncthreads();   // every lane has consumed its parked row data: the park becomes the record store
         if (cpk >= 0) rec_st(tid, Tk);
       }
+      auto tm_finish = [&](int e, double (&W)[9]) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) GROUP_SUM(W[k])
+        if (sub == 0) {
+          double* Tm = P.Tm + 9 * (size_t)e;
+          double* Tmu = P.Tmu + 3 * (size_t)e;
+          const bool pads = fold && P.fold_mc_partial && e == pe0;
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const double t0 = W[a * 3] * i00;
+            const double t1 = (W[a * 3 + 1] - l10 * t0) * i11;
+            const double t2 = (W[a * 3 + 2] - l20 * t0 - l21 * t1) * i22;
+            Tm[a * 3 + 0] = t0; Tm[a * 3 + 1] = t1; Tm[a * 3 + 2] = t2;
+            Tmu[a] = t0 * u0 + t1 * u1 + t2 * u2;
+            if (pads) {   // into the tenth doubles of the point's first five records, for the intrinsics x camera products below
+              const double tv[3] = {t0, t1, t2};
+#pragma unroll
+              for (int c = 0; c < 3; c++) { const int k = a * 3 + c; ((k & 1) ? H1 : H0)[(tid + (k >> 1)) * 10 + 9] = tv[c]; }
+            }
+          }
+        }
+      };
+      auto tm_row = [&](double (&W)[9], const double (&jms)[6], const double (&jps)[6]) {
+        const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const double ja = jms[a], jb = jms[3 + a];
+          W[a * 3 + 0] += ja * a0 + jb * b0;
+          W[a * 3 + 1] += ja * a1 + jb * b1;
+          W[a * 3 + 2] += ja * a2 + jb * b2;
+        }
+      };
+      // (two separate paths, so that the rows held in registers are not alive beside the linearisation of the long tracks)
+      if (single) {
+        for (int e = pe0; e < pe1; e++) {
+          const int mb = e == pe0 ? mb_first : P.pm_mb[e];
+          double W[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) W[k] = 0.0;
+          if (f + sub < l && my_mb == mb) tm_row(W, pjm, pjp);
+          tm_finish(e, W);
+        }
+      } else {
+        for (int e = pe0; e < pe1; e++) {
+          const int mb = e == pe0 ? mb_first : P.pm_mb[e];
+          double W[9];
+#pragma unroll
+          for (int k = 0; k < 9; k++) W[k] = 0.0;
+          for (int base = f; base < l; base += 8) {
+            const int i = base + sub;
+            if (i < l && P.B.o_mb[i] == mb) {
+              double r0, r1, jcs[12], jms[6], jps[6];
+              obs_linearize(P.B, i, r0, r1, jcs, jms, jps);
+              tm_row(W, jms, jps);
+            }
+          }
+          tm_finish(e, W);
+        }
+      }
+      if (fold && P.fold_mc_partial && sub == 0 && act && pe0 == pe1) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) ((k & 1) ? H1 : H0)[(tid + (k >> 1)) * 10 + 9] = 0.0;
+      }
+      FSTAMP(5);
       for (int rd = 8; __any(f + rd < l); rd += 8) {
+        const int ovf = (fold && act) ? P.fold_ovf_off[pb] : 0;   // (asked for before the round's own loads)
         round(rd, Tk, cpk);
-        if (fold && cpk >= 0) rec_st(256 + P.fold_ovf_off[pb] + (rd - 8) + sub, Tk);
+        if (fold && cpk >= 0) {
+          const int rec = 256 + ovf + (rd - 8) + sub;
+          rec_st(rec, Tk);
+          H0[rec * 10 + 9] = (double)(tid >> 3);   // (a second-round record names its point)
+        }
       }
     }
+    FSTAMP(6);
     if (fold) {
-      __syncthreads();
-      // four threads per slot, nine entries of the 6 x 6 product each; the entries of a slot in point order
-      const int q = tid & 3, ra = 3 * (q >> 1), rb = 3 * (q & 1);
-      const int s0 = P.fold_wg_slot_first[blockIdx.x], s1 = P.fold_wg_slot_first[blockIdx.x + 1];
-      auto rec_ld = [&](int rec, int c0, double (&t)[9]) {   // components c0 .. c0 + 8 = rows c0 / 3 .. c0 / 3 + 2 of the record
-        const double* o = (c0 ? H1 : H0) + rec * 10;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) {
-          const double2 v = *reinterpret_cast<const double2*>(o + 2 * k2);
-          t[2 * k2] = v.x; t[2 * k2 + 1] = v.y;
+      const int q = tid & 3, ra = q >> 1, rb = q & 1, sl4 = tid >> 2;   // rows 3 ra .. of record i times rows 3 rb .. of record j
+      for (int p = fp0; p < fp1; p++) {
+        const int slot0 = __builtin_amdgcn_readfirstlane(P.fold_pass[p].slot0), n_slots = __builtin_amdgcn_readfirstlane(P.fold_pass[p].n_slots);
+        const int n_diag = P.fold_mc_partial ? __builtin_amdgcn_readfirstlane(P.fold_pass[p].n_diag) : 0;
+        if (p > fp0) {
+          __syncthreads();   // (the previous pass is done with the staged words)
+          stage(__builtin_amdgcn_readfirstlane(P.fold_pass[p].off), __builtin_amdgcn_readfirstlane(P.fold_pass[p].words));
         }
-        t[8] = o[8];
-      };
-      for (int sb = s0; sb < s1; sb += 64) {
-        // the entries of this pass's slots are one contiguous range of the list: staged in LDS by all threads, so that the
-        // slot loops below do not sit behind a global load per entry
-        const int eb = P.fold_slot_ent_first[sb], ee = P.fold_slot_ent_first[min(sb + 64, s1)];
-        __syncthreads();   // (the previous pass is done with ent_s)
-        for (int e = eb + tid; e < min(ee, eb + FOLD_ENT_CAP); e += 256) ent_s[e - eb] = P.fold_ent[e];
-        __syncthreads();
-        const int sl = sb + (tid >> 2);
-        if (sl < s1) {
-          double acc[9];
+        __syncthreads();     // records stored (first pass); the pass's words have arrived (the barrier waits for the copy)
+        // where the results go: asked for now, needed after the loops
+        int rank0 = 0, rank1 = 0;
+        if (sl4 < n_slots) rank0 = P.fold_slot_rank[slot0 + sl4];
+        if (sl4 + 64 < n_slots) rank1 = P.fold_slot_rank[slot0 + sl4 + 64];
+        const int hdr = (n_slots + 3) & ~3;
+        for (int sl = sl4, rnk = rank0; sl < n_slots; sl += 64, rnk = rank1) {
+          // the slot's four threads form nine entries of the 6 x 6 product each, over the slot's entries in point order
+          // (measured alternatives, config 3: the next entry's records kept in flight behind the multiplies - no change; every
+          // fourth entry per thread with the whole 6 x 6 product and a sum across the quad - k_point 0.41 -> 0.52 ms.  The
+          // phase is bound by the LDS array: the records a lane group gathers fall on the 16 four-bank groups at random)
+          const unsigned h = ent_s[sl];
+          const int e0 = hdr + (int)(h & 0xffffu), e1 = e0 + (int)(h >> 16);
+          // intrinsics x camera: Tm_p T_rec^T summed over the records of one camera in this workgroup - exactly the entries of
+          // the camera's diagonal slot that pair a record with itself (a camera that sees a point twice also has the two cross
+          // entries there).  The two threads that hold rows 0..2 of record i take nine entries of the 3 x 6 product each: the
+          // rows of record j they have loaded anyway, times the point's Tm from the spare doubles of its records.
+          // (rows 0 and 1 of the 3 x 6 product with the threads that hold rows 0..2 of record i, row 2 with the other two)
+          const bool mcd = sl < n_diag;
+          const int ma0 = ra ? 2 : 0;
+          double acc[9], accm[6];
 #pragma unroll
           for (int k = 0; k < 9; k++) acc[k] = 0.0;
-          const int e0 = P.fold_slot_ent_first[sl], e1 = P.fold_slot_ent_first[sl + 1];
+#pragma unroll
+          for (int k = 0; k < 6; k++) accm[k] = 0.0;
           for (int e = e0; e < e1; e++) {
-            const unsigned pr = e - eb < FOLD_ENT_CAP ? ent_s[e - eb] : P.fold_ent[e];
+            const unsigned pr = ent_s[e];
+            const double* oi = (ra ? H1 : H0) + (int)(pr & 0xffffu) * 10;
+            const double* oj = (rb ? H1 : H0) + (int)(pr >> 16) * 10;
             double ti[9], tj[9];
-            rec_ld((int)(pr & 0xffffu), 3 * ra, ti);
-            rec_ld((int)(pr >> 16), 3 * rb, tj);
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+              const double2 vi = *reinterpret_cast<const double2*>(oi + 2 * k2);
+              const double2 vj = *reinterpret_cast<const double2*>(oj + 2 * k2);
+              ti[2 * k2] = vi.x; ti[2 * k2 + 1] = vi.y; tj[2 * k2] = vj.x; tj[2 * k2 + 1] = vj.y;
+            }
+            ti[8] = oi[8]; tj[8] = oj[8];
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
               for (int c = 0; c < 3; c++)
                 acc[a * 3 + c] += ti[a * 3] * tj[c * 3] + ti[a * 3 + 1] * tj[c * 3 + 1] + ti[a * 3 + 2] * tj[c * 3 + 2];
+            if (mcd && (pr & 0xffffu) == (pr >> 16)) {
+              const int rec = (int)(pr & 0xffffu);
+              int r0 = rec & ~7;
+              if (rec >= 256) r0 = 8 * (int)H0[rec * 10 + 9];   // (second-round record: its point is written beside it)
+              double tm[6];
+#pragma unroll
+              for (int k6 = 0; k6 < 6; k6++) { const int k = 3 * ma0 + k6; tm[k6] = ((k & 1) ? H1 : H0)[(r0 + (k >> 1)) * 10 + 9]; }   // (row 3 is never used)
+#pragma unroll
+              for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                  accm[a * 3 + c] += tm[a * 3] * tj[c * 3] + tm[a * 3 + 1] * tj[c * 3 + 1] + tm[a * 3 + 2] * tj[c * 3 + 2];
+            }
           }
-          double* out = P.fold_partial + (size_t)P.fold_slot_rank[sl] * 36;
+          if (mcd) {
+            double* om = P.fold_mc_partial + (size_t)rnk * 18;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+              if (ma0 + a < 3) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) om[(ma0 + a) * 6 + 3 * rb + c] = accm[a * 3 + c];
+              }
+          }
+          double* out = P.fold_partial + (size_t)rnk * 36;
 #pragma unroll
           for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) out[(ra + a) * 6 + rb + c] = acc[a * 3 + c];
+            for (int c = 0; c < 3; c++) out[(3 * ra + a) * 6 + 3 * rb + c] = acc[a * 3 + c];
         }
       }
+      FSTAMP(7);
     }
   }
   if (P.store_rows) {
@@ -542,7 +657,7 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_point(PointPtrs P, double* __restrict__ gmax_partial) {
   __shared__ double sh[4];
   __shared__ double park[24 * 256];
-  __shared__ unsigned ent_s[FOLD_ENT_CAP];
+  __shared__ __attribute__((aligned(16))) unsigned ent_s[FOLD_WORDS];
   k_point_body(P, gmax_partial, sh, park, ent_s);
 }
 
@@ -826,7 +941,7 @@ __global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int
 // camera-camera blocks: 64 threads (36 used) per block.
 __device__ __forceinline__ void asm_cc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                        const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
-                                       const int* __restrict__ blk_fold_first, const double* __restrict__ fold_partial,
+                                       const int* __restrict__ blk_fold_range, const double* __restrict__ fold_partial,
                                        const double* __restrict__ camftf, const double* __restrict__ diag_c,
                                        double radius, const int* __restrict__ cb_off, double* __restrict__ M, int ld, int lead) {
   const int t = threadIdx.x;
@@ -835,10 +950,10 @@ __device__ __forceinline__ void asm_cc(int b, const int* __restrict__ blk_row, c
   double s = 0.0;
   if (blk_chunk_first)   // (nullptr: every entry was folded into k_point, the gather kernel did not run)
     for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 36 + t];
-  if (blk_fold_first) {   // the products formed inside k_point: one partial per (workgroup, block), in workgroup order
+  if (blk_fold_range) {   // the products formed inside k_point: one partial per (workgroup, block), in workgroup order
     // four running sums (slots sl, sl + 1, sl + 2, sl + 3 mod 4) keep four loads in flight; combined in a fixed order
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-    const int f0 = blk_fold_first[b], f1 = blk_fold_first[b + 1];
+    const int f0 = blk_fold_range[2 * b], f1 = blk_fold_range[2 * b + 1];
     int sl = f0;
     for (; sl + 3 < f1; sl += 4) {
       const double v0 = fold_partial[(size_t)sl * 36 + t], v1 = fold_partial[(size_t)(sl + 1) * 36 + t];
@@ -860,13 +975,27 @@ __device__ __forceinline__ void asm_cc(int b, const int* __restrict__ blk_row, c
 // intrinsics-camera blocks (rows 6*ncb + 3*mb.., cols 6*cb..): 18 used threads.
 __device__ __forceinline__ void asm_mc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                        const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+                                       const int* __restrict__ fold_range, const double* __restrict__ fold_partial,
                                        const double* __restrict__ camftf, const int* __restrict__ cb_mb,
                                        const int* __restrict__ cb_off, int mo, double* __restrict__ M, int ld, int lead) {
   const int t = threadIdx.x;
   if (t >= 18) return;
   const int mb = blk_row[b], cb = blk_col[b];
   double s = 0.0;
-  for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 18 + t];
+  if (blk_chunk_first)
+    for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 18 + t];
+  if (fold_range) {   // the products formed inside k_point: one partial per (workgroup, camera), in workgroup order
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    const int f0 = fold_range[2 * b], f1 = fold_range[2 * b + 1];
+    int sl = f0;
+    for (; sl + 3 < f1; sl += 4) {
+      const double v0 = fold_partial[(size_t)sl * 18 + t], v1 = fold_partial[(size_t)(sl + 1) * 18 + t];
+      const double v2 = fold_partial[(size_t)(sl + 2) * 18 + t], v3 = fold_partial[(size_t)(sl + 3) * 18 + t];
+      q0 += v0; q1 += v1; q2 += v2; q3 += v3;
+    }
+    for (; sl < f1; sl++) q0 += fold_partial[(size_t)sl * 18 + t];
+    s += (q0 + q1) + (q2 + q3);
+  }
   double v = -s;
   if (lead && cb_mb[cb] == mb) v += camftf[(size_t)cb * PSTRIDE + F_JMJC + t];
   const int a = t / 6, c = t % 6;
@@ -925,6 +1054,8 @@ struct AsmArgs {
   const int* padcol;
   const int* cc_fold_first;
   const double* cc_fold_partial;
+  const int* mc_fold_range;
+  const double* mc_fold_partial;
   const int *cc_row, *cc_col, *cc_first, *mc_row, *mc_col, *mc_first, *mm_row, *mm_col, *mm_first, *cb_mb, *cb_off;
   const double *cc_partial, *mc_partial, *mm_partial, *camftf, *diag_c, *modelsum, *diag_m;
   double radius;
@@ -935,7 +1066,7 @@ __global__ __launch_bounds__(64) void k_asm_all(AsmArgs a) {
   int b = blockIdx.x;
   if (b < a.n_cc) { asm_cc(b, a.cc_row, a.cc_col, a.cc_first, a.cc_partial, a.cc_fold_first, a.cc_fold_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead); return; }
   b -= a.n_cc;
-  if (b < a.n_mc) { asm_mc(b, a.mc_row, a.mc_col, a.mc_first, a.mc_partial, a.camftf, a.cb_mb, a.cb_off, a.mo, a.M, a.ld, a.lead); return; }
+  if (b < a.n_mc) { asm_mc(b, a.mc_row, a.mc_col, a.mc_first, a.mc_partial, a.mc_fold_range, a.mc_fold_partial, a.camftf, a.cb_mb, a.cb_off, a.mo, a.M, a.ld, a.lead); return; }
   b -= a.n_mc;
   if (b < a.n_mm) { asm_mm(b, a.mm_row, a.mm_col, a.mm_first, a.mm_partial, a.modelsum, a.diag_m, a.radius, a.mo, a.n, a.M, a.ld, a.lead); return; }
   b -= a.n_mm;
@@ -1162,10 +1293,17 @@ struct FoldTables {
   bool all = false;   // every entry of the camera x camera list is folded: k_pairs<6,6> and its chunk partials are not needed at all
   int n_live = 0;     // chunks of the camera x camera list that still hold a live entry (the others' partials stay zero)
   DevBuf<int> live_chunk;
-  int n_wg = 0, n_slots = 0, n_entries = 0;
-  DevBuf<int> wg_fold, ovf_off, wg_slot_first, slot_ent_first, slot_rank, blk_fold_first;
-  DevBuf<unsigned> ent;
+  int n_wg = 0, n_slots = 0, n_entries = 0, n_pass = 0;
+  DevBuf<int> wg_fold, ovf_off, wg_pass_first, slot_rank, blk_range;
+  DevBuf<FoldPass> pass;
+  DevBuf<unsigned> stream;   // per pass: slot headers, then entries (FoldPass); FOLD_WORDS words of padding behind the last pass
   DevBuf<double> partial;
+  // intrinsics x camera list (one intrinsics block): the records of a camera's diagonal slot are exactly its observations in
+  // the workgroup, so the same tables serve; the 3 x 6 partials are indexed by the diagonal slots' ranks
+  bool mc_on = false, mc_all = false;
+  int n_diag = 0, mc_n_live = 0;
+  DevBuf<int> mc_range, mc_live_chunk;
+  DevBuf<double> mc_partial;
 };
 
 struct PairJobs {
@@ -1510,6 +1648,21 @@ MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
   (void)hipSetDevice(ctx->device);   // the caller's thread may have another device current (Python __del__ after set_device)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);   // the pair kernels read T / Tm and write the partials freed below
+#ifdef MSFM_FOLD_STAMPS
+  if (ba->fold.on) {
+    static long long h[8192][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fold_stamps), sizeof(h)) == hipSuccess) {
+      double d[8] = {0}; int n = 0;
+      for (int w = 0; w < std::min(8192, ba->fold.n_wg); w++) {
+        if (h[w][7] <= h[w][0]) continue;
+        for (int k = 1; k < 8; k++) d[k] += (double)(h[w][k] - h[w][k - 1]);
+        n++;
+      }
+      fprintf(stderr, "msfm: k_point stamps (mean over %d workgroups, cycles of wave 0): linearise %.0f, reduce+factor %.0f, Tm %.0f, round 0 %.0f, records %.0f, later rounds %.0f, fold passes %.0f\n",
+              n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n, d[7] / n);
+    }
+  }
+#endif
   if (ba->h_scal) (void)hipHostFree(ba->h_scal);
   if (ba->ev_scal) (void)hipEventDestroy(ba->ev_scal);
   if (ba->h_fail) (void)hipHostFree(ba->h_fail);
@@ -1930,6 +2083,9 @@ __global__ __launch_bounds__(256) void k_fold_wg(int npb, int n_wg, const int* _
   }
   wg_fold[w] = ok && ovf <= FOLD_OVF;
 }
+// block key of a slot: the camera-diagonal blocks first (a workgroup's diagonal slots are then its first ones, and their
+// ranks are 0 .. number of diagonal slots - 1: the index of the intrinsics x camera partials)
+__host__ __device__ inline unsigned fold_block_key(int row, int col, int ncb) { return row == col ? (unsigned)row : (unsigned)ncb + (unsigned)row * (unsigned)ncb + (unsigned)col; }
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_fold_entries(int npb, int ncb, const int* __restrict__ pt_first, const int* __restrict__ o_cb,
                                                        const int* __restrict__ o_cpos, const int* __restrict__ wg_fold, const int* __restrict__ ovf_off,
@@ -1946,7 +2102,7 @@ __global__ __launch_bounds__(256) void k_fold_entries(int npb, int ncb, const in
       for (int j = f; j < l; j++) {
         if (o_cpos[j] < 0 || o_cb[i] < o_cb[j]) continue;
         if (EMIT) {
-          key[base + n] = ((unsigned long long)w << 32) | (unsigned)(o_cb[i] * ncb + o_cb[j]);
+          key[base + n] = ((unsigned long long)w << 32) | fold_block_key(o_cb[i], o_cb[j], ncb);
           val[base + n] = (unsigned)rec(i) | ((unsigned)rec(j) << 16);
         }
         n++;
@@ -1983,19 +2139,87 @@ __global__ __launch_bounds__(256) void k_fold_rank(int n_slots, const int* __res
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r < n_slots) rank[sorted_id[r]] = r;
 }
-// first partial of every camera x camera block (the blocks are numbered in key order)
-__global__ __launch_bounds__(256) void k_fold_blk_first(int n_blocks, int n_slots, int ncb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
-                                                         const unsigned long long* __restrict__ sorted_key2, int* __restrict__ blk_fold_first) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b > n_blocks) return;
-  if (b == n_blocks) { blk_fold_first[b] = n_slots; return; }
-  const unsigned long long k = (unsigned long long)(unsigned)(blk_row[b] * ncb + blk_col[b]) << 32;
-  int lo = 0, hi = n_slots;
+// the partials of every camera x camera block: ranks [range[2 b], range[2 b + 1])
+__device__ inline int fold_lower_bound(const unsigned long long* __restrict__ sorted_key2, int n, unsigned long long k) {
+  int lo = 0, hi = n;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (sorted_key2[mid] < k) lo = mid + 1; else hi = mid;
   }
-  blk_fold_first[b] = lo;
+  return lo;
+}
+__global__ __launch_bounds__(256) void k_fold_blk_range(int n_blocks, int n_slots, int ncb, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                         const unsigned long long* __restrict__ sorted_key2, int* __restrict__ range) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_blocks) return;
+  const unsigned long long k = fold_block_key(blk_row[b], blk_col[b], ncb);
+  range[2 * b] = fold_lower_bound(sorted_key2, n_slots, k << 32);
+  range[2 * b + 1] = fold_lower_bound(sorted_key2, n_slots, (k + 1) << 32);
+}
+// Order of a workgroup's slots inside its passes: the camera-diagonal ones first (k_point counts on that), then by falling
+// entry count - the sixteen slots of a wave then take about equally long (a wave lasts as long as its longest slot: in block
+// order the waves' lanes were idle for more than half of the phase).
+__global__ __launch_bounds__(256) void k_fold_perm_key(int NS, int ncb, const unsigned long long* __restrict__ slot_key2, const int* __restrict__ slot_ent_first,
+                                                        const int* __restrict__ wg_slot_first, unsigned long long* __restrict__ key, int* __restrict__ id) {
+  const int sl = blockIdx.x * 256 + threadIdx.x;
+  if (sl >= NS) return;
+  const unsigned w = (unsigned)(slot_key2[sl] & 0xffffffffull);
+  const unsigned dg = (unsigned)(slot_key2[sl] >> 32) < (unsigned)ncb ? 0u : 1u;
+  const unsigned cnt = (unsigned)min(0x7fff, slot_ent_first[sl + 1] - slot_ent_first[sl]);
+  const unsigned loc = (unsigned)(sl - wg_slot_first[w]) & 0xffffu;
+  key[sl] = ((unsigned long long)w << 32) | (dg << 31) | ((0x7fffu - cnt) << 16) | loc;
+  id[sl] = sl;
+}
+__global__ __launch_bounds__(256) void k_fold_gather_rank(int NS, const int* __restrict__ perm, const int* __restrict__ rank, int* __restrict__ rank_pos) {
+  const int pos = blockIdx.x * 256 + threadIdx.x;
+  if (pos < NS) rank_pos[pos] = rank[perm[pos]];
+}
+// passes of every workgroup: as many slots as fit FOLD_WORDS words and FOLD_PASS_SLOTS slots.  COUNT: passes and words per
+// workgroup; EMIT: the pass descriptors, the slot headers (written into the stream here) and where every slot's entries go.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_fold_passes(int n_wg, int ncb, const int* __restrict__ wg_slot_first, const int* __restrict__ slot_ent_first,
+                                                      const unsigned long long* __restrict__ slot_key2, const int* __restrict__ perm, int* __restrict__ wg_npass, int* __restrict__ wg_words,
+                                                      const int* __restrict__ pass_first, const int* __restrict__ words_first, FoldPass* __restrict__ pass,
+                                                      unsigned* __restrict__ stream, int* __restrict__ slot_ent_pos) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= n_wg) return;
+  const int s0 = wg_slot_first[w], s1 = wg_slot_first[w + 1];
+  int np = 0, words = 0;
+  int a = s0;
+  while (a < s1) {
+    int b = a, ent = 0;
+    while (b < s1 && b - a < FOLD_PASS_SLOTS) {
+      const int c = slot_ent_first[perm[b] + 1] - slot_ent_first[perm[b]];
+      if (b > a && ((b + 1 - a + 3) & ~3) + ent + c > FOLD_WORDS) break;   // (one slot always fits: at most one entry per pair of records)
+      ent += c; b++;
+    }
+    const int hdr = (b - a + 3) & ~3, pw = (hdr + ent + 3) & ~3;
+    if (EMIT) {
+      const int off = words_first[w] + words;
+      int nd = 0, rel = 0;
+      for (int pos = a; pos < b; pos++) {
+        const int sl = perm[pos];
+        const int c = slot_ent_first[sl + 1] - slot_ent_first[sl];
+        if ((unsigned)(slot_key2[sl] >> 32) < (unsigned)ncb) nd++;
+        stream[off + (pos - a)] = (unsigned)rel | ((unsigned)c << 16);
+        slot_ent_pos[sl] = off + hdr + rel;
+        rel += c;
+      }
+      FoldPass fp;
+      fp.off = off; fp.words = pw; fp.slot0 = a; fp.n_slots = b - a; fp.n_diag = nd; fp.pad0 = fp.pad1 = fp.pad2 = 0;
+      pass[pass_first[w] + np] = fp;
+    }
+    np++; words += pw;
+    a = b;
+  }
+  if (!EMIT) { wg_npass[w] = np; wg_words[w] = words; }
+}
+__global__ __launch_bounds__(256) void k_fold_stream_entries(int E, const int* __restrict__ head, const int* __restrict__ slot_of, const int* __restrict__ slot_ent_first,
+                                                              const int* __restrict__ slot_ent_pos, const unsigned* __restrict__ ent, unsigned* __restrict__ stream) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int sl = slot_of[e] + head[e] - 1;   // (slot_of: exclusive count of slot heads)
+  stream[slot_ent_pos[sl] + (e - slot_ent_first[sl])] = ent[e];
 }
 __global__ __launch_bounds__(256) void k_fold_mark_cpos(int npb, const int* __restrict__ pt_first, const int* __restrict__ o_cpos, const int* __restrict__ wg_fold,
                                                          uint8_t* __restrict__ folded) {
@@ -2005,15 +2229,29 @@ __global__ __launch_bounds__(256) void k_fold_mark_cpos(int npb, const int* __re
 }
 __global__ __launch_bounds__(256) void k_fold_live_flags(int nch, const int* __restrict__ ch_start, const int* __restrict__ ch_end, const int* __restrict__ pa,
                                                           int* __restrict__ flag) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per chunk
   if (c >= nch) return;
   int any = 0;
-  for (int e = ch_start[c]; e < ch_end[c] && !any; e++) any = pa[e] >= 0;
-  flag[c] = any;
+  for (int e = ch_start[c] + lane; e < ch_end[c]; e += 64) any |= pa[e] >= 0;
+  any = __any(any);
+  if (lane == 0) flag[c] = any;
 }
 __global__ __launch_bounds__(256) void k_fold_live_list(int nch, const int* __restrict__ flag, const int* __restrict__ pos, int* __restrict__ live) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c < nch && flag[c]) live[pos[c]] = c;
+}
+// the partials of every intrinsics x camera block: the ranks of the camera's diagonal slots
+__global__ __launch_bounds__(256) void k_fold_mc_range(int n_blocks, int n_slots, const int* __restrict__ blk_col, const unsigned long long* __restrict__ sorted_key2,
+                                                        int* __restrict__ range) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_blocks) return;
+  const unsigned long long k = (unsigned)blk_col[b];
+  range[2 * b] = fold_lower_bound(sorted_key2, n_slots, k << 32);
+  range[2 * b + 1] = fold_lower_bound(sorted_key2, n_slots, (k + 1) << 32);
+}
+__global__ __launch_bounds__(256) void k_fold_mark_mc(int n, const uint8_t* __restrict__ folded, int* __restrict__ pa, const int* __restrict__ pb) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n && pa[e] >= 0 && folded[pb[e]]) pa[e] = ~pa[e];
 }
 __global__ __launch_bounds__(256) void k_fold_mark_pairs(int n, const uint8_t* __restrict__ folded, int* __restrict__ pa) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -2030,11 +2268,20 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
   // (small problems keep the gather path: their pair list fits the caches anyway and the tables would only lengthen the set-up;
   //  MSFM_FOLD_MIN overrides the threshold, e.g. 0 to fold everything in a test)
   static const long fold_min = getenv("MSFM_FOLD_MIN") ? atol(getenv("MSFM_FOLD_MIN")) : 262144;
-  if (off || npb == 0 || ncb == 0 || ba->cc.n_pairs == 0 || ba->cc.n_pairs < fold_min || (long)ncb * ncb > 0x7fffffffL) return MSFM_OK;
+  if (off || npb == 0 || ncb == 0 || ba->cc.n_pairs == 0 || ba->cc.n_pairs < fold_min || (long)ncb * (ncb + 1) > 0x7fffffffL) return MSFM_OK;
   hipStream_t s = ctx->stream;
   DevBuf<char> tmp;
   const int n_wg = cdiv(npb, 32);
   F.n_wg = n_wg;
+  static const bool laps = getenv("MSFM_FOLD_LAPS") != nullptr;   // developer switch: where the set-up time goes
+  auto t_last = std::chrono::steady_clock::now();
+  auto flap = [&](const char* what) {
+    if (!laps) return;
+    (void)hipStreamSynchronize(s);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "msfm: fold set-up %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   DTRY(F.wg_fold.alloc(n_wg)); DTRY(F.ovf_off.alloc(npb));
   hipLaunchKernelGGL(k_fold_wg, dim3(cdiv(n_wg, 256)), dim3(256), 0, s, npb, n_wg, ba->pt_first.p, F.ovf_off.p, F.wg_fold.p);
   DevBuf<int> count, offset;
@@ -2047,19 +2294,23 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
   DTRY(hipMemcpyAsync(&E, offset.p + npb, sizeof(int), hipMemcpyDeviceToHost, s));
   DTRY(hipStreamSynchronize(s));
   if (E <= 0) return MSFM_OK;
+  flap("count entries");
   DevBuf<unsigned long long> key, key_s, slot_key2, slot_key2_s;
   DevBuf<unsigned> val;
   DevBuf<int> head, slot_of, slot_id, slot_id_s;
-  DTRY(key.alloc(E)); DTRY(key_s.alloc(E)); DTRY(val.alloc(E)); DTRY(F.ent.alloc(E));
+  DevBuf<unsigned> ent_sorted;
+  DTRY(key.alloc(E)); DTRY(key_s.alloc(E)); DTRY(val.alloc(E)); DTRY(ent_sorted.alloc(E));
   hipLaunchKernelGGL((k_fold_entries<true>), dim3(cdiv(npb, 256)), dim3(256), 0, s, npb, ncb, ba->pt_first.p, ba->o_cb.p, ba->o_cpos.p, F.wg_fold.p,
                      F.ovf_off.p, (int*)nullptr, offset.p, key.p, val.p);
   {
     size_t bytes = 0;
     const int bits = 32 + bits_for(std::max(2, n_wg));
-    DTRY(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, val.p, F.ent.p, (size_t)E, 0, bits, s));
+    DTRY(rocprim::radix_sort_pairs(nullptr, bytes, key.p, key_s.p, val.p, ent_sorted.p, (size_t)E, 0, bits, s));
     if (tmp.n < bytes) DTRY(tmp.alloc(bytes));
-    DTRY(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, val.p, F.ent.p, (size_t)E, 0, bits, s));   // stable: point order inside a slot
+    flap("emit entries");
+    DTRY(rocprim::radix_sort_pairs(tmp.p, bytes, key.p, key_s.p, val.p, ent_sorted.p, (size_t)E, 0, bits, s));   // stable: point order inside a slot
   }
+  flap("sort entries");
   DTRY(head.alloc((size_t)E + 1)); DTRY(slot_of.alloc((size_t)E + 1));
   DTRY(hipMemsetAsync(head.p + E, 0, sizeof(int), s));
   hipLaunchKernelGGL(k_fold_heads, dim3(cdiv(E, 256)), dim3(256), 0, s, E, key_s.p, head.p);
@@ -2067,22 +2318,67 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
   int NS = 0;
   DTRY(hipMemcpyAsync(&NS, slot_of.p + E, sizeof(int), hipMemcpyDeviceToHost, s));
   DTRY(hipStreamSynchronize(s));
-  DTRY(F.slot_ent_first.alloc((size_t)NS + 1)); DTRY(slot_key2.alloc(NS)); DTRY(slot_key2_s.alloc(NS)); DTRY(slot_id.alloc(NS)); DTRY(slot_id_s.alloc(NS));
-  hipLaunchKernelGGL(k_fold_slots, dim3(cdiv(E, 256)), dim3(256), 0, s, E, key_s.p, head.p, slot_of.p, F.slot_ent_first.p, slot_key2.p, slot_id.p);
-  DTRY(hipMemcpyAsync(F.slot_ent_first.p + NS, &E, sizeof(int), hipMemcpyHostToDevice, s));
-  DTRY(F.wg_slot_first.alloc((size_t)n_wg + 1));
-  hipLaunchKernelGGL(k_fold_wg_first, dim3(cdiv(n_wg + 1, 256)), dim3(256), 0, s, n_wg, NS, slot_key2.p, F.wg_slot_first.p);
+  DevBuf<int> slot_ent_first;
+  DTRY(slot_ent_first.alloc((size_t)NS + 1)); DTRY(slot_key2.alloc(NS)); DTRY(slot_key2_s.alloc(NS)); DTRY(slot_id.alloc(NS)); DTRY(slot_id_s.alloc(NS));
+  hipLaunchKernelGGL(k_fold_slots, dim3(cdiv(E, 256)), dim3(256), 0, s, E, key_s.p, head.p, slot_of.p, slot_ent_first.p, slot_key2.p, slot_id.p);
+  DTRY(hipMemcpyAsync(slot_ent_first.p + NS, &E, sizeof(int), hipMemcpyHostToDevice, s));
+  DevBuf<int> wg_slot_first;
+  DTRY(wg_slot_first.alloc((size_t)n_wg + 1));
+  hipLaunchKernelGGL(k_fold_wg_first, dim3(cdiv(n_wg + 1, 256)), dim3(256), 0, s, n_wg, NS, slot_key2.p, wg_slot_first.p);
+  flap("slots");
+  // the passes and the stream they read
+  DevBuf<int> perm;
+  {
+    DevBuf<unsigned long long> pk, pk_s;
+    DevBuf<int> pid;
+    DTRY(pk.alloc(NS)); DTRY(pk_s.alloc(NS)); DTRY(pid.alloc(NS)); DTRY(perm.alloc(NS));
+    hipLaunchKernelGGL(k_fold_perm_key, dim3(cdiv(NS, 256)), dim3(256), 0, s, NS, ncb, slot_key2.p, slot_ent_first.p, wg_slot_first.p, pk.p, pid.p);
+    size_t bytes = 0;
+    const int bits = 32 + bits_for(std::max(2, n_wg));
+    DTRY(rocprim::radix_sort_pairs(nullptr, bytes, pk.p, pk_s.p, pid.p, perm.p, (size_t)NS, 0, bits, s));
+    if (tmp.n < bytes) DTRY(tmp.alloc(bytes));
+    DTRY(rocprim::radix_sort_pairs(tmp.p, bytes, pk.p, pk_s.p, pid.p, perm.p, (size_t)NS, 0, bits, s));
+    DTRY(hipStreamSynchronize(s));
+  }
+  flap("slot order");
+  {
+    DevBuf<int> wg_npass, wg_words, words_first, slot_ent_pos;
+    DTRY(wg_npass.alloc((size_t)n_wg + 1)); DTRY(wg_words.alloc((size_t)n_wg + 1)); DTRY(words_first.alloc((size_t)n_wg + 1));
+    DTRY(F.wg_pass_first.alloc((size_t)n_wg + 1)); DTRY(slot_ent_pos.alloc(NS));
+    DTRY(hipMemsetAsync(wg_npass.p + n_wg, 0, sizeof(int), s)); DTRY(hipMemsetAsync(wg_words.p + n_wg, 0, sizeof(int), s));
+    hipLaunchKernelGGL((k_fold_passes<false>), dim3(cdiv(n_wg, 256)), dim3(256), 0, s, n_wg, ncb, wg_slot_first.p, slot_ent_first.p, slot_key2.p, perm.p, wg_npass.p, wg_words.p,
+                       (const int*)nullptr, (const int*)nullptr, (FoldPass*)nullptr, (unsigned*)nullptr, (int*)nullptr);
+    DTRY(excl_scan(wg_npass.p, F.wg_pass_first.p, (size_t)n_wg + 1, s, tmp));
+    DTRY(excl_scan(wg_words.p, words_first.p, (size_t)n_wg + 1, s, tmp));
+    int npass = 0, nwords = 0;
+    DTRY(hipMemcpyAsync(&npass, F.wg_pass_first.p + n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
+    DTRY(hipMemcpyAsync(&nwords, words_first.p + n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
+    DTRY(hipStreamSynchronize(s));
+    DTRY(F.pass.alloc((size_t)std::max(1, npass))); DTRY(F.stream.alloc((size_t)nwords + FOLD_WORDS));
+    DTRY(hipMemsetAsync(F.stream.p, 0, sizeof(unsigned) * ((size_t)nwords + FOLD_WORDS), s));
+    hipLaunchKernelGGL((k_fold_passes<true>), dim3(cdiv(n_wg, 256)), dim3(256), 0, s, n_wg, ncb, wg_slot_first.p, slot_ent_first.p, slot_key2.p, perm.p, (int*)nullptr, (int*)nullptr,
+                       F.wg_pass_first.p, words_first.p, F.pass.p, F.stream.p, slot_ent_pos.p);
+    hipLaunchKernelGGL(k_fold_stream_entries, dim3(cdiv(E, 256)), dim3(256), 0, s, E, head.p, slot_of.p, slot_ent_first.p, slot_ent_pos.p, ent_sorted.p, F.stream.p);
+    F.n_pass = npass;
+    DTRY(hipStreamSynchronize(s));
+  }
   {
     size_t bytes = 0;
     DTRY(rocprim::radix_sort_pairs(nullptr, bytes, slot_key2.p, slot_key2_s.p, slot_id.p, slot_id_s.p, (size_t)NS, 0, 64, s));
     if (tmp.n < bytes) DTRY(tmp.alloc(bytes));
     DTRY(rocprim::radix_sort_pairs(tmp.p, bytes, slot_key2.p, slot_key2_s.p, slot_id.p, slot_id_s.p, (size_t)NS, 0, 64, s));
   }
-  DTRY(F.slot_rank.alloc(NS));
-  hipLaunchKernelGGL(k_fold_rank, dim3(cdiv(NS, 256)), dim3(256), 0, s, NS, slot_id_s.p, F.slot_rank.p);
-  DTRY(F.blk_fold_first.alloc((size_t)ba->cc.n_blocks + 1));
-  hipLaunchKernelGGL(k_fold_blk_first, dim3(cdiv(ba->cc.n_blocks + 1, 256)), dim3(256), 0, s, ba->cc.n_blocks, NS, ncb, ba->cc.blk_row.p, ba->cc.blk_col.p,
-                     slot_key2_s.p, F.blk_fold_first.p);
+  {
+    DevBuf<int> rank;   // by slot; k_point asks by position inside the workgroup's passes
+    DTRY(rank.alloc(NS)); DTRY(F.slot_rank.alloc(NS));
+    hipLaunchKernelGGL(k_fold_rank, dim3(cdiv(NS, 256)), dim3(256), 0, s, NS, slot_id_s.p, rank.p);
+    hipLaunchKernelGGL(k_fold_gather_rank, dim3(cdiv(NS, 256)), dim3(256), 0, s, NS, perm.p, rank.p, F.slot_rank.p);
+    DTRY(hipStreamSynchronize(s));
+  }
+  DTRY(F.blk_range.alloc(2 * (size_t)std::max(1, ba->cc.n_blocks)));
+  hipLaunchKernelGGL(k_fold_blk_range, dim3(cdiv(std::max(1, ba->cc.n_blocks), 256)), dim3(256), 0, s, ba->cc.n_blocks, NS, ncb, ba->cc.blk_row.p, ba->cc.blk_col.p,
+                     slot_key2_s.p, F.blk_range.p);
+  flap("passes, stream, ranks, ranges");
   // the same entries leave the gather path
   DevBuf<uint8_t> folded;
   DTRY(folded.alloc((size_t)std::max(1, ba->NCR)));
@@ -2091,27 +2387,62 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
   hipLaunchKernelGGL(k_fold_mark_pairs, dim3(cdiv(ba->cc.n_pairs, 256)), dim3(256), 0, s, ba->cc.n_pairs, folded.p, ba->cc.pa.p);
   DTRY(F.partial.alloc((size_t)NS * 36));
   // chunks that keep a live entry: the gather kernel visits only those, the partials of the others are zero for good
-  {
+  auto live_chunks = [&](PairJobs& J, int width, int& n_live, DevBuf<int>& live) -> int {
     DevBuf<int> lf, lpos;
-    const int nch = ba->cc.n_chunks;
+    const int nch = J.n_chunks;
     DTRY(lf.alloc((size_t)nch + 1)); DTRY(lpos.alloc((size_t)nch + 1));
     DTRY(hipMemsetAsync(lf.p + nch, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_fold_live_flags, dim3(cdiv(std::max(1, nch), 256)), dim3(256), 0, s, nch, ba->cc.ch_start.p, ba->cc.ch_end.p, ba->cc.pa.p, lf.p);
+    hipLaunchKernelGGL(k_fold_live_flags, dim3(cdiv(std::max(1, nch), 4)), dim3(256), 0, s, nch, J.ch_start.p, J.ch_end.p, J.pa.p, lf.p);
     DTRY(excl_scan(lf.p, lpos.p, (size_t)nch + 1, s, tmp));
-    DTRY(hipMemcpyAsync(&F.n_live, lpos.p + nch, sizeof(int), hipMemcpyDeviceToHost, s));
+    DTRY(hipMemcpyAsync(&n_live, lpos.p + nch, sizeof(int), hipMemcpyDeviceToHost, s));
     DTRY(hipStreamSynchronize(s));
-    DTRY(F.live_chunk.alloc((size_t)std::max(1, F.n_live)));
-    hipLaunchKernelGGL(k_fold_live_list, dim3(cdiv(std::max(1, nch), 256)), dim3(256), 0, s, nch, lf.p, lpos.p, F.live_chunk.p);
-    DTRY(hipMemsetAsync(ba->cc.partial.p, 0, sizeof(double) * 36 * (size_t)std::max(1, nch), s));
+    DTRY(live.alloc((size_t)std::max(1, n_live)));
+    hipLaunchKernelGGL(k_fold_live_list, dim3(cdiv(std::max(1, nch), 256)), dim3(256), 0, s, nch, lf.p, lpos.p, live.p);
+    DTRY(hipMemsetAsync(J.partial.p, 0, sizeof(double) * width * (size_t)std::max(1, nch), s));
     DTRY(hipStreamSynchronize(s));
+    return MSFM_OK;
+  };
+  MSFM_TRY(live_chunks(ba->cc, 36, F.n_live, F.live_chunk));
+  flap("mark + live chunks");
+  // intrinsics x camera list: with ONE intrinsics block every point has at most one (point, intrinsics) entry and the
+  // products Tm_p T^T of a camera are summed over exactly the records of its diagonal slots
+  F.mc_on = false;
+  static const bool mc_off = getenv("MSFM_NO_FOLD_MC") != nullptr;
+  if (!mc_off && ba->nmb == 1 && ba->mc.n_pairs > 0) {
+    DTRY(F.mc_range.alloc(2 * (size_t)ba->mc.n_blocks));
+    hipLaunchKernelGGL(k_fold_mc_range, dim3(cdiv(ba->mc.n_blocks, 256)), dim3(256), 0, s, ba->mc.n_blocks, NS, ba->mc.blk_col.p, slot_key2_s.p, F.mc_range.p);
+    // (diagonal keys are the ncb smallest: their slots have the ranks 0 .. n_diag - 1)
+    {
+      DevBuf<int> one;
+      DTRY(one.alloc(2));
+      int col = ncb;   // k_fold_mc_range on a single pseudo block with column ncb gives lower_bound(ncb << 32) in range[0]
+      DevBuf<int> colbuf;
+      DTRY(colbuf.alloc(1));
+      DTRY(hipMemcpyAsync(colbuf.p, &col, sizeof(int), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_fold_mc_range, dim3(1), dim3(256), 0, s, 1, NS, colbuf.p, slot_key2_s.p, one.p);
+      int h[2] = {0, 0};
+      DTRY(hipMemcpyAsync(h, one.p, sizeof(h), hipMemcpyDeviceToHost, s));
+      DTRY(hipStreamSynchronize(s));
+      F.n_diag = h[0];
+    }
+    if (F.n_diag > 0) {
+      DTRY(F.mc_partial.alloc((size_t)F.n_diag * 18));
+      DTRY(hipMemsetAsync(F.mc_partial.p, 0, sizeof(double) * 18 * (size_t)F.n_diag, s));
+      hipLaunchKernelGGL(k_fold_mark_mc, dim3(cdiv(ba->mc.n_pairs, 256)), dim3(256), 0, s, ba->mc.n_pairs, folded.p, ba->mc.pa.p, ba->mc.pb.p);
+      MSFM_TRY(live_chunks(ba->mc, 18, F.mc_n_live, F.mc_live_chunk));
+      F.mc_on = true;
+      F.mc_all = F.mc_n_live == 0;
+    }
   }
+  flap("intrinsics x camera");
   DTRY(hipGetLastError());
   DTRY(hipStreamSynchronize(s));   // the temporaries above go back to the pool
   F.n_slots = NS; F.n_entries = E;
   F.on = true;
   F.all = E == ba->cc.n_pairs;
   if (getenv("MSFM_VERBOSE") && ctx->rank == 0)
-    fprintf(stderr, "msfm: fold tables: %d workgroups, %d slots (%.1f MB of partials), %d of %d entries folded\n", n_wg, NS, NS * 288e-6, E, ba->cc.n_pairs);
+    fprintf(stderr, "msfm: fold tables: %d workgroups, %d passes, %d slots (%.1f MB of partials), %d of %d entries folded; intrinsics x camera: %s, %d diagonal slots, %d of %d chunks live\n",
+            n_wg, F.n_pass, NS, NS * 288e-6, E, ba->cc.n_pairs, F.mc_on ? "folded" : "gathered", F.n_diag, F.mc_n_live, ba->mc.n_chunks);
   return MSFM_OK;
 }
 
@@ -2998,8 +3329,9 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     Q.reuse_diag = reuse_diag; Q.mode = mode; Q.fail = ba->fail.p;
     Q.store_rows = store_rows ? 1 : 0; Q.cost_partial = ba->partial.p;
     const FoldTables& F = ba->fold;
-    Q.fold_wg = F.on ? F.wg_fold.p : nullptr; Q.fold_ovf_off = F.ovf_off.p; Q.fold_wg_slot_first = F.wg_slot_first.p;
-    Q.fold_slot_ent_first = F.slot_ent_first.p; Q.fold_slot_rank = F.slot_rank.p; Q.fold_ent = F.ent.p; Q.fold_partial = F.partial.p;
+    Q.fold_wg = F.on ? F.wg_fold.p : nullptr; Q.fold_ovf_off = F.ovf_off.p; Q.fold_wg_pass_first = F.wg_pass_first.p; Q.fold_slot_rank = F.slot_rank.p;
+    Q.fold_pass = F.pass.p; Q.fold_stream = F.stream.p; Q.fold_partial = F.partial.p;
+    Q.fold_mc_partial = (F.on && F.mc_on) ? F.mc_partial.p : nullptr;
     hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, s, Q, ba->gmax_buf.p);
   }
   // The Schur pair products read only what k_point wrote (T, Tm, Tmu) and write their own partials; the per-camera sums
@@ -3010,7 +3342,12 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   // camera x camera list does, so those two would only slow each other down - and the large list last, beside the
   // latency-bound k_camftf / k_modelsum / k_reduce tail of the main stream)
   auto launch_pairs = [&](hipStream_t sp) {
-    if (ba->mc.n_chunks)
+    if (ba->fold.on && ba->fold.mc_on) {
+      if (ba->fold.mc_n_live)
+        hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->fold.mc_n_live, 4)), dim3(256), 0, sp, ba->fold.mc_n_live, ba->mc.ch_start.p,
+                           ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR),
+                           ba->mc.partial.p, ba->fold.mc_live_chunk.p);
+    } else if (ba->mc.n_chunks)
       hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->mc.n_chunks, 4)), dim3(256), 0, sp, ba->mc.n_chunks, ba->mc.ch_start.p,
                          ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->mc.partial.p);
     if (ba->mm.n_chunks)
@@ -3113,8 +3450,13 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     AsmArgs aa;
     aa.n_cc = ba->cc.n_blocks; aa.n_mc = ba->mc.n_blocks; aa.n_mm = ba->mm.n_blocks; aa.n_rhs = cdiv(6 * ncb, 64);
     aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = (ba->fold.on && ba->fold.all) ? nullptr : ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
-    aa.cc_fold_first = ba->fold.on ? ba->fold.blk_fold_first.p : nullptr; aa.cc_fold_partial = ba->fold.partial.p;
-    aa.mc_row = ba->mc.blk_row.p; aa.mc_col = ba->mc.blk_col.p; aa.mc_first = ba->mc.blk_chunk_first.p; aa.mc_partial = ba->mc.partial.p;
+    aa.cc_fold_first = ba->fold.on ? ba->fold.blk_range.p : nullptr; aa.cc_fold_partial = ba->fold.partial.p;
+    aa.mc_row = ba->mc.blk_row.p; aa.mc_col = ba->mc.blk_col.p; aa.mc_partial = ba->mc.partial.p;
+    {
+      const bool fmc = ba->fold.on && ba->fold.mc_on;
+      aa.mc_first = (fmc && ba->fold.mc_all) ? nullptr : ba->mc.blk_chunk_first.p;
+      aa.mc_fold_range = fmc ? ba->fold.mc_range.p : nullptr; aa.mc_fold_partial = ba->fold.mc_partial.p;
+    }
     aa.mm_row = ba->mm.blk_row.p; aa.mm_col = ba->mm.blk_col.p; aa.mm_first = ba->mm.blk_chunk_first.p; aa.mm_partial = ba->mm.partial.p;
     aa.cb_mb = ba->cb_mb.p; aa.cb_off = ba->cb_off.p; aa.camftf = ba->camftf.p; aa.diag_c = ba->diag_c.p; aa.modelsum = ba->modelsum.p;
     aa.diag_m = ba->diag_m.p; aa.radius = radius; aa.ncb = ncb; aa.mo = ba->mo; aa.n = ba->nsys; aa.ld = ba->npad; aa.lead = lead; aa.M = ba->M.p;
