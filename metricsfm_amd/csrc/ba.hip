@@ -938,38 +938,47 @@ __global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int
   for (int e = threadIdx.x; e < 64 * 32; e += 256) base[(size_t)(e >> 5) * (ld / 2) + (e & 31)] = make_double2(0.0, 0.0);
 }
 
-// camera-camera blocks: 64 threads (36 used) per block.
-__device__ __forceinline__ void asm_cc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
-                                       const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
+// camera-camera blocks: three blocks per 64-thread workgroup, 18 threads per block, two neighbouring entries of a row each
+// (16-byte loads of the partials, one 16-byte store into M: the launch is bound by the number of waves and their dependent
+// loads, not by bytes - one block per wave with 36 single entries took 0.059 ms at config 3, this 0.055; skipping the zero chunk partials 0.052).
+__device__ __forceinline__ void asm_cc(int b, int t2, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                       const int* __restrict__ blk_chunk_first, const uint8_t* __restrict__ blk_live, const double* __restrict__ partial,
                                        const int* __restrict__ blk_fold_range, const double* __restrict__ fold_partial,
                                        const double* __restrict__ camftf, const double* __restrict__ diag_c,
                                        double radius, const int* __restrict__ cb_off, double* __restrict__ M, int ld, int lead) {
-  const int t = threadIdx.x;
-  if (t >= 36) return;
   const int rb = blk_row[b], cbk = blk_col[b];
-  double s = 0.0;
-  if (blk_chunk_first)   // (nullptr: every entry was folded into k_point, the gather kernel did not run)
-    for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 36 + t];
+  const int t = 2 * t2;
+  double s0 = 0.0, s1 = 0.0;
+  // (blk_chunk_first nullptr: every entry was folded into k_point, the gather kernel did not run; blk_live: which blocks still
+  //  have an entry on the gather path - the chunk partials of the others are zero and their two dependent loads are skipped)
+  if (blk_chunk_first && (!blk_live || blk_live[b]))
+    for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) {
+      const double2 v = *reinterpret_cast<const double2*>(partial + (size_t)ch * 36 + t);
+      s0 += v.x; s1 += v.y;
+    }
   if (blk_fold_range) {   // the products formed inside k_point: one partial per (workgroup, block), in workgroup order
     // four running sums (slots sl, sl + 1, sl + 2, sl + 3 mod 4) keep four loads in flight; combined in a fixed order
-    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    double2 q0 = make_double2(0.0, 0.0), q1 = q0, q2 = q0, q3 = q0;
     const int f0 = blk_fold_range[2 * b], f1 = blk_fold_range[2 * b + 1];
+    const double2* fp = reinterpret_cast<const double2*>(fold_partial + t);
     int sl = f0;
     for (; sl + 3 < f1; sl += 4) {
-      const double v0 = fold_partial[(size_t)sl * 36 + t], v1 = fold_partial[(size_t)(sl + 1) * 36 + t];
-      const double v2 = fold_partial[(size_t)(sl + 2) * 36 + t], v3 = fold_partial[(size_t)(sl + 3) * 36 + t];
-      q0 += v0; q1 += v1; q2 += v2; q3 += v3;
+      const double2 v0 = fp[(size_t)sl * 18], v1 = fp[(size_t)(sl + 1) * 18], v2 = fp[(size_t)(sl + 2) * 18], v3 = fp[(size_t)(sl + 3) * 18];
+      q0.x += v0.x; q0.y += v0.y; q1.x += v1.x; q1.y += v1.y; q2.x += v2.x; q2.y += v2.y; q3.x += v3.x; q3.y += v3.y;
     }
-    for (; sl < f1; sl++) q0 += fold_partial[(size_t)sl * 36 + t];
-    s += (q0 + q1) + (q2 + q3);
+    for (; sl < f1; sl++) { const double2 v = fp[(size_t)sl * 18]; q0.x += v.x; q0.y += v.y; }
+    s0 += (q0.x + q1.x) + (q2.x + q3.x);
+    s1 += (q0.y + q1.y) + (q2.y + q3.y);
   }
-  double v = -s;
+  double v0 = -s0, v1 = -s1;
   const int a = t / 6, c = t % 6;
   if (rb == cbk && lead) {
-    v += camftf[(size_t)rb * PSTRIDE + F_JCJC + t];
-    if (a == c) { const double q = sqrt(diag_c[6 * rb + a] / radius); v += q * q; }
+    const double2 f = *reinterpret_cast<const double2*>(camftf + (size_t)rb * PSTRIDE + F_JCJC + t);
+    v0 += f.x; v1 += f.y;
+    if (a == c) { const double q = sqrt(diag_c[6 * rb + a] / radius); v0 += q * q; }
+    if (a == c + 1) { const double q = sqrt(diag_c[6 * rb + a] / radius); v1 += q * q; }
   }
-  M[(size_t)(cb_off[rb] + a) * ld + cb_off[cbk] + c] = v;
+  *reinterpret_cast<double2*>(&M[(size_t)(cb_off[rb] + a) * ld + cb_off[cbk] + c]) = make_double2(v0, v1);
 }
 
 // intrinsics-camera blocks (rows 6*ncb + 3*mb.., cols 6*cb..): 18 used threads.
@@ -1053,6 +1062,7 @@ struct AsmArgs {
   int n_cc, n_mc, n_mm, n_rhs, n_padcol;   // n_padcol > 0 only on a single rank (with several, the padding follows the exchange)
   const int* padcol;
   const int* cc_fold_first;
+  const uint8_t* cc_live;
   const double* cc_fold_partial;
   const int* mc_fold_range;
   const double* mc_fold_partial;
@@ -1064,8 +1074,14 @@ struct AsmArgs {
 };
 __global__ __launch_bounds__(64) void k_asm_all(AsmArgs a) {
   int b = blockIdx.x;
-  if (b < a.n_cc) { asm_cc(b, a.cc_row, a.cc_col, a.cc_first, a.cc_partial, a.cc_fold_first, a.cc_fold_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead); return; }
-  b -= a.n_cc;
+  const int n_cc3 = (a.n_cc + 2) / 3;
+  if (b < n_cc3) {
+    const int sub = (int)threadIdx.x / 18, blk = 3 * b + sub;
+    if (sub < 3 && blk < a.n_cc)
+      asm_cc(blk, (int)threadIdx.x - 18 * sub, a.cc_row, a.cc_col, a.cc_first, a.cc_live, a.cc_partial, a.cc_fold_first, a.cc_fold_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead);
+    return;
+  }
+  b -= n_cc3;
   if (b < a.n_mc) { asm_mc(b, a.mc_row, a.mc_col, a.mc_first, a.mc_partial, a.mc_fold_range, a.mc_fold_partial, a.camftf, a.cb_mb, a.cb_off, a.mo, a.M, a.ld, a.lead); return; }
   b -= a.n_mc;
   if (b < a.n_mm) { asm_mm(b, a.mm_row, a.mm_col, a.mm_first, a.mm_partial, a.modelsum, a.diag_m, a.radius, a.mo, a.n, a.M, a.ld, a.lead); return; }
@@ -1295,6 +1311,7 @@ struct FoldTables {
   DevBuf<int> live_chunk;
   int n_wg = 0, n_slots = 0, n_entries = 0, n_pass = 0;
   DevBuf<int> wg_fold, ovf_off, wg_pass_first, slot_rank, blk_range;
+  DevBuf<uint8_t> blk_live;   // camera x camera blocks that still have an entry on the gather path
   DevBuf<FoldPass> pass;
   DevBuf<unsigned> stream;   // per pass: slot headers, then entries (FoldPass); FOLD_WORDS words of padding behind the last pass
   DevBuf<double> partial;
@@ -2236,6 +2253,13 @@ __global__ __launch_bounds__(256) void k_fold_live_flags(int nch, const int* __r
   any = __any(any);
   if (lane == 0) flag[c] = any;
 }
+__global__ __launch_bounds__(256) void k_fold_blk_live(int n_blocks, const int* __restrict__ blk_chunk_first, const int* __restrict__ flag, uint8_t* __restrict__ live) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_blocks) return;
+  int any = 0;
+  for (int c = blk_chunk_first[b]; c < blk_chunk_first[b + 1]; c++) any |= flag[c];
+  live[b] = (uint8_t)any;
+}
 __global__ __launch_bounds__(256) void k_fold_live_list(int nch, const int* __restrict__ flag, const int* __restrict__ pos, int* __restrict__ live) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c < nch && flag[c]) live[pos[c]] = c;
@@ -2387,7 +2411,7 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
   hipLaunchKernelGGL(k_fold_mark_pairs, dim3(cdiv(ba->cc.n_pairs, 256)), dim3(256), 0, s, ba->cc.n_pairs, folded.p, ba->cc.pa.p);
   DTRY(F.partial.alloc((size_t)NS * 36));
   // chunks that keep a live entry: the gather kernel visits only those, the partials of the others are zero for good
-  auto live_chunks = [&](PairJobs& J, int width, int& n_live, DevBuf<int>& live) -> int {
+  auto live_chunks = [&](PairJobs& J, int width, int& n_live, DevBuf<int>& live, DevBuf<uint8_t>* blk_live) -> int {
     DevBuf<int> lf, lpos;
     const int nch = J.n_chunks;
     DTRY(lf.alloc((size_t)nch + 1)); DTRY(lpos.alloc((size_t)nch + 1));
@@ -2398,11 +2422,15 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
     DTRY(hipStreamSynchronize(s));
     DTRY(live.alloc((size_t)std::max(1, n_live)));
     hipLaunchKernelGGL(k_fold_live_list, dim3(cdiv(std::max(1, nch), 256)), dim3(256), 0, s, nch, lf.p, lpos.p, live.p);
+    if (blk_live) {
+      DTRY(blk_live->alloc((size_t)std::max(1, J.n_blocks)));
+      hipLaunchKernelGGL(k_fold_blk_live, dim3(cdiv(std::max(1, J.n_blocks), 256)), dim3(256), 0, s, J.n_blocks, J.blk_chunk_first.p, lf.p, blk_live->p);
+    }
     DTRY(hipMemsetAsync(J.partial.p, 0, sizeof(double) * width * (size_t)std::max(1, nch), s));
     DTRY(hipStreamSynchronize(s));
     return MSFM_OK;
   };
-  MSFM_TRY(live_chunks(ba->cc, 36, F.n_live, F.live_chunk));
+  MSFM_TRY(live_chunks(ba->cc, 36, F.n_live, F.live_chunk, &F.blk_live));
   flap("mark + live chunks");
   // intrinsics x camera list: with ONE intrinsics block every point has at most one (point, intrinsics) entry and the
   // products Tm_p T^T of a camera are summed over exactly the records of its diagonal slots
@@ -2429,7 +2457,7 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
       DTRY(F.mc_partial.alloc((size_t)F.n_diag * 18));
       DTRY(hipMemsetAsync(F.mc_partial.p, 0, sizeof(double) * 18 * (size_t)F.n_diag, s));
       hipLaunchKernelGGL(k_fold_mark_mc, dim3(cdiv(ba->mc.n_pairs, 256)), dim3(256), 0, s, ba->mc.n_pairs, folded.p, ba->mc.pa.p, ba->mc.pb.p);
-      MSFM_TRY(live_chunks(ba->mc, 18, F.mc_n_live, F.mc_live_chunk));
+      MSFM_TRY(live_chunks(ba->mc, 18, F.mc_n_live, F.mc_live_chunk, nullptr));
       F.mc_on = true;
       F.mc_all = F.mc_n_live == 0;
     }
@@ -3450,7 +3478,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     AsmArgs aa;
     aa.n_cc = ba->cc.n_blocks; aa.n_mc = ba->mc.n_blocks; aa.n_mm = ba->mm.n_blocks; aa.n_rhs = cdiv(6 * ncb, 64);
     aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = (ba->fold.on && ba->fold.all) ? nullptr : ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
-    aa.cc_fold_first = ba->fold.on ? ba->fold.blk_range.p : nullptr; aa.cc_fold_partial = ba->fold.partial.p;
+    aa.cc_fold_first = ba->fold.on ? ba->fold.blk_range.p : nullptr; aa.cc_live = ba->fold.on ? ba->fold.blk_live.p : nullptr; aa.cc_fold_partial = ba->fold.partial.p;
     aa.mc_row = ba->mc.blk_row.p; aa.mc_col = ba->mc.blk_col.p; aa.mc_partial = ba->mc.partial.p;
     {
       const bool fmc = ba->fold.on && ba->fold.mc_on;
@@ -3462,7 +3490,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     aa.diag_m = ba->diag_m.p; aa.radius = radius; aa.ncb = ncb; aa.mo = ba->mo; aa.n = ba->nsys; aa.ld = ba->npad; aa.lead = lead; aa.M = ba->M.p;
     aa.n_padcol = ctx->world <= 1 ? ba->n_padcol : 0;
     aa.padcol = ba->padcol.p;
-    const int nasm = aa.n_cc + aa.n_mc + aa.n_mm + aa.n_rhs + cdiv(aa.n_padcol, 64);
+    const int nasm = cdiv(aa.n_cc, 3) + aa.n_mc + aa.n_mm + aa.n_rhs + cdiv(aa.n_padcol, 64);
     if (nasm) hipLaunchKernelGGL(k_asm_all, dim3(nasm), dim3(64), 0, s, aa);
   }
   hipError_t e = hipGetLastError();

@@ -12,12 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,which,port", [(2, "c2", 29741), (3, "gps", 29742), (2, "domains", 29743), (2, "c3", 29745), (2, "c5w", 29746)])
+@pytest.mark.parametrize("world,which,port", [(2, "c2", 29741), (3, "gps", 29742), (2, "domains", 29743), (2, "c3", 29745), (2, "c5w", 29746), (2, "c2+fold", 29748), (3, "gps+fold", 29749)])
 def test_sharded_ba_matches_single_rank(tmp_path, world, which, port):
     out = tmp_path / "mr.npz"
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if which == "domains":
         env["MSFM_CHOL_DOMAINS"] = "2"
+    if which.endswith("+fold"):   # the Schur products formed inside k_point (FoldTables) also on these small problems
+        env["MSFM_FOLD_MIN"] = "0"
+        which = which[:-5]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "multirank_worker.py"), str(out), which]
     subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=600)
