@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -140,11 +141,17 @@ __device__ __forceinline__ int32_t ratio_code(float d0, float d1, int id0, float
 }
 
 // merge candidate (d, i) into the sorted pair (d0,i0) <= (d1,i1); ties keep the earlier (lower index first)
+// (selects, not branches: with `if (lt0) ... else if (lt1) ...` the compiler kept the four values of every query in scratch
+//  memory and wrote them through computed addresses - ten dependent scratch round trips per window flush)
 __device__ __forceinline__ void top2_insert(u32& d0, int& i0, u32& d1, int& i1, u32 d, int i) {
   const bool lt0 = d < d0 || (d == d0 && i < i0);
   const bool lt1 = d < d1 || (d == d1 && i < i1);
-  if (lt0) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
-  else if (lt1) { d1 = d; i1 = i; }
+  const u32 nd1 = lt0 ? d0 : (lt1 ? d : d1);
+  const int ni1 = lt0 ? i0 : (lt1 ? i : i1);
+  d0 = lt0 ? d : d0;
+  i0 = lt0 ? i : i0;
+  d1 = nd1;
+  i1 = ni1;
 }
 
 // merge a window's two packed keys into the lane's running (distance, row) top-2
@@ -312,12 +319,14 @@ struct PairTask8 {
 };
 
 __device__ __forceinline__ void flush_window8(u32& k0, u32& k1, u32& D0, int& I0, u32& D1, int& I1, int base) {
-  if (k0 != 0xffffffffu) top2_insert(D0, I0, D1, I1, ((k0 >> 9) << 1) | ((k0 >> 8) & 1u), base + (int)(k0 & 255u));
-  if (k1 != 0xffffffffu) top2_insert(D0, I0, D1, I1, ((k1 >> 9) << 1) | ((k1 >> 8) & 1u), base + (int)(k1 & 255u));
+  // (an empty slot becomes the candidate (0xffffffff, INT_MAX), which loses every comparison: no branch)
+  const bool e0 = k0 == 0xffffffffu, e1 = k1 == 0xffffffffu;
+  top2_insert(D0, I0, D1, I1, e0 ? 0xffffffffu : (((k0 >> 9) << 1) | ((k0 >> 8) & 1u)), e0 ? 0x7fffffff : base + (int)(k0 & 255u));
+  top2_insert(D0, I0, D1, I1, e1 ? 0xffffffffu : (((k1 >> 9) << 1) | ((k1 >> 8) & 1u)), e1 ? 0x7fffffff : base + (int)(k1 & 255u));
   k0 = k1 = 0xffffffffu;
 }
 
-__global__ __launch_bounds__(256, 2) void k_knn2_i8(const PairTask8* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+__global__ __launch_bounds__(256, 3) void k_knn2_i8(const PairTask8* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
                                                      float ratio_good, float ratio_all, int32_t* __restrict__ code,
                                                      int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ n_all,
                                                      int* __restrict__ n_good) {
@@ -380,6 +389,14 @@ __global__ __launch_bounds__(256, 2) void k_knn2_i8(const PairTask8* __restrict_
   commit(0);
   __syncthreads();
   int cur = 0;
+  // Measured round 3 (config-2-sized images, 2 256 pairs; scripts/mfma_valu_probe.hip for the bare instruction streams): a wave
+  // that issues its eight MFMAs and then its 96 selection operations spends 15.7 ns per MFMA in the first block and about 1.9 ns
+  // per vector operation in the second, and the blocks of the three or four waves of a SIMD do not overlap (41-44 ns per MFMA
+  // per SIMD here, MFMA pipe 0.36 busy).  The bare stream with twelve operations BETWEEN consecutive MFMAs runs at 26 ns per
+  // MFMA, but three pipelined forms of this loop did not get there: selecting the previous half's accumulators between this
+  // half's MFMAs with a second accumulator set (200-228 registers, two waves per SIMD; with the next half's operands and the
+  // tile after next staged ahead as well) 6.8-8.2 ms against 6.2, and letting the two accumulator sets of a lane take turns
+  // (b selected under a's MFMAs; 168-178 registers) 6.7-6.9 ms.  What did pay: top2_insert without branches (above).
   for (int tile = 0; tile < n_tiles; tile++) {
     if (tile + 1 < n_tiles) fetch(tile + 1);
     const unsigned char* la = lds_a[cur];
