@@ -3390,10 +3390,11 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
       hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->cc.n_chunks, 4)), dim3(256), 0, sp, ba->cc.n_chunks, ba->cc.ch_start.p,
                          ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR), ba->cc.partial.p);
   };
-  // Round 3: measured again at config 3 over 40 iterations, the fork gives nothing (1.277 ms per iteration with it, 1.255-1.273
-  // without: the pair kernels fill the chip by themselves, the per-camera sums beside them only take bandwidth away), so the
-  // plain order is the default and MSFM_OVERLAP=1 brings the second stream back for comparison.
-  static const bool overlap = getenv("MSFM_OVERLAP") != nullptr;
+  // Round 3: with the gather path (the three pair kernels fill the chip by themselves) the fork gave nothing (1.277 ms per
+  // iteration with it, 1.255-1.273 without); with the fold tables the pair kernels are three short launches and the fork
+  // pays again (1.251 -> 1.229 ms per iteration at config 3).  So: forked when the fold tables are on, MSFM_OVERLAP=0 / 1 forces.
+  static const char* overlap_env = getenv("MSFM_OVERLAP");
+  const bool overlap = overlap_env ? atoi(overlap_env) != 0 : ba->fold.on;
   const bool forked = mode == 0 && !ctx->profile && overlap;
   if (forked) {
     if (!ctx->stream2) {
