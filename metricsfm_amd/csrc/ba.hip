@@ -3396,6 +3396,25 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   static const char* overlap_env = getenv("MSFM_OVERLAP");
   const bool overlap = overlap_env ? atoi(overlap_env) != 0 : ba->fold.on;
   const bool forked = mode == 0 && !ctx->profile && overlap;
+  // zero fill of the reduced system in front of the assembly (reads nothing: with the fork it runs on the second stream too)
+  auto zero_system = [&](hipStream_t sz) -> int {
+    const int nb64 = ba->npad / 64;
+    if (ctx->world > 1 || nb64 > 256) {
+      // (several ranks sum whole rows of M: every entry must be defined)
+      HIP_TRY(ctx, hipMemsetAsync(ba->M.p, 0, sizeof(double) * (size_t)ba->npad * ba->npad, sz));
+    } else {
+      ZeroMap Z;
+      Z.nb = nb64;
+      for (int b = 0; b < nb64; b++) { Z.lev[b] = 127; Z.lo[b] = 0; Z.hi[b] = 0x7fff; }   // root chain / dense order: couples to everything
+      for (int lv = 0; lv < ba->plan.n_levels; lv++)
+        for (int k = 0; k < ba->plan.level[lv].K; k++) {
+          const msfm_chol_node& nd = ba->plan.level[lv].node[k];
+          for (int b = nd.begin / 64; b < nd.end / 64; b++) { Z.lev[b] = (unsigned char)lv; Z.lo[b] = (short)nd.leaf_lo; Z.hi[b] = (short)nd.leaf_hi; }
+        }
+      hipLaunchKernelGGL(k_zero_system, dim3(nb64 * (nb64 + 1) / 2), dim3(256), 0, sz, ba->M.p, ba->npad, Z);
+    }
+    return MSFM_OK;
+  };
   if (forked) {
     if (!ctx->stream2) {
       HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -3405,6 +3424,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     launch_pairs(ctx->stream2);
+    MSFM_TRY(zero_system(ctx->stream2));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   }
   // Every way out of this function from here on - the error returns of the collective hook and of HIP_TRY included - must
@@ -3461,21 +3481,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   }
   {
     KTimer t(ctx, "ba_assemble");
-    const int nb64 = ba->npad / 64;
-    if (ctx->world > 1 || nb64 > 256) {
-      // (several ranks sum whole rows of M: every entry must be defined)
-      HIP_TRY(ctx, hipMemsetAsync(ba->M.p, 0, sizeof(double) * (size_t)ba->npad * ba->npad, s));
-    } else {
-      ZeroMap Z;
-      Z.nb = nb64;
-      for (int b = 0; b < nb64; b++) { Z.lev[b] = 127; Z.lo[b] = 0; Z.hi[b] = 0x7fff; }   // root chain / dense order: couples to everything
-      for (int lv = 0; lv < ba->plan.n_levels; lv++)
-        for (int k = 0; k < ba->plan.level[lv].K; k++) {
-          const msfm_chol_node& nd = ba->plan.level[lv].node[k];
-          for (int b = nd.begin / 64; b < nd.end / 64; b++) { Z.lev[b] = (unsigned char)lv; Z.lo[b] = (short)nd.leaf_lo; Z.hi[b] = (short)nd.leaf_hi; }
-        }
-      hipLaunchKernelGGL(k_zero_system, dim3(nb64 * (nb64 + 1) / 2), dim3(256), 0, s, ba->M.p, ba->npad, Z);
-    }
+    if (!forked) MSFM_TRY(zero_system(s));   // (forked: done on the second stream beside the per-camera sums, joined above)
     AsmArgs aa;
     aa.n_cc = ba->cc.n_blocks; aa.n_mc = ba->mc.n_blocks; aa.n_mm = ba->mm.n_blocks; aa.n_rhs = cdiv(6 * ncb, 64);
     aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = (ba->fold.on && ba->fold.all) ? nullptr : ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
