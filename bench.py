@@ -281,9 +281,22 @@ def main():
         n_pairs_cc = int((k * (k + 1) // 2).sum())
         # (the rows are linearised inside k_point and again inside k_backsub: 52 bytes of row data per observation in,
         # instead of a 26-double stored Jacobian row written once and read twice)
-        add("ba_point", "hbm", sc.n_obs * (52 + 160 + 144 + 48) + sc.n_points * (24 + 96),
-            "row data + point in; camera-major row (160 B), T (144 B), T.u (48 B) per observation and L, g, diagonal per point out")
-        add("ba_schur_pairs", "hbm", (n_pairs_cc + sc.n_obs) * 288 + sc.n_points * 144, "two 144-byte T records gathered per pair entry")
+        # With the fold tables (round 3) the camera x camera and intrinsics x camera products are formed inside k_point: its
+        # algorithmic bytes gain the slot partials it writes (288 B per camera x camera slot, 144 B per intrinsics x camera
+        # slot), and the gather kernels keep only the entries that did not fold (plus the intrinsics x intrinsics list).
+        fold = lay.get("fold", {})
+        cc_live = fold.get("cc_entries", n_pairs_cc) - fold.get("cc_entries_folded", 0)
+        mc_live = fold.get("mc_entries", sc.n_obs) - fold.get("mc_entries_folded", 0)
+        fold_bytes = fold.get("slots", 0) * 288 + fold.get("mc_slots", 0) * 144
+        add("ba_point", "hbm", sc.n_obs * (52 + 160 + 144 + 48) + sc.n_points * (24 + 96) + fold_bytes,
+            "row data + point in; camera-major row (160 B), T (144 B), T.u (48 B) per observation and L, g, diagonal per point out"
+            + ("; %d + %d slot partials of the Schur products formed in the kernel (%.1f MB)" % (fold.get("slots", 0), fold.get("mc_slots", 0), fold_bytes / 1e6)
+               if fold_bytes else ""))
+        add("ba_schur_pairs", "hbm", (cc_live + mc_live) * 288 + sc.n_points * 144,
+            "two 144-byte T records gathered per pair entry that is not folded into k_point (%d of %d camera x camera, %d of %d intrinsics x camera)"
+            % (cc_live, fold.get("cc_entries", n_pairs_cc), mc_live, fold.get("mc_entries", sc.n_obs)))
+        add("ba_assemble", "hbm", fold_bytes + (cc_live + mc_live > 0) * 0 + lay["reduced_order"] ** 2 * 4,
+            "slot partials in, lower triangle of the reduced system out")
         add("ba_backsub", "hbm", sc.n_obs * 52 + sc.n_points * 12 * 8, "row data, point and its 3x3 factor in, candidate point out")
         add("ba_ftf", "hbm", sc.n_obs * 26 * 8, "camera-major rows in")
     dom = kernels[0]

@@ -284,6 +284,14 @@ typedef struct msfm_ba_layout {
   int level_nodes[3];
   int level_begin[3];     /* first column of each level */
   int root_cols;          /* root separator + intrinsics: the final dense chain */
+  /* Schur products formed inside the point kernel instead of by the gather kernels (0 everywhere: gather path only):
+   * pair-list entries of the camera x camera list in all / folded; (workgroup, block) slots = 288-byte partial sums the
+   * point kernel writes and the assembly reads; the same for the intrinsics x camera list (144-byte partials) */
+  long long cc_entries, cc_entries_folded;
+  int fold_slots, fold_passes;
+  long long mc_entries, mc_entries_folded;
+  int fold_mc_slots;
+  int reserved_;
 } msfm_ba_layout;
 int msfm_ba_get_layout(const msfm_ba* ba, msfm_ba_layout* out);
 

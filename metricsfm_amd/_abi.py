@@ -31,7 +31,9 @@ class BaLayout(C.Structure):
     """msfm_ba_layout (include/msfm.h)."""
     _fields_ = [("reduced_order", C.c_int), ("system_order", C.c_int), ("n_domains", C.c_int), ("domain_cols", C.c_int * 8),
                 ("separator_cols", C.c_int), ("panel_launches", C.c_int), ("n_levels", C.c_int), ("level_nodes", C.c_int * 3),
-                ("level_begin", C.c_int * 3), ("root_cols", C.c_int)]
+                ("level_begin", C.c_int * 3), ("root_cols", C.c_int),
+                ("cc_entries", C.c_longlong), ("cc_entries_folded", C.c_longlong), ("fold_slots", C.c_int), ("fold_passes", C.c_int),
+                ("mc_entries", C.c_longlong), ("mc_entries_folded", C.c_longlong), ("fold_mc_slots", C.c_int), ("reserved_", C.c_int)]
 
 
 class FransacOptions(C.Structure):

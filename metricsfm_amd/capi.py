@@ -608,7 +608,9 @@ class BaResident:
         return dict(reduced_order=lay.reduced_order, system_order=lay.system_order, n_domains=lay.n_domains,
                     domain_cols=list(lay.domain_cols)[:max(0, lay.n_domains if lay.n_domains > 1 else 0)],
                     separator_cols=lay.separator_cols, panel_launches=lay.panel_launches, n_levels=lay.n_levels,
-                    level_nodes=list(lay.level_nodes)[:lay.n_levels], level_begin=list(lay.level_begin)[:lay.n_levels], root_cols=lay.root_cols)
+                    level_nodes=list(lay.level_nodes)[:lay.n_levels], level_begin=list(lay.level_begin)[:lay.n_levels], root_cols=lay.root_cols,
+                    fold=dict(cc_entries=lay.cc_entries, cc_entries_folded=lay.cc_entries_folded, slots=lay.fold_slots, passes=lay.fold_passes,
+                              mc_entries=lay.mc_entries, mc_entries_folded=lay.mc_entries_folded, mc_slots=lay.fold_mc_slots))
 
     def upload(self, cam_pose=None, cam_model=None, point=None):
         cp, cm, pt = A.as_c(cam_pose, np.float64), A.as_c(cam_model, np.float64), A.as_c(point, np.float64)

@@ -1319,6 +1319,7 @@ struct FoldTables {
   // the workgroup, so the same tables serve; the 3 x 6 partials are indexed by the diagonal slots' ranks
   bool mc_on = false, mc_all = false;
   int n_diag = 0, mc_n_live = 0;
+  long long mc_entries_folded = 0;
   DevBuf<int> mc_range, mc_live_chunk;
   DevBuf<double> mc_partial;
 };
@@ -2273,6 +2274,11 @@ __global__ __launch_bounds__(256) void k_fold_mc_range(int n_blocks, int n_slots
   range[2 * b] = fold_lower_bound(sorted_key2, n_slots, k << 32);
   range[2 * b + 1] = fold_lower_bound(sorted_key2, n_slots, (k + 1) << 32);
 }
+__global__ __launch_bounds__(256) void k_fold_count_marked(int n, const int* __restrict__ pa, int* __restrict__ count) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(e < n && pa[e] < 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
 __global__ __launch_bounds__(256) void k_fold_mark_mc(int n, const uint8_t* __restrict__ folded, int* __restrict__ pa, const int* __restrict__ pb) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < n && pa[e] >= 0 && folded[pb[e]]) pa[e] = ~pa[e];
@@ -2458,6 +2464,17 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
       DTRY(hipMemsetAsync(F.mc_partial.p, 0, sizeof(double) * 18 * (size_t)F.n_diag, s));
       hipLaunchKernelGGL(k_fold_mark_mc, dim3(cdiv(ba->mc.n_pairs, 256)), dim3(256), 0, s, ba->mc.n_pairs, folded.p, ba->mc.pa.p, ba->mc.pb.p);
       MSFM_TRY(live_chunks(ba->mc, 18, F.mc_n_live, F.mc_live_chunk, nullptr));
+      {
+        // (how many entries left the gather list: reported by msfm_ba_get_layout)
+        DevBuf<int> cnt;
+        DTRY(cnt.alloc(1));
+        DTRY(hipMemsetAsync(cnt.p, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_fold_count_marked, dim3(cdiv(ba->mc.n_pairs, 256)), dim3(256), 0, s, ba->mc.n_pairs, ba->mc.pa.p, cnt.p);
+        int h = 0;
+        DTRY(hipMemcpyAsync(&h, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        DTRY(hipStreamSynchronize(s));
+        F.mc_entries_folded = h;
+      }
       F.mc_on = true;
       F.mc_all = F.mc_n_live == 0;
     }
@@ -3249,6 +3266,14 @@ MSFM_API int msfm_ba_get_layout(const msfm_ba* ba, msfm_ba_layout* out) {
   out->separator_cols = K ? ba->nsys - pl.level[0].b0 : ba->nsys;
   out->panel_launches = launches + cdiv(out->root_cols, 64);
   if (!K) out->domain_cols[0] = 0;
+  out->cc_entries = ba->cc.n_pairs;
+  out->mc_entries = ba->mc.n_pairs;
+  if (ba->fold.on) {
+    out->cc_entries_folded = ba->fold.n_entries;
+    out->fold_slots = ba->fold.n_slots;
+    out->fold_passes = ba->fold.n_pass;
+    if (ba->fold.mc_on) { out->mc_entries_folded = ba->fold.mc_entries_folded; out->fold_mc_slots = ba->fold.n_diag; }
+  }
   return MSFM_OK;
 }
 
