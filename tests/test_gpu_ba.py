@@ -282,6 +282,9 @@ def test_ba_folded_schur_products_match_the_oracle_and_the_gather_path(oracle):
             "run(scene.make_aerial_scene(60, 5000, seed=71))\n"
             "sc = scene.make_ring_scene(14, 900, seed=72)           # every point seen by all 14 cameras: second-round records\n"
             "run(sc)\n"
+            "run(scene.make_ring_scene(20, 700, seed=74))           # 20 rows per point: no workgroup folds, everything stays on the gather lists\n"
+            "sc = scene.make_aerial_scene(90, 9000, seed=75)        # mixed: a few long tracks among short ones -> some workgroups fold, some do not\n"
+            "run(sc)\n"
             "sc = scene.make_aerial_scene(40, 4000, seed=73, n_models=5, gps_sigma=0.5)\n"
             "rng = np.random.default_rng(3); cm = (np.arange(40) %% 6 != 0).astype(np.uint8); pm = (rng.random(4000) > 0.15).astype(np.uint8)\n"
             "run(sc, cam_mutable=cm, pt_mutable=pm, gps_xyz=sc.gps_xyz, gps_weight=50.0)\n"
