@@ -228,6 +228,24 @@ def test_ba_full_size_properties(ctx, monkeypatch):
     assert _rel(a0.cam_pose, a.cam_pose) < 1e-7 and _rel(a0.point, a.point) < 1e-7
 
 
+def test_ba_two_runs_are_bitwise_identical(ctx):
+    """Determinism: every reduction has a fixed shape, so two solves of the headline configuration - fold
+    tables on, pair kernels on the second stream - give bitwise the same trajectory and parameters."""
+    from metricsfm_amd import capi
+    sc = scene.config_scene(3)
+    runs = []
+    for _ in range(2):
+        a = A.BaArrays.from_scene(sc)
+        r = ctx.ba_solve(a, capi.default_options(max_num_iterations=6))
+        runs.append((r, a))
+    (r0, a0), (r1, a1) = runs
+    np.testing.assert_array_equal(r0["iterations"]["cost"], r1["iterations"]["cost"])
+    np.testing.assert_array_equal(r0["iterations"]["gradient_max_norm"], r1["iterations"]["gradient_max_norm"])
+    np.testing.assert_array_equal(a0.cam_pose, a1.cam_pose)
+    np.testing.assert_array_equal(a0.cam_model, a1.cam_model)
+    np.testing.assert_array_equal(a0.point, a1.point)
+
+
 def test_ba_config3_full_size_trajectory_parity(ctx, oracle):
     """The headline configuration itself (BASELINE config 3: 500 cameras / 200 000 points / 1.2 M observations) against the
     OpenMP oracle on every core of the box - bit-identical to its 1-thread run (tests/test_oracle.py) - for 12 LM iterations:
