@@ -1275,6 +1275,18 @@ __global__ __launch_bounds__(256) void k_mcc_rest(int A, int AE, int ncb, const 
 }
 
 __global__ void k_zero_int(int* p) { *p = 0; }
+// The iteration's scalars go to the host through mapped pinned memory: sixteen doubles, then (after a system-scope fence) the
+// sequence number the host thread is spinning on - no copy engine, no event.  The failure bits were folded into
+// scal[S_FAIL] by the last k_reduce, so the flag word is cleared here for the next iteration (one launch less at its start).
+__global__ __launch_bounds__(64) void k_publish_scalars(const double* __restrict__ scal, double* h_scal, unsigned long long seq, int* fail) {
+  const int lane = threadIdx.x;
+  if (lane < 16) __hip_atomic_store(&h_scal[lane], scal[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  if (lane == 0) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_scal + 16), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (fail) *fail = 0;
+  }
+}
 __global__ void k_fill(int n, double v, double* __restrict__ p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1367,8 +1379,9 @@ struct msfm_ba {
   DevBuf<double> partial, partial2, partial3, gmax_buf, scal, sloc;
   double* swrite = nullptr;  // where the kernels put scalars: scal (one rank) or sloc (partials, summed by reduce_scalars)
   DevBuf<int> fail;
-  double* h_scal = nullptr;  // pinned
-  hipEvent_t ev_scal = nullptr;
+  double* h_scal = nullptr;  // pinned, mapped: [0, 16) scalars, [16] sequence number (k_publish_scalars)
+  double* h_scal_dev = nullptr;
+  unsigned long long scal_seq = 0;
   int* h_fail = nullptr;
   int nblk_obs = 0, nblk_pt = 0;
   bool lin_pending = false;   // run_evaluate(jac) was asked for: the next k_point linearises, writes the camera rows and the cost
@@ -1682,7 +1695,6 @@ MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
   }
 #endif
   if (ba->h_scal) (void)hipHostFree(ba->h_scal);
-  if (ba->ev_scal) (void)hipEventDestroy(ba->ev_scal);
   if (ba->h_fail) (void)hipHostFree(ba->h_fail);
   delete ba;
   msfm_ctx_child_released(ctx);
@@ -3225,8 +3237,9 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   ba->swrite = ctx->world > 1 ? ba->sloc.p : ba->scal.p;
   HIP_TRY(ctx, hipMemsetAsync(ba->scal.p, 0, sizeof(double) * S_N, s));
   HIP_TRY(ctx, hipMemsetAsync(ba->sloc.p, 0, sizeof(double) * S_N, s));
-  HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_scal, 16 * sizeof(double)));
-  HIP_TRY(ctx, hipEventCreateWithFlags(&ba->ev_scal, hipEventDisableTiming));
+  HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_scal, 24 * sizeof(double), hipHostMallocMapped));
+  memset(ba->h_scal, 0, 24 * sizeof(double));
+  HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ba->h_scal_dev, ba->h_scal, 0));
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_fail, 4 * sizeof(int)));
   HIP_TRY(ctx, hipMemsetAsync(ba->z.p, 0, sizeof(double) * (size_t)(ba->npad + 8), s));  // tail entries are read (times zero) by frozen blocks
   HIP_TRY(ctx, hipMemsetAsync(ba->camrow.p, 0, sizeof(double) * std::max<size_t>(1, 20 * (size_t)NCR), s));
@@ -3573,21 +3586,25 @@ static int reduce_scalars(msfm_ba* ba) {
 
 static int read_scalars(msfm_ba* ba) {
   msfm_ctx* ctx = ba->ctx;
-  HIP_TRY(ctx, hipMemcpyAsync(ba->h_scal, ba->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(ba->ev_scal, ctx->stream));
-  // spin: the wake-up of a blocking wait costs more than the copy.  Bounded: a wedged kernel, or a peer rank that left the
-  // loop so that a collective never completes, must surface as an error code, not as a host thread spinning forever.
+  const unsigned long long seq = ++ba->scal_seq;
+  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, ctx->stream, ba->scal.p, ba->h_scal_dev, seq, ba->fail.p);
+  // spin on the sequence number: the wake-up of a blocking wait costs more than the whole hand-over.  Bounded: a wedged kernel,
+  // or a peer rank that left the loop so that a collective never completes, must surface as an error code, not as a host thread
+  // spinning forever; a launch or execution error surfaces through the stream query that accompanies the clock check.
   static const double limit_s = [] { const char* e = getenv("MSFM_SYNC_TIMEOUT_S"); const double v = e ? atof(e) : 120.0; return v > 0 ? v : 120.0; }();
-  hipError_t q;
+  const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ba->h_scal + 16);
   unsigned long long spins = 0;
   const auto t0 = std::chrono::steady_clock::now();   // taken once: the deadline never re-arms, whatever the poll count does
-  while ((q = hipEventQuery(ba->ev_scal)) == hipErrorNotReady) {
-    if ((++spins & 0xFFFull) == 0) {   // look at the clock every 4096 polls only
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0x3FFFFull) == 0) {   // look at the stream and the clock every 262 144 polls only
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(ctx, q);
+      if (q == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq)
+        return msfm_set_error(ctx, MSFM_E_DEVICE, "the iteration's scalars did not arrive although the stream is idle");
       if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
         return msfm_set_error(ctx, MSFM_E_DEVICE, "device did not finish an LM iteration within %.0f s (MSFM_SYNC_TIMEOUT_S)", limit_s);
     }
   }
-  HIP_TRY(ctx, q);
   return MSFM_OK;
 }
 
@@ -3778,7 +3795,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
       }
     }
     // ---- next reduced system (new Jacobian after a successful step, else new radius only) ----
-    hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
+    // (the failure bits were cleared by k_publish_scalars when it handed the last iteration's scalars over)
     if (relinearise) {
       MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
     }
