@@ -16,6 +16,10 @@ echo "pmc write done"
 cd $R
 python3 scripts/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc > $O/pmc_summary.txt 2>&1 || echo "pmc post-processing failed"
 # the bench line comes after the counters so that it can attach them (same kernel sources: the hash inside matches)
+# matrix-pipe utilisation of the three MFMA kernels (SQ counter passes; writes gpurun_out/mfma/r03_mfma_util.json)
+bash scripts/mfma_util.sh > $O/mfma_util.log 2>&1 || echo "mfma_util failed"
+cp gpurun_out/mfma/r03_mfma_util.json profiles/r03_mfma_util.json || true
+echo "mfma util done"
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
 python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 echo "bench done"; tail -c 300 $O/bench.json
@@ -23,7 +27,4 @@ python3 bench.py --config 5 --window --steps 20 --warmup 3 > $O/bench_c5_window.
 echo "config 5 window done"
 python3 scripts/extra_bench.py --c5 > $O/extra.json 2> $O/extra.err
 echo "extra done"
-# matrix-pipe utilisation of the three MFMA kernels (SQ counter passes; writes gpurun_out/mfma/r03_mfma_util.json)
-bash scripts/mfma_util.sh > $O/mfma_util.log 2>&1 || echo "mfma_util failed"
-echo "mfma util done"
 find $O -name "*kernel_stats.csv" | head -3
