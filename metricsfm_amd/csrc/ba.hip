@@ -2239,6 +2239,8 @@ __global__ __launch_bounds__(256) void k_fold_passes(int n_wg, int ncb, const in
       fp.off = off; fp.words = pw; fp.slot0 = a; fp.n_slots = b - a; fp.n_diag = nd; fp.pad0 = fp.pad1 = fp.pad2 = 0;
       pass[pass_first[w] + np] = fp;
     }
+    if (pw > FOLD_WORDS) np = 0x20000000;   // one slot alone does not fit the staging area (thousands of repeated observations of
+                                            // one camera pair inside 32 points): the host sees the count and keeps the gather path
     np++; words += pw;
     a = b;
   }
@@ -2396,6 +2398,7 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
     DTRY(hipMemcpyAsync(&npass, F.wg_pass_first.p + n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
     DTRY(hipMemcpyAsync(&nwords, words_first.p + n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
     DTRY(hipStreamSynchronize(s));
+    if (npass < 0 || npass >= 0x20000000) return MSFM_OK;   // (k_fold_passes: a slot too large to stage; nothing has been marked yet)
     DTRY(F.pass.alloc((size_t)std::max(1, npass))); DTRY(F.stream.alloc((size_t)nwords + FOLD_WORDS));
     DTRY(hipMemsetAsync(F.stream.p, 0, sizeof(unsigned) * ((size_t)nwords + FOLD_WORDS), s));
     hipLaunchKernelGGL((k_fold_passes<true>), dim3(cdiv(n_wg, 256)), dim3(256), 0, s, n_wg, ncb, wg_slot_first.p, slot_ent_first.p, slot_key2.p, perm.p, (int*)nullptr, (int*)nullptr,
