@@ -570,7 +570,10 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
           __syncthreads();   // (the previous pass is done with the staged words)
           stage(__builtin_amdgcn_readfirstlane(P.fold_pass[p].off), __builtin_amdgcn_readfirstlane(P.fold_pass[p].words));
         }
-        __syncthreads();     // records stored (first pass); the pass's words have arrived (the barrier waits for the copy)
+        // the LDS-DMA copy of stage() counts in vmcnt, and s_barrier itself does not wait for it: every wave drains its own
+        // copy explicitly before the barrier (this toolchain happens to emit the wait; nothing guarantees that it always will)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();     // records stored (first pass); the pass's words have arrived in LDS
         // where the results go: asked for now, needed after the loops
         int rank0 = 0, rank1 = 0;
         if (sl4 < n_slots) rank0 = P.fold_slot_rank[slot0 + sl4];
@@ -2210,7 +2213,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(256) void k_fold_passes(int n_wg, int ncb, const int* __restrict__ wg_slot_first, const int* __restrict__ slot_ent_first,
                                                       const unsigned long long* __restrict__ slot_key2, const int* __restrict__ perm, int* __restrict__ wg_npass, int* __restrict__ wg_words,
                                                       const int* __restrict__ pass_first, const int* __restrict__ words_first, FoldPass* __restrict__ pass,
-                                                      unsigned* __restrict__ stream, int* __restrict__ slot_ent_pos) {
+                                                      unsigned* __restrict__ stream, int* __restrict__ slot_ent_pos, int* __restrict__ too_large) {
   const int w = blockIdx.x * 256 + threadIdx.x;
   if (w >= n_wg) return;
   const int s0 = wg_slot_first[w], s1 = wg_slot_first[w + 1];
@@ -2239,8 +2242,10 @@ __global__ __launch_bounds__(256) void k_fold_passes(int n_wg, int ncb, const in
       fp.off = off; fp.words = pw; fp.slot0 = a; fp.n_slots = b - a; fp.n_diag = nd; fp.pad0 = fp.pad1 = fp.pad2 = 0;
       pass[pass_first[w] + np] = fp;
     }
-    if (pw > FOLD_WORDS) np = 0x20000000;   // one slot alone does not fit the staging area (thousands of repeated observations of
-                                            // one camera pair inside 32 points): the host sees the count and keeps the gather path
+    // one slot alone does not fit the staging area (thousands of repeated observations of one camera pair inside 32 points):
+    // the host reads the flag beside the counts and keeps the gather path (a flag of its own: the counts are summed by a
+    // 32-bit scan, a sentinel inside them could wrap)
+    if (pw > FOLD_WORDS && too_large) atomicOr(too_large, 1);
     np++; words += pw;
     a = b;
   }
@@ -2389,20 +2394,23 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
     DevBuf<int> wg_npass, wg_words, words_first, slot_ent_pos;
     DTRY(wg_npass.alloc((size_t)n_wg + 1)); DTRY(wg_words.alloc((size_t)n_wg + 1)); DTRY(words_first.alloc((size_t)n_wg + 1));
     DTRY(F.wg_pass_first.alloc((size_t)n_wg + 1)); DTRY(slot_ent_pos.alloc(NS));
+    DevBuf<int> too_large;
+    DTRY(too_large.alloc(1)); DTRY(hipMemsetAsync(too_large.p, 0, sizeof(int), s));
     DTRY(hipMemsetAsync(wg_npass.p + n_wg, 0, sizeof(int), s)); DTRY(hipMemsetAsync(wg_words.p + n_wg, 0, sizeof(int), s));
     hipLaunchKernelGGL((k_fold_passes<false>), dim3(cdiv(n_wg, 256)), dim3(256), 0, s, n_wg, ncb, wg_slot_first.p, slot_ent_first.p, slot_key2.p, perm.p, wg_npass.p, wg_words.p,
-                       (const int*)nullptr, (const int*)nullptr, (FoldPass*)nullptr, (unsigned*)nullptr, (int*)nullptr);
+                       (const int*)nullptr, (const int*)nullptr, (FoldPass*)nullptr, (unsigned*)nullptr, (int*)nullptr, too_large.p);
     DTRY(excl_scan(wg_npass.p, F.wg_pass_first.p, (size_t)n_wg + 1, s, tmp));
     DTRY(excl_scan(wg_words.p, words_first.p, (size_t)n_wg + 1, s, tmp));
-    int npass = 0, nwords = 0;
+    int npass = 0, nwords = 0, h_too_large = 0;
+    DTRY(hipMemcpyAsync(&h_too_large, too_large.p, sizeof(int), hipMemcpyDeviceToHost, s));
     DTRY(hipMemcpyAsync(&npass, F.wg_pass_first.p + n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
     DTRY(hipMemcpyAsync(&nwords, words_first.p + n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
     DTRY(hipStreamSynchronize(s));
-    if (npass < 0 || npass >= 0x20000000) return MSFM_OK;   // (k_fold_passes: a slot too large to stage; nothing has been marked yet)
+    if (h_too_large || npass < 0 || nwords < 0) return MSFM_OK;   // (k_fold_passes: a slot too large to stage; nothing has been marked yet)
     DTRY(F.pass.alloc((size_t)std::max(1, npass))); DTRY(F.stream.alloc((size_t)nwords + FOLD_WORDS));
     DTRY(hipMemsetAsync(F.stream.p, 0, sizeof(unsigned) * ((size_t)nwords + FOLD_WORDS), s));
     hipLaunchKernelGGL((k_fold_passes<true>), dim3(cdiv(n_wg, 256)), dim3(256), 0, s, n_wg, ncb, wg_slot_first.p, slot_ent_first.p, slot_key2.p, perm.p, (int*)nullptr, (int*)nullptr,
-                       F.wg_pass_first.p, words_first.p, F.pass.p, F.stream.p, slot_ent_pos.p);
+                       F.wg_pass_first.p, words_first.p, F.pass.p, F.stream.p, slot_ent_pos.p, (int*)nullptr);
     hipLaunchKernelGGL(k_fold_stream_entries, dim3(cdiv(E, 256)), dim3(256), 0, s, E, head.p, slot_of.p, slot_ent_first.p, slot_ent_pos.p, ent_sorted.p, F.stream.p);
     F.n_pass = npass;
     DTRY(hipStreamSynchronize(s));
@@ -3621,9 +3629,15 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
   if (ba->nred > 0) {
     double* const zcur = ba->zsys.p + (size_t)ba->zflip * (ba->npad + 8);
     double* const znext = ba->zsys.p + (size_t)(ba->zflip ^ 1) * (ba->npad + 8);
-    ba->zflip ^= 1;
-    MSFM_TRY(msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, zcur, ba->fail.p,
-                                    ba->plan.n_levels > 0 ? &ba->plan : nullptr, znext));
+    const int rc = msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, zcur, ba->fail.p,
+                                          ba->plan.n_levels > 0 ? &ba->plan : nullptr, znext);
+    if (rc != MSFM_OK) {
+      // the call may have stopped before the solve kernel marked znext: neither half can be trusted to be "pending"
+      // any more (a stale half would be taken for published values by the next solve) - mark both again
+      (void)msfm_chol_fill_pending(ctx, ba->zsys.p, 2 * (ba->npad + 8));
+      return rc;
+    }
+    ba->zflip ^= 1;   // only a completed solve hands the other half over
     zsolved = zcur;
   }
   {

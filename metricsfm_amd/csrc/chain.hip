@@ -163,6 +163,9 @@ struct msfm_chain {
   msfm_ctx* ctx = nullptr;
   int n_images = 0, n_pairs = 0;
   std::vector<int> pairs, count, feat_off;
+  // The chain keeps its OWN copy of the keypoints (one flat buffer, kp[i] points into it): the descriptor set may re-upload
+  // or drop them, or be destroyed, while the chain lives (verify and triangulate read them long after create).
+  DevBuf<float> kp_own;
   std::vector<const float*> kp;
   DevBuf<const float*> d_kp;
   // verification
@@ -203,10 +206,17 @@ MSFM_API int msfm_chain_create(msfm_match_result* res, msfm_chain** out) {
   C->ctx = ctx; C->n_images = v.n_images; C->n_pairs = v.n_pairs;
   C->pairs.assign(v.pairs, v.pairs + 2 * (size_t)v.n_pairs);
   C->count = v.count;
-  C->kp = v.kp;
   C->feat_off.assign(v.n_images + 1, 0);
   for (int i = 0; i < v.n_images; i++) C->feat_off[i + 1] = C->feat_off[i] + v.count[i];
   hipStream_t s = ctx->stream;
+  C->kp.assign(v.n_images, nullptr);
+  CH_TRY(C->kp_own.alloc(2 * (size_t)std::max(1, C->feat_off[v.n_images])));
+  for (int i = 0; i < v.n_images; i++) {
+    if (!v.kp[i] || v.count[i] == 0) continue;
+    float* dst = C->kp_own.p + 2 * (size_t)C->feat_off[i];
+    CH_TRY(hipMemcpyAsync(dst, v.kp[i], sizeof(float) * 2 * (size_t)v.count[i], hipMemcpyDeviceToDevice, s));
+    C->kp[i] = dst;
+  }
   // ---- matches_good / matches_all of every pair, gathered from the codes ----
   std::vector<int> ng(std::max(1, v.n_pairs)), na(std::max(1, v.n_pairs));
   if (v.n_pairs) {

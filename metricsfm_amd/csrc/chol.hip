@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void k_backsolve_pair(const double* __restrict
 // on the chip together (host: nblk <= MSFM_BACKSOLVE_CHAIN_MAX), and every poll loop is bounded: on expiry the failure word
 // gets MSFM_FAIL_SYNC (the host returns MSFM_E_DEVICE) and the value is taken as 0 so that every workgroup still drains.
 // ---------------------------------------------------------------------------------------
-#define MSFM_BACKSOLVE_CHAIN_MAX 224
+#define MSFM_BACKSOLVE_CHAIN_MAX 224   // upper bound; the limit in force is what the device can hold at once (resident_workgroups)
 struct BackTree {
   int n_levels;
   int root_blk;                       // first block of the root chain
@@ -1089,6 +1089,18 @@ static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /
   jb.nwg = jb.ncw + bulk_workgroups(jb.ntile);
   jb.wg0 = 0; jb.corner = corner; jb.ldc = ldc; jb.defer_corner = 0;
   return jb;
+}
+
+// Workgroups of `kernel` (256 threads, static LDS only) that the device of `ctx` keeps resident at the same time: a kernel
+// whose workgroups wait for each other inside one launch is used only up to this many (asked once per device and kernel).
+// The waits themselves only ever go to workgroups with a LOWER blockIdx, so with every workgroup resident no dispatch order
+// can starve them; the polls are bounded besides.
+template <class K>
+static int resident_workgroups(msfm_ctx* ctx, K kernel, int threads) {
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) return 0;
+  return std::max(0, per_cu) * std::max(0, cus);
 }
 
 __global__ __launch_bounds__(256) void k_fill_pending(int n, unsigned long long* __restrict__ z) {
@@ -1247,7 +1259,10 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     KTimer t(ctx, "chol_backsolve");
     const int nblk = cdiv(n, NB);
     static const bool launches_env = getenv("MSFM_BACKSOLVE_LAUNCHES") != nullptr;   // the round-2 chain of launches, for comparison
-    const bool chain = !launches_env && nblk <= MSFM_BACKSOLVE_CHAIN_MAX;
+    static int chain_max[64] = {0};   // per device: min(MSFM_BACKSOLVE_CHAIN_MAX, resident workgroups of k_backsolve_chain), 0 = not asked yet
+    int& cmax = chain_max[ctx->device & 63];
+    if (cmax == 0) cmax = std::max(1, std::min(MSFM_BACKSOLVE_CHAIN_MAX, resident_workgroups(ctx, k_backsolve_chain, 256)));
+    const bool chain = !launches_env && nblk <= cmax;
     if (!chain) hipLaunchKernelGGL(k_trinv64_full, dim3(nblk + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, nblk, M, npad, w, npad,
                                    (unsigned long long*)nullptr);
     if (chain) {

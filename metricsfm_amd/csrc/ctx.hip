@@ -205,16 +205,18 @@ MSFM_API int msfm_ctx_set_allreduce(msfm_ctx* ctx, msfm_allreduce_fn fn, void* u
 }
 
 // ---- native RCCL collective ------------------------------------------------------------
-// rccl.h is not included on purpose (the library must build and load where RCCL is absent); the few types used:
+// rccl.h is not included on purpose (the library must build and load where RCCL is absent); the few types used are declared
+// in rccl_iface.h and checked against the real header by a compile-time test.
 #include <dlfcn.h>
+#include "rccl_iface.h"
 namespace {
-struct RcclId { char internal[MSFM_RCCL_ID_BYTES]; };   // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
-typedef int (*rccl_get_unique_id_t)(RcclId*);
-typedef int (*rccl_comm_init_rank_t)(void** comm, int nranks, RcclId id, int rank);
-typedef int (*rccl_all_reduce_t)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream);
-typedef int (*rccl_comm_destroy_t)(void* comm);
-typedef const char* (*rccl_error_string_t)(int);
-enum { RCCL_SUM = 0, RCCL_MAX = 2, RCCL_FLOAT64 = 8 };   // ncclRedOp_t / ncclDataType_t values of rccl.h
+using RcclId = msfm_rccl::UniqueId;
+typedef msfm_rccl::get_unique_id_t rccl_get_unique_id_t;
+typedef msfm_rccl::comm_init_rank_t rccl_comm_init_rank_t;
+typedef msfm_rccl::all_reduce_t rccl_all_reduce_t;
+typedef msfm_rccl::comm_destroy_t rccl_comm_destroy_t;
+typedef msfm_rccl::error_string_t rccl_error_string_t;
+enum { RCCL_SUM = msfm_rccl::SUM, RCCL_MAX = msfm_rccl::MAX, RCCL_FLOAT64 = msfm_rccl::FLOAT64 };
 
 void* rccl_open(msfm_ctx* ctx) {
   if (ctx->rccl_lib) return ctx->rccl_lib;
@@ -229,7 +231,7 @@ void* rccl_open(msfm_ctx* ctx) {
 int rccl_hook(void* user, double* buf, size_t count, int op, void* stream) {
   msfm_ctx* ctx = static_cast<msfm_ctx*>(user);
   const int rc = reinterpret_cast<rccl_all_reduce_t>(ctx->rccl_allreduce)(buf, buf, count, RCCL_FLOAT64, op == MSFM_REDUCE_MAX ? RCCL_MAX : RCCL_SUM,
-                                                                           ctx->rccl_comm, (hipStream_t)stream);
+                                                                           ctx->rccl_comm, stream);
   return rc;   // ncclSuccess = 0
 }
 }  // namespace

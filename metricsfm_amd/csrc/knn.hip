@@ -63,6 +63,8 @@ struct msfm_descset {
   // bumped by every upload: a match result remembers the generation its device pointer tables were built at and
   // refuses to run or to be read once an image has been replaced under it
   unsigned long generation = 0;
+  // bumped by every keypoint upload: the gate tables of a SLAM match result hold raw pointers into kp[]
+  unsigned long kp_generation = 0;
 };
 
 // ---- prep: f32 -> bf16, squared norms, integrality flag -------------------------------
@@ -1033,6 +1035,7 @@ MSFM_API int msfm_descset_upload(msfm_descset* s, int image, const float* desc, 
   HIP_TRY(ctx, hipStreamSynchronize(st));
   s->generation++;
   delete s->kp[image]; s->kp[image] = nullptr;   // positions belong to the features they were uploaded with
+  s->kp_generation++;
   delete s->f32[image]; delete s->bf16[image]; delete s->norm[image];
   delete s->th16[image]; delete s->qh16[image]; delete s->n2s[image]; delete s->rerr[image];
   s->th16[image] = new DevBuf<unsigned short>(); s->qh16[image] = new DevBuf<unsigned short>(); s->n2s[image] = new DevBuf<float>();
@@ -1164,6 +1167,7 @@ struct msfm_match_result {
   int n_tiles = 0;
   bool exact_path = false;
   unsigned long generation = 0;   // of the descriptor set when the task tables were built
+  unsigned long kp_generation = 0;   // of its keypoints (read by the SLAM gates only)
   // SLAM form (msfm_match_pairs_slam): prior F / H gates behind the ratio test
   bool slam = false;
   DevBuf<SlamGateTask> gate_tasks;
@@ -1180,6 +1184,9 @@ static int check_generation(const msfm_match_result* R) {
   if (R->generation != R->set->generation)
     return msfm_set_error(R->ctx, MSFM_E_INVAL, "an image of the descriptor set was uploaded again after this match result was created; "
                                                      "create a new result with msfm_match_pairs");
+  if (R->slam && R->kp_generation != R->set->kp_generation)
+    return msfm_set_error(R->ctx, MSFM_E_INVAL, "the keypoints of an image were uploaded again after this SLAM match result was created "
+                                                     "(its gate tables point at the old positions); create a new result with msfm_match_pairs_slam");
   return MSFM_OK;
 }
 
@@ -1248,6 +1255,7 @@ static int match_pairs_impl(msfm_descset* s, const int* pairs, int n_pairs, floa
   struct Guard { msfm_match_result* p; msfm_ctx* c; ~Guard() { if (p) { delete p; msfm_ctx_child_released(c); } } } guard{R, ctx};
   ctx->children++;
   R->generation = s->generation;
+  R->kp_generation = s->kp_generation;
   R->ctx = ctx;
   R->set = s; R->n_pairs = n_pairs; R->keep_knn = keep_knn != 0; R->ratio_good = ratio_good; R->ratio_all = ratio_all;
   R->pairs.assign(pairs, pairs + 2 * (size_t)n_pairs);
@@ -1360,6 +1368,7 @@ MSFM_API int msfm_descset_upload_keypoints(msfm_descset* s, int image, const flo
     return msfm_set_error(ctx, MSFM_E_INVAL, "image %d has %d descriptors, %d keypoints given (upload the descriptors first)", image, s->count[image], count);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // a gate kernel may still be reading the old positions
+  s->kp_generation++;   // SLAM results built on the old positions refuse to run from now on (check_generation)
   delete s->kp[image];
   s->kp[image] = new DevBuf<float>();
   if (count == 0) return MSFM_OK;

@@ -75,3 +75,14 @@ def test_product_never_uses_the_oracle():
                 assert "msfm_oracle" not in txt and "liboracle" not in txt and "orc_" not in txt, f
     out = subprocess.check_output(["ldd", capi.LIB_PATH], text=True)
     assert "oracle" not in out
+
+
+def test_rccl_interface_matches_rccl_h():
+    """libmsfm declares the few RCCL types and values it uses by hand (metricsfm_amd/csrc/rccl_iface.h; librccl is opened with
+    dlopen).  tests/rccl_iface_check.cpp includes the real rccl.h beside them and static_asserts the id size, ncclFloat64,
+    ncclSum, ncclMax and the parameter lists of every entry point the library resolves - compiling it is the test."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no rccl.h in this image")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "rccl_iface_check.cpp")])

@@ -104,3 +104,38 @@ def test_chain_refuses_what_it_cannot_do(ctx):
     assert ok.sum() == 0 and n_m.sum() == 0                    # random descriptors: nothing to verify (< 30 matches)
     assert ch.build_tracks() == (0, 0)
     ch.close(); res.close(); ds.close()
+
+
+def test_chain_owns_its_keypoints(ctx):
+    """The chain copies the keypoints when it is created: positions uploaded again afterwards (or a descriptor set destroyed
+    before the triangulation) do not reach it - same matches, tracks and points as the undisturbed chain."""
+    sc = scene.add_features(scene.config_scene(1), 1500)
+    kps = [np.ascontiguousarray(k, np.float32) for k in sc.kp_xy]
+    pairs = scene.all_pairs(sc.n_cams)
+    R, t, c, fk = scene.cameras_for_tracks(sc)
+
+    def run(disturb):
+        ds = ctx.descset(sc.desc, keypoints=kps)
+        res = ds.match_pairs(pairs, 0.6, 0.85)
+        ch = capi.Chain(res)
+        if disturb:
+            for i in range(sc.n_cams):
+                ds.upload_keypoints(i, np.full_like(kps[i], 1.0e6))     # the old blocks go back to the pool ...
+            junk = [ctx.descset([np.zeros((len(k), 128), np.float32)], keypoints=[np.full_like(k, -7.0)]) for k in kps[:4]]   # ... and are reused
+        n_m, ok, F = ch.verify(3.0, seed=5)
+        nt, no = ch.build_tracks()
+        if disturb:
+            res.close(); ds.close()                                      # the set is gone before the triangulation
+            for j in junk:
+                j.close()
+        n_acc = ch.triangulate(R, t, c, fk, 7.0, np.deg2rad(3.0))
+        out = (n_m.copy(), ok.copy(), F.copy(), nt, no, n_acc) + tuple(x.copy() for x in ch.fetch_points())
+        ch.close()
+        if not disturb:
+            res.close(); ds.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert a[3] > 500 and a[5] > 0.8 * a[3]
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)

@@ -291,7 +291,7 @@ def test_float_path_vlfeat_scale_full_tiles(ctx, oracle):
     np.testing.assert_array_equal(res2.counts()[0], res.counts()[0])
 
 
-def _check_pairs_against_oracle(ctx, oracle, descs, pairs):
+def _check_pairs_against_oracle(ctx, oracle, descs, pairs, fast=True):
     """ids, distances, ratio codes and the two counts of every pair in `pairs` identical to oracle.knn2 + ratio_codes."""
     oracle.set_num_threads(oracle.host_cores())
     try:
@@ -302,7 +302,7 @@ def _check_pairs_against_oracle(ctx, oracle, descs, pairs):
         n_good = 0
         for p, (i, j) in enumerate(pairs):
             code, ids, d = res.fetch(p)
-            ids_r, d_r = oracle.knn2(descs[i], descs[j], fast=True)   # identical to the plain form on integer data (tests/test_oracle.py)
+            ids_r, d_r = oracle.knn2(descs[i], descs[j], fast=fast)   # fast: identical to the plain form on integer data (tests/test_oracle.py)
             code_r, na_r, ng_r = oracle.ratio_codes(ids_r, d_r, 0.6, 0.85)
             assert np.array_equal(ids, ids_r) and np.array_equal(d, d_r) and np.array_equal(code, code_r), (p, i, j)
             assert (na[p], ng[p]) == (na_r, ng_r), (p, i, j)
@@ -337,6 +337,27 @@ def test_config3_pair_sample_matches_the_oracle(ctx, oracle):
     descs = [sc.desc[i] if sc.desc[i] is not None else np.zeros((0, 128), np.float32) for i in range(sc.n_cams)]
     n_good, stats = _check_pairs_against_oracle(ctx, oracle, descs, pairs)
     assert stats["slow_path"] == 0 and n_good > 100
+
+
+def test_config3_float_pair_sample_matches_the_oracle(ctx, oracle):
+    """The path the reference's real extractors feed (feature_extractor_vl_sift.cpp:202: `512.0F * x`, never cast) at
+    configuration scale: a seeded sample of 20 of config 3's ordered pairs + 4 neighbours on the flight line, 4096 features
+    each, `512 * unit-norm` floats exactly as bench.py's `matching_float` leg builds them, matched as ONE batch
+    (k_knn2_f16 + the grouped filing of uncertified queries into k_exact_flagged) and compared id for id, distance for
+    distance, code for code and count for count with the oracle's binary64 definition (fine_matching_graph.cc:87-133)."""
+    sc = scene.config_scene(3)
+    rng = np.random.default_rng(0x4D53464D + 12)
+    all_pairs = scene.all_pairs(sc.n_cams)
+    pairs = all_pairs[np.sort(rng.choice(len(all_pairs), 20, replace=False))]
+    pairs = np.concatenate([pairs, [[0, 1], [1, 0], [498, 499], [499, 0]]]).astype(np.int32)
+    images = sorted(set(pairs.ravel().tolist()))
+    scene.add_features(sc, 4096, images=images)
+    descs = [(512.0 * sc.desc[i] / np.linalg.norm(sc.desc[i], axis=1, keepdims=True)).astype(np.float32) if sc.desc[i] is not None
+             else np.zeros((0, 128), np.float32) for i in range(sc.n_cams)]
+    n_good, stats = _check_pairs_against_oracle(ctx, oracle, descs, pairs, fast=False)
+    assert stats["queries"] == 24 * 4096
+    assert 0 < stats["slow_path"] < 0.02 * stats["queries"]     # the slow path ran at this size, and stayed the exception
+    assert n_good > 100
 
 
 def _prior_F_H(sc, i, j):
@@ -400,7 +421,15 @@ def test_match_pairs_slam_gates(ctx, oracle):
     na2, ng2 = res.counts()
     np.testing.assert_array_equal(na, na2)
     np.testing.assert_array_equal(ng, ng2)
+    # keypoints uploaded again: the gate tables of the result point at the freed positions -> refused, not read
+    ds.upload_keypoints(2, kps[2] + 1.0)
+    with pytest.raises(capi.MsfmError) as e:
+        res.rerun()
+    assert e.value.code == A.MSFM_E_INVAL
     res.close()
+    res3 = ds.match_pairs_slam(pairs, F, H)                    # a new result sees the new positions and runs
+    res3.rerun()
+    res3.close()
     # without keypoints the gates cannot run
     ds2 = ctx.descset(descs)
     with pytest.raises(capi.MsfmError) as e:
