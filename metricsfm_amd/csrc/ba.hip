@@ -1353,6 +1353,7 @@ struct msfm_ba {
   // solver layout of the reduced system: camera block cb at column cb_off[cb], intrinsics at mo + 3 mb, order nsys
   int nsys = 0, mo = 0, n_padcol = 0;
   msfm_chol_plan plan;
+  msfm_chol_ws* chol_ws = nullptr;   // hand-off state of the persistent panel chain (chol.hip)
   DevBuf<int> cb_off, padcol;
   DevBuf<double> zsys, corners;
   int zflip = 0;   // which half of zsys the next solve writes (the other half is being marked "pending" meanwhile)
@@ -1682,6 +1683,8 @@ MSFM_API void msfm_ba_destroy(msfm_ba* ba) {
   (void)hipSetDevice(ctx->device);   // the caller's thread may have another device current (Python __del__ after set_device)
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);   // the pair kernels read T / Tm and write the partials freed below
+  msfm_chol_ws_destroy(ba->chol_ws);
+  ba->chol_ws = nullptr;
 #ifdef MSFM_FOLD_STAMPS
   if (ba->fold.on) {
     static long long h[8192][8];
@@ -3234,6 +3237,7 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
 #undef AL
   // the first solve's solution buffer starts out "pending"; from then on every solve marks the other one (k_backsolve_chain)
   MSFM_TRY(msfm_chol_fill_pending(ctx, ba->zsys.p, ba->npad));
+  if (ba->nred > 0) MSFM_TRY(msfm_chol_ws_create(ctx, ba->npad, &ba->chol_ws));
   {
     // every device buffer a kernel may dereference must exist before the first launch
     const void* must[] = {ba->cam.p, ba->model.p, ba->pt.p, ba->cam_c.p, ba->model_c.p, ba->pt_c.p, ba->lin_r.p, ba->lin_Jc.p,
@@ -3630,7 +3634,7 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
     double* const zcur = ba->zsys.p + (size_t)ba->zflip * (ba->npad + 8);
     double* const znext = ba->zsys.p + (size_t)(ba->zflip ^ 1) * (ba->npad + 8);
     const int rc = msfm_chol_factor_solve(ctx, ba->M.p, ba->npad, ba->nsys, ba->Linv.p, ba->w.p, zcur, ba->fail.p,
-                                          ba->plan.n_levels > 0 ? &ba->plan : nullptr, znext);
+                                          ba->plan.n_levels > 0 ? &ba->plan : nullptr, znext, ba->chol_ws);
     if (rc != MSFM_OK) {
       // the call may have stopped before the solve kernel marked znext: neither half can be trusted to be "pending"
       // any more (a stale half would be taken for published values by the next solve) - mark both again

@@ -13,6 +13,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 
 #define NB 64
 #define MSFM_Z_PENDING 0xFFF85A5A5A5A5A5Aull   // "not solved yet" in the solution vector of k_backsolve_chain
@@ -633,6 +634,571 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
   }
 }
 
+// =======================================================================================
+// The panel chain of a tree level as ONE persistent launch (round 4; replaces the level's k_panel_v2 launches).
+//
+// The work is the launch chain's, decomposed the same way - row owners (the column-0 workgroups: every one of them factors the
+// updated diagonal block redundantly and solves its own three 16-row tiles behind the sub-panels) and bulk workgroups (64 x 64
+// tiles of the trailing update) - but nothing ends between two 64-column steps:
+//  * a row owner owns ABSOLUTE row tiles for the whole chain.  Its rows of the new panel stay in registers and are the
+//    `preg` operand of its next step; only the 64 x 64 block L[t+1, t] (the rows of the next diagonal block) has to travel,
+//    from the one or two workgroups that own those rows to everybody else;
+//  * that block travels through `hb`, a buffer of self-tagged values: every double is its own {data, tag} granule, published
+//    with an agent-scope (sc1) 8-byte store and polled by the consumers against MSFM_Z_PENDING - one memory round trip, no
+//    flag, no fence (the mechanism of k_backsolve_chain).  Two buffers alternate from solve to solve; a launch marks the
+//    other one "pending" for its own blocks;
+//  * everything else that crosses workgroups (the rows of a finished panel for the bulk tiles, the updated tiles for the row
+//    owners' next column) is written with sc1 stores, read with sc1 loads and ordered by counters: rowflag[job][tile] = steps
+//    finished by the owner of that 16-row tile, tileflag[I][J] = panels the bulk workgroups have applied to tile (I, J); both
+//    carry the solve's epoch in their upper bits, so nothing is ever reset;
+//  * bulk tiles are handed out by a ticket counter in (step, job, column-major) order: any resident bulk workgroup can take
+//    any tile, so progress needs the row owners resident (they are the first blocks of the grid) and one bulk workgroup.
+// Every poll is bounded and gives up for the whole launch once MSFM_FAIL_SYNC is set (the host returns MSFM_E_DEVICE).
+// The arithmetic and its order are exactly those of the launch chain: the factor is bit-identical.
+// =======================================================================================
+// cycle stamps of one row-owner workgroup per step (scripts/chol_probe.hip; compiled out of the library)
+#ifdef MSFM_CHAIN_STAMPS
+__device__ long long g_chain_stamp[256][8];
+__device__ int g_chain_stamp_wg = 0;
+#define CSTAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x == g_chain_stamp_wg && l < 256) g_chain_stamp[l][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CSTAMP_H(i) do { if (threadIdx.x == 64 && (int)blockIdx.x == g_chain_stamp_wg && l < 256) g_chain_stamp[l][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define CSTAMP(i) do {} while (0)
+#define CSTAMP_H(i) do {} while (0)
+#endif
+struct ChainJob {
+  int begin;            // first column of the node
+  int P;                // factor steps = 64-column blocks of the node
+  int nA64;             // 64-row blocks of range A (the node itself; the dense root chain: everything down to the rhs row)
+  int nb16, nB64, nseg; // range B: 16-row tiles with data, 64-row blocks, segments
+  int sb0[4], sn16[4];
+  int nrt;              // 16-row tiles that carry data, A then B, counted from the node's first row
+  int ncw, wg0;         // row-owner workgroups [wg0, wg0 + ncw)
+  int flag0;            // first entry of the job in rowflag
+};
+struct ChainJobs {
+  int count, n_row_wg, n_bulk_wg, n_steps;   // n_steps: entries of task_first / 8
+  ChainJob job[8];
+};
+struct ChainCtl {
+  unsigned* rowflag;          // [jobs][tiles]
+  unsigned* tileflag;         // [nblk][nblk] by absolute 64-blocks of M
+  double* hb;                 // [nblk][64][64] the rows of diagonal block i in panel i - 1, self-tagged
+  unsigned long long* hb_next;
+  int* ticket;                // this launch's counter (zero when the launch starts)
+  int* ticket_next;           // zeroed here for the next launch
+  const int* task_first;      // [(n_steps + 1) * 8]: first ticket of (launch step l = 1 + i / 8, job i % 8)
+  unsigned base;              // epoch << 12
+  unsigned spin_limit;
+  int nblk;                   // npad / 64
+  int* dbg;                   // [8] the first poll that gave up: site, workgroup, step, awaited count, seen value, index
+};
+__device__ __forceinline__ void chain_note(int* dbg, int site, int step, unsigned need, unsigned seen, int index) {
+  if (atomicCAS(&dbg[0], 0, site) == 0) { dbg[1] = (int)blockIdx.x; dbg[2] = step; dbg[3] = (int)need; dbg[4] = (int)seen; dbg[5] = index; dbg[6] = (int)threadIdx.x; }
+}
+// Coherent (agent-scope, sc1) accesses of any width through buffer instructions: the compiler tracks them like any load
+// (8-byte __hip_atomic accesses cost an instruction per double: the 44 loads and 32 stores of a helper lane per step took
+// ~10 k cycles to issue).  Offsets are bytes from the start of the buffer (32 bits: the host refuses systems past 4 GB).
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t coh_buf;
+#define MSFM_COH_SC1 16
+__device__ __forceinline__ coh_buf coh_make(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)std::min<size_t>(bytes, 0xFFFFFFFFull), 0x00020000);
+}
+__device__ __forceinline__ double ld_coh(coh_buf r, size_t idx) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(unsigned)(idx * 8), 0, MSFM_COH_SC1));
+}
+__device__ __forceinline__ d2 ld_coh2(coh_buf r, size_t idx) {
+  return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(unsigned)(idx * 8), 0, MSFM_COH_SC1));
+}
+__device__ __forceinline__ d4 ld_coh4(coh_buf r, size_t idx) {
+  const d2 a = ld_coh2(r, idx), b = ld_coh2(r, idx + 2);
+  d4 v = {a.x, a.y, b.x, b.y};
+  return v;
+}
+__device__ __forceinline__ void st_coh(coh_buf r, size_t idx, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)(unsigned)(idx * 8), 0, MSFM_COH_SC1);
+}
+__device__ __forceinline__ void st_coh2(coh_buf r, size_t idx, d2 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)(unsigned)(idx * 8), 0, MSFM_COH_SC1);
+}
+__device__ __forceinline__ bool chain_aborted(int* fail) {
+  return (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & MSFM_FAIL_SYNC) != 0;
+}
+// wave-uniform wait for a counter of this solve to reach `need`
+__device__ __forceinline__ void wait_count(const unsigned* f, unsigned base, unsigned need, unsigned limit, int* fail, int* dbg, int site, int step,
+                                           int index) {
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned d = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+    if (d < 4096u && d >= need) return;
+    if ((++spins & 1023u) == 0 && (spins > limit || chain_aborted(fail))) {
+      if (spins > limit) chain_note(dbg, site, step, need, d, index);
+      atomicOr(fail, MSFM_FAIL_SYNC);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ int chain_row16(const ChainJob& jb, int at) {
+  if (at < 4 * jb.nA64) return jb.begin + 16 * at;
+  int r = at - 4 * jb.nA64, g = 0;
+  while (g + 1 < jb.nseg && r >= jb.sn16[g]) { r -= jb.sn16[g]; g++; }
+  return jb.sb0[g] + 16 * r;
+}
+// the 64 x 64 block L[t, t-1] from the hand-off buffer into pv (the layout of p0_load), polled value by value
+// (rows from `rows` on carry no data - the system's last block - and have no owner: they are zero, as in M)
+__device__ __forceinline__ void hb_poll(coh_buf hb, size_t blk, int tid, int rows, d2 (&pv)[8], unsigned limit, int* fail, int* dbg, int step) {
+  const double pend_d = __longlong_as_double((long long)MSFM_Z_PENDING);
+  auto is_pend = [](double v) { return (unsigned long long)__double_as_longlong(v) == MSFM_Z_PENDING; };
+#pragma unroll
+  for (int it = 0; it < 8; it++) pv[it].x = pv[it].y = ((tid + 256 * it) >> 5) < rows ? pend_d : 0.0;
+  unsigned spins = 0;
+  for (;;) {
+    bool pend = false;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+      if (is_pend(pv[it].x) || is_pend(pv[it].y)) pv[it] = ld_coh2(hb, blk * NB * NB + r * NB + c2);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) pend |= is_pend(pv[it].x) || is_pend(pv[it].y);
+    if (!__builtin_amdgcn_ballot_w64(pend)) break;
+    if ((++spins & 255u) == 0 && (spins > limit || chain_aborted(fail))) {
+      if (spins > limit && pend) chain_note(dbg, 3, step, 0u, 0u, tid);
+      atomicOr(fail, MSFM_FAIL_SYNC);
+#pragma unroll
+      for (int it = 0; it < 8; it++) { if (is_pend(pv[it].x)) pv[it].x = 0.0; if (is_pend(pv[it].y)) pv[it].y = 0.0; }
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ double hb_safe(double v) {   // (no arithmetic produces the mark; keep the protocol safe anyway)
+  return (unsigned long long)__double_as_longlong(v) == MSFM_Z_PENDING ? __longlong_as_double(0x7FF8000000000000ll) : v;
+}
+
+// A row-owner workgroup runs two programs with the same barriers per step, each with its own loop over the steps (so that
+// a wave's registers hold either the pivot chain's state or a helper's tiles and carried rows, never both):
+// the pivot wave (wave 0) and three helper waves with one 16-row tile of the panel each.  The bodies are panel_col0's; what
+// differs is where the operands come from and go to.
+//
+// One coherent (sc1) round trip costs ~2.5 k cycles on MI355X (measured: scripts/chol_probe), a step's pivot chain 19 k, so
+// a step must not pay more than the one round trip it cannot avoid (L[t, t-1] from its owners):
+//  * the next step's tiles of the diagonal block and of the own rows are fetched DURING the current step, at the start of a
+//    helper phase, once their counters (asked for one phase earlier, tested without waiting) say that the bulk workgroups
+//    are done with them; wave 1 also fetches tile (0, 0) for the pivot wave and hands it over through LDS;
+//  * the rows of the new panel go out without waiting; the counter that releases them to the bulk workgroups is written a
+//    step later, behind the first poll of the hand-off buffer (memory operations complete in issue order), or on exit.
+struct ChainWave {
+  int b, at;        // workgroup of the job, the wave's row tile counted from the node's first row
+  size_t r0;        // first row of that tile in M
+};
+__device__ __forceinline__ bool chain_alive(const ChainJob& jb, int b, int l) { return l < jb.P && (3 * b + 2 >= 4 * l || b == jb.ncw - 1); }
+__device__ __forceinline__ bool chain_is_pub(const ChainJob& jb, int b, int l) { return b == min(l == 0 ? 0 : (4 * l) / 3, jb.ncw - 1); }
+__device__ __forceinline__ bool count_ready(unsigned v, unsigned base, unsigned need) { const unsigned d = v - base; return d < 4096u && d >= need; }
+
+template <bool FULL>
+__device__ __forceinline__ void chain_pivot_step(const ChainJob& jb, const ChainCtl& ctl, coh_buf cH, int l, int n, int* fail, double* Bs, double* Ls,
+                                                 double* dinv, double* dvec, const double* d00s) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int t0 = jb.begin + NB * l;
+  const bool upd = l > 0;
+  const int ncol = min(NB, n - t0);
+  const int tb = t0 / NB;
+  CSTAMP(0);
+  if (upd) {
+    d2 pv[8];
+    hb_poll(cH, (size_t)tb, tid, 16 * min(4, jb.nrt - 4 * l), pv, ctl.spin_limit, fail, ctl.dbg, l);
+    p0_store(Bs, tid, pv);
+  }
+  CSTAMP(2);
+  __syncthreads();   // S1: L[t, t-1] and the block's tile (0, 0) are in LDS
+  d4 D0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) D0[i] = d00s[4 * lane + i];
+  if (upd) D0 = mm_nt_neg<16>(Bs, 0, Bs, 0, 0, lr, lk, D0);
+  tile_st(Ls, 0, 0, lr, lk, D0);
+  __syncthreads();   // S2
+  CSTAMP(3);
+  potrf16_v2<0, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+  __syncthreads();
+  __syncthreads();  // A1
+  if (FULL || 16 < ncol) potrf16_v2<1, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+  else potrf16_skip<1>(dinv, lane);
+  __syncthreads();
+  __syncthreads();  // A2
+  if (FULL || 32 < ncol) potrf16_v2<2, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+  else potrf16_skip<2>(dinv, lane);
+  __syncthreads();
+  __syncthreads();  // A3
+  if (FULL || 48 < ncol) potrf16_v2<3, FULL>(Ls, dinv, dvec, ncol, lane, fail);
+  else potrf16_skip<3>(dinv, lane);
+  __syncthreads();
+  CSTAMP(4);
+}
+
+// what a helper wave carries from step to step
+struct ChainCarry {
+  double xr[16];          // its rows of the previous panel (the `preg` operand)
+  d4 Tn[4], Dn0, Dn1, Dn2, Dn00;   // next step's operands, fetched ahead
+  bool have_next;         // ... are in the registers above
+  unsigned fd, fo;        // the two counters they depend on, as last read
+  bool polled;
+  int store_step;         // > 0: the rows of step store_step - 1 (in xr) have not been written to M yet
+  int flag_step;          // > 0: rowflag[at] = base + flag_step is still to be written (the rows went out without waiting)
+};
+// a helper wave's rows of the panel of step `step` (in xr) to M - for the bulk tiles; nobody on the chain waits for them
+__device__ __forceinline__ void chain_store_rows(coh_buf cM, int ld, const ChainJob& jb, size_t r0, int step, const double (&xr)[16], int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const size_t dst = (r0 + lr) * ld + jb.begin + NB * step;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const d2 lo = {xr[4 * q], xr[4 * q + 1]}, hi = {xr[4 * q + 2], xr[4 * q + 3]};
+    st_coh2(cM, dst + 16 * q + 4 * lk, lo);
+    st_coh2(cM, dst + 16 * q + 4 * lk + 2, hi);
+  }
+}
+__device__ __forceinline__ void chain_release_rows(const ChainJob& jb, const ChainCtl& ctl, int at, int flag_step, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have reached the coherence point before the counter moves
+  if (lane == 0) __hip_atomic_store(&ctl.rowflag[jb.flag0 + at], ctl.base + (unsigned)flag_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool FULL>
+__device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_buf cM, coh_buf cH, int ld, const ChainJob& jb, const ChainCtl& ctl,
+                                                  const ChainWave& W, int l, int n,
+                                                  double* __restrict__ Dinv, double* __restrict__ Ldiag, int* fail, double* Bs, double* Ls, double* dinv,
+                                                  double* d00s, ChainCarry& C) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int t0 = jb.begin + NB * l, at = W.at;
+  const size_t r0 = W.r0;
+  const bool upd = l > 0;
+  const int tb = t0 / NB;
+  const bool is_pub = chain_is_pub(jb, W.b, l);
+  const bool own = at >= 4 * (l + 1) && at < jb.nrt;
+  double* const pub_lo = Ldiag + (size_t)tb * NB * NB;
+  double* const pub_out = Dinv + (size_t)tb * 1024;
+  const int plr = 4 * (lr & 3) + (lr >> 2);
+  const int ta = wave, tb2 = wave == 1 ? 2 : 3, tc = wave == 3 ? 3 : 2;
+  d4 T[4], D0, D1, D2, D00;
+  if (C.have_next) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) T[q] = C.Tn[q];
+    D0 = C.Dn0; D1 = C.Dn1; D2 = C.Dn2; D00 = C.Dn00;
+  } else {
+    // not fetched ahead (first step; or the bulk workgroups were late): wait for the counters here
+    const unsigned need = l >= 2 ? (unsigned)(l - 1) : 0u;
+    if (need) wait_count(&ctl.tileflag[(size_t)tb * ctl.nblk + tb], ctl.base, need, ctl.spin_limit, fail, ctl.dbg, 1, l, tb * ctl.nblk + tb);
+    if (own) {
+      if (need) wait_count(&ctl.tileflag[(size_t)(r0 / NB) * ctl.nblk + tb], ctl.base, need, ctl.spin_limit, fail, ctl.dbg, 2, l, (int)(r0 / NB) * ctl.nblk + tb);
+      const size_t src = (r0 + lr) * ld;
+#pragma unroll
+      for (int q = 0; q < 4; q++) T[q] = ld_coh4(cM, src + t0 + 16 * q + 4 * lk);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      D0[i] = ld_coh(cM, (size_t)(t0 + 16 * wave + lk + 4 * i) * ld + t0 + lr);
+      D1[i] = ld_coh(cM, (size_t)(t0 + 16 * ta + lk + 4 * i) * ld + t0 + 16 + lr);
+      D2[i] = ld_coh(cM, (size_t)(t0 + 16 * tb2 + lk + 4 * i) * ld + t0 + 16 * tc + lr);
+      if (wave == 1) D00[i] = ld_coh(cM, (size_t)(t0 + lk + 4 * i) * ld + t0 + lr);
+    }
+  }
+  C.have_next = false;
+  C.polled = false;
+  // next step's operands: which, and behind which counters
+  const bool want_next = chain_alive(jb, W.b, l + 1);
+  const bool own_n = at >= 4 * (l + 2) && at < jb.nrt;
+  const unsigned need_n = l + 1 >= 2 ? (unsigned)l : 0u;
+  const int t1 = t0 + NB;
+  const unsigned* const fdp = &ctl.tileflag[(size_t)(tb + 1) * ctl.nblk + tb + 1];
+  const unsigned* const fop = &ctl.tileflag[(size_t)(r0 / NB) * ctl.nblk + tb + 1];
+  auto fetch_ahead = [&]() {
+    if (!want_next || C.have_next) return;
+    if (need_n == 0 || (C.polled && count_ready(C.fd, ctl.base, need_n) && (!own_n || count_ready(C.fo, ctl.base, need_n)))) {
+      if (own_n) {
+        const size_t src = (r0 + lr) * ld;
+#pragma unroll
+        for (int q = 0; q < 4; q++) C.Tn[q] = ld_coh4(cM, src + t1 + 16 * q + 4 * lk);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        C.Dn0[i] = ld_coh(cM, (size_t)(t1 + 16 * wave + lk + 4 * i) * ld + t1 + lr);
+        C.Dn1[i] = ld_coh(cM, (size_t)(t1 + 16 * ta + lk + 4 * i) * ld + t1 + 16 + lr);
+        C.Dn2[i] = ld_coh(cM, (size_t)(t1 + 16 * tb2 + lk + 4 * i) * ld + t1 + 16 * tc + lr);
+        if (wave == 1) C.Dn00[i] = ld_coh(cM, (size_t)(t1 + lk + 4 * i) * ld + t1 + lr);
+      }
+      C.have_next = true;
+    } else {
+      C.fd = __hip_atomic_load(fdp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      C.fo = own_n ? __hip_atomic_load(fop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      C.polled = true;
+    }
+  };
+  if (upd) {
+    d2 pv[8];
+    hb_poll(cH, (size_t)tb, tid, 16 * min(4, jb.nrt - 4 * l), pv, ctl.spin_limit, fail, ctl.dbg, l);
+    p0_store(Bs, tid, pv);
+  }
+  if (wave == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) d00s[4 * lane + i] = D00[i];
+  }
+  CSTAMP_H(5);
+  __syncthreads();   // S1
+#define MSFM_KC(s) (16 * ((s) >> 2) + 4 * lk + ((s) & 3))
+  // ---- column 0 of the updated diagonal block: one 16x16 tile per wave ----
+  if (upd) D0 = mm_nt_neg<16>(Bs, 16 * wave, Bs, 0, 0, lr, lk, D0);
+  tile_st(Ls, wave, 0, lr, lk, D0);
+  __syncthreads();   // S2
+  d4 X[4];
+  // ---- B0 ----
+  if (C.store_step > 0) {   // the rows of the previous step, now that nobody on the chain waits for this wave
+    chain_store_rows(cM, ld, jb, r0, C.store_step - 1, C.xr, lane);
+    C.flag_step = C.store_step;
+    C.store_step = 0;
+  }
+  fetch_ahead();
+  if (upd) D1 = mm_nt_neg<16>(Bs, 16 * ta, Bs, 16, 0, lr, lk, D1);
+  tile_st(Ls, ta, 1, lr, lk, D1);
+  if (own && upd) {
+#pragma unroll
+    for (int s = 0; s < 16; s++) T[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[plr * LDT + MSFM_KC(s)], C.xr[s], T[0], 0, 0, 0);
+  }
+  __syncthreads();
+  // ---- A1 ----
+  tile_st(Ls, ta, 1, lr, lk, mm_nt_neg<4>(Ls, 16 * ta, Ls, 16, 0, lr, lk, tile_ld(Ls, ta, 1, lr, lk)));
+  __syncthreads();
+  // ---- B1 ----
+  if (C.flag_step > 0) { chain_release_rows(jb, ctl, at, C.flag_step, lane); C.flag_step = 0; }
+  fetch_ahead();
+  if (upd) D2 = mm_nt_neg<16>(Bs, 16 * tb2, Bs, 16 * tc, 0, lr, lk, D2);
+  D2 = mm_nt_neg<4>(Ls, 16 * tb2, Ls, 16 * tc, 0, lr, lk, D2);
+  tile_st(Ls, tb2, tc, lr, lk, D2);
+  if (own) {
+    d4 Y = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[plr * DV + 4 * lk + s], T[0][s], Y, 0, 0, 0);
+    X[0] = Y;
+    if (upd) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(16 + plr) * LDT + MSFM_KC(s)], C.xr[s], T[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(16 + plr) * LDT + 4 * lk + s], X[0][s], T[1], 0, 0, 0);
+  }
+  if (is_pub) publish_subpanel(Ls, dinv, pub_lo, pub_out, 0, tid - 64, 192);
+  __syncthreads();
+  // ---- A2 ----
+  if (wave != 3) tile_st(Ls, tb2, 2, lr, lk, mm_nt_neg<4>(Ls, 16 * tb2, Ls, 32, 16, lr, lk, tile_ld(Ls, tb2, 2, lr, lk)));
+  __syncthreads();
+  // ---- B2 ----
+  fetch_ahead();
+  if (wave == 3) tile_st(Ls, 3, 3, lr, lk, mm_nt_neg<4>(Ls, 48, Ls, 48, 16, lr, lk, tile_ld(Ls, 3, 3, lr, lk)));
+  if (own) {
+    d4 Y = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(16 + plr) * DV + 4 * lk + s], T[1][s], Y, 0, 0, 0);
+    X[1] = Y;
+    if (upd) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(32 + plr) * LDT + MSFM_KC(s)], C.xr[s], T[2], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 2; i2++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(32 + plr) * LDT + 16 * i2 + 4 * lk + s], X[i2][s], T[2], 0, 0, 0);
+  }
+  if (is_pub) publish_subpanel(Ls, dinv, pub_lo, pub_out, 1, tid - 64, 192);
+  __syncthreads();
+  // ---- A3 ----
+  if (wave == 3) tile_st(Ls, 3, 3, lr, lk, mm_nt_neg<4>(Ls, 48, Ls, 48, 32, lr, lk, tile_ld(Ls, 3, 3, lr, lk)));
+  __syncthreads();
+  // ---- B3 ----
+  fetch_ahead();
+  if (own) {
+    d4 Y = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(32 + plr) * DV + 4 * lk + s], T[2][s], Y, 0, 0, 0);
+    X[2] = Y;
+    if (upd) {
+#pragma unroll
+      for (int s = 0; s < 16; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(48 + plr) * LDT + MSFM_KC(s)], C.xr[s], T[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 3; i2++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(48 + plr) * LDT + 16 * i2 + 4 * lk + s], X[i2][s], T[3], 0, 0, 0);
+  }
+  if (is_pub) publish_subpanel(Ls, dinv, pub_lo, pub_out, 2, tid - 64, 192);
+  __syncthreads();   // S9
+  // ---- tail: X_3 = T_3 Dinv_3^T; the rows go out: to the hand-off buffer first when they are the rows of the next diagonal
+  //      block (everybody's next step waits for them), then to M for the bulk tiles ----
+  if (own) {
+    d4 Y = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(48 + plr) * DV + 4 * lk + s], T[3][s], Y, 0, 0, 0);
+    X[3] = Y;
+    if (at < 4 * (l + 2) && l + 1 < jb.P) {
+      const size_t hrow = (size_t)(tb + 1) * NB * NB + (size_t)(16 * (at & 3) + lr) * NB;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const d2 lo = {hb_safe(X[q][0]), hb_safe(X[q][1])}, hi = {hb_safe(X[q][2]), hb_safe(X[q][3])};
+        st_coh2(cH, hrow + 16 * q + 4 * lk, lo);
+        st_coh2(cH, hrow + 16 * q + 4 * lk + 2, hi);
+      }
+    }
+    CSTAMP_H(6);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) C.xr[4 * q + j] = X[q][j];
+    C.store_step = l + 1;   // to M during the next step (or on exit)
+  }
+  CSTAMP_H(7);
+#undef MSFM_KC
+  if (is_pub) {
+    // (publish_subpanel of the last quarter by the helper waves alone: the pivot wave is already on its way to the next step)
+    publish_subpanel(Ls, dinv, pub_lo, pub_out, 3, tid - 64, 192);
+    if (!FULL) {
+      for (int e = tid - 64; e < NB * NB; e += 192) {
+        const int r = e >> 6, c = e & 63;
+        if (c <= r) M[(size_t)(t0 + r) * ld + t0 + c] = Ls[r * LDT + c];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, int n, double* __restrict__ Dinv, double* __restrict__ Ldiag,
+                                                int* fail, ChainJobs jobs, ChainCtl ctl) {
+  __shared__ double sm[80 + 64 * DV + 2 * 64 * LDT];
+  __shared__ double d00s[256];
+  __shared__ int task[8];
+  double* As = sm + 80 + 64 * DV;
+  double* Bs = As + 64 * LDT;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const coh_buf cM = coh_make(M, (size_t)ld * ld * sizeof(double));
+  const coh_buf cH = coh_make(ctl.hb, (size_t)ctl.nblk * NB * NB * sizeof(double));
+  if ((int)blockIdx.x < jobs.n_row_wg) {
+    // ---------------- row owner ----------------
+    int ji = 0;
+    for (int k = 1; k < jobs.count; k++)
+      if ((int)blockIdx.x >= jobs.job[k].wg0) ji = k;
+    const ChainJob& jb = jobs.job[ji];
+    const int b = blockIdx.x - jb.wg0;
+    if (wave == 0) {
+      for (int l = 0; chain_alive(jb, b, l); l++) {
+        if (n - (jb.begin + NB * l) >= NB) chain_pivot_step<true>(jb, ctl, cH, l, n, fail, Bs, As, sm + 80, sm, d00s);
+        else chain_pivot_step<false>(jb, ctl, cH, l, n, fail, Bs, As, sm + 80, sm, d00s);
+      }
+    } else {
+      ChainWave W;
+      W.b = b;
+      W.at = 4 + 3 * b + wave - 1;
+      W.r0 = (size_t)chain_row16(jb, W.at < jb.nrt ? W.at : 0);
+      ChainCarry C;
+#pragma unroll
+      for (int i = 0; i < 16; i++) C.xr[i] = 0.0;
+      C.have_next = false; C.polled = false; C.fd = C.fo = 0u; C.flag_step = 0; C.store_step = 0;
+      for (int l = 0; chain_alive(jb, b, l); l++) {
+        if (n - (jb.begin + NB * l) >= NB) chain_helper_step<true>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C);
+        else chain_helper_step<false>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C);
+      }
+      if (C.store_step > 0) { chain_store_rows(cM, ld, jb, W.r0, C.store_step - 1, C.xr, lane); C.flag_step = C.store_step; }
+      if (C.flag_step > 0) chain_release_rows(jb, ctl, W.at, C.flag_step, lane);
+    }
+    return;
+  }
+  // ---------------- bulk: tiles of the trailing updates, by ticket ----------------
+  const int bi = blockIdx.x - jobs.n_row_wg;
+  {
+    // the other hand-off buffer becomes "pending" for the blocks of this launch; the next launch's ticket counter zero
+    for (int k = 0; k < jobs.count; k++) {
+      unsigned long long* dst = ctl.hb_next + (size_t)(jobs.job[k].begin / NB) * NB * NB;
+      const size_t cnt = (size_t)jobs.job[k].P * NB * NB;
+      for (size_t e = (size_t)bi * 256 + tid; e < cnt; e += (size_t)jobs.n_bulk_wg * 256) dst[e] = MSFM_Z_PENDING;
+    }
+    if (bi == 0 && tid == 0) *ctl.ticket_next = 0;
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;
+  const int total = ctl.task_first[jobs.n_steps * 8];
+  int cur = 0;   // (thread 0) position in task_first
+  for (;;) {
+    if (tid == 0) {
+      const int t = atomicAdd(ctl.ticket, 1);
+      int l = -1, k = 0, I = 0, J = 0;
+      if (t < total) {
+        while (t >= ctl.task_first[cur + 1]) cur++;
+        l = 1 + cur / 8; k = cur % 8;
+        int q = t - ctl.task_first[cur];
+        const ChainJob& jb = jobs.job[k];
+        const int nA = jb.nA64 - l;                    // 64-row blocks of range A from the diagonal block on
+        // column-major over the columns 1 .. nA - 1 behind the diagonal block: the rows of A from the column on, then range B
+        J = 1;
+        for (;;) { const int c = nA - J + jb.nB64; if (q < c) break; q -= c; J++; }
+        I = q < nA - J ? J + q : nA + (q - (nA - J));
+      }
+      task[0] = l; task[1] = k; task[2] = I; task[3] = J;
+    }
+    __syncthreads();
+    const int l = task[0], k = task[1], I = task[2], J = task[3];
+    if (l < 0) break;
+    const ChainJob& jb = jobs.job[k];
+    const int j0 = jb.begin + NB * (l - 1);             // the panel to apply
+    const int ti = 4 * (I + l), tj = 4 * (J + l);      // first row tiles of the two 64-row blocks, counted from the node's first row
+    const int ri = chain_row16(jb, ti), rj = chain_row16(jb, tj);
+    const size_t C = (size_t)ri * ld + rj;
+    if (wave == 0) {
+      // the eight row tiles of the panel, and the tile's own history
+      if (lane < 8) {
+        const int tt = (lane < 4 ? ti : tj) + (lane & 3);
+        if (tt < jb.nrt) wait_count(&ctl.rowflag[jb.flag0 + tt], ctl.base, (unsigned)l, ctl.spin_limit, fail, ctl.dbg, 4, l, tt);
+      } else if (lane == 8 && l >= 2) {
+        wait_count(&ctl.tileflag[(size_t)(ri / NB) * ctl.nblk + rj / NB], ctl.base, (unsigned)(l - 1), ctl.spin_limit, fail, ctl.dbg, 5, l, (ri / NB) * ctl.nblk + rj / NB);
+      }
+    }
+    __syncthreads();
+    d4 c00, c01, c10, c11;
+    d2 va[8], vb[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+      va[it] = ld_coh2(cM, (size_t)(ri + r) * ld + j0 + c2);
+      vb[it] = ld_coh2(cM, (size_t)(rj + r) * ld + j0 + c2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
+      const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
+      c00[i] = ld_coh(cM, p0); c01[i] = ld_coh(cM, p0 + 16); c10[i] = ld_coh(cM, p1); c11[i] = ld_coh(cM, p1 + 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+      As[r * LDT + c2] = -va[it].x;
+      As[r * LDT + c2 + 1] = -va[it].y;
+      Bs[r * LDT + c2] = vb[it].x;
+      Bs[r * LDT + c2 + 1] = vb[it].y;
+    }
+    __syncthreads();
+    quad_abt(As, Bs, wr, wc, lr, lk, c00, c01, c10, c11);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
+      const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
+      st_coh(cM, p0, c00[i]); st_coh(cM, p0 + 16, c01[i]); st_coh(cM, p1, c10[i]); st_coh(cM, p1 + 16, c11[i]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every wave's part of the tile is out (and everybody is done with As / Bs and task[])
+    if (tid == 0)
+      __hip_atomic_store(&ctl.tileflag[(size_t)(ri / NB) * ctl.nblk + rj / NB], ctl.base + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // The separator x separator part of the domain chains' trailing updates, all at once:  corner_r[I][J] = -sum_p X_I,p X_J,p^T
 // over the 64-column panels p = p_begin + r, p_begin + r + nsplit, ... of the level's columns [64 p_begin, b0) (X = the rows
 // of the factor from b0 on).
@@ -1114,12 +1680,173 @@ int msfm_chol_fill_pending(msfm_ctx* ctx, double* z, int npad) {
   return MSFM_OK;
 }
 
+// ---- host side of the persistent chain ----
+struct ChainLaunch {
+  ChainJobs jobs;
+  int task_off = 0;     // first entry of the launch's table in ws->task_first
+  int steps = 0;        // panel steps on its critical path (for the timers)
+  bool usable = false;
+};
+struct msfm_chol_ws {
+  msfm_ctx* ctx = nullptr;
+  int npad = 0;
+  DevBuf<unsigned> flags;     // rowflag [8][npad / 16], then tileflag [(npad / 64)^2]
+  DevBuf<double> hb;          // two hand-off buffers of npad x 64
+  DevBuf<int> tickets;        // [8]
+  DevBuf<int> task_first;
+  unsigned epoch = 0, n_launch = 0, flag_epoch = 0;   // solves (hand-off buffer parity), launches (ticket slot), launches (counter tag)
+  bool dirty = true;          // the hand-off buffers and tickets must be (re)initialised before the next use
+  // launches of the plan they were built for (levels in order, then the root chain)
+  std::vector<ChainLaunch> launch;
+  unsigned long long sig = 0;
+  int capacity = 0;           // resident workgroups of k_chain on the context's device
+};
+
+int msfm_chol_ws_create(msfm_ctx* ctx, int npad, msfm_chol_ws** out) {
+  if (!ctx || !out || npad < NB || npad % NB) return MSFM_E_INVAL;
+  std::unique_ptr<msfm_chol_ws> w(new msfm_chol_ws());
+  w->ctx = ctx; w->npad = npad;
+  const size_t nt16 = npad / 16, nb = npad / NB;
+  HIP_TRY(ctx, w->flags.alloc(8 * nt16 + nb * nb));
+  HIP_TRY(ctx, w->hb.alloc(2 * (size_t)npad * NB));
+  HIP_TRY(ctx, w->tickets.alloc(16));   // eight ticket counters, then the eight words of the give-up note
+  HIP_TRY(ctx, hipMemsetAsync(w->tickets.p, 0, sizeof(int) * 16, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(w->flags.p, 0, sizeof(unsigned) * w->flags.n, ctx->stream));
+  w->capacity = resident_workgroups(ctx, k_chain, 256);
+  *out = w.release();
+  return MSFM_OK;
+}
+void msfm_chol_ws_destroy(msfm_chol_ws* w) { delete w; }
+
+// The launches of a plan: one per tree level (its K node chains side by side), then the root chain.
+static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
+  msfm_ctx* ctx = ws->ctx;
+  const int nrows = n + 1, n_levels = plan ? plan->n_levels : 0;
+  unsigned long long sig = 1469598103934665603ull;
+  auto mix = [&](long v) { sig = (sig ^ (unsigned long long)v) * 1099511628211ull; };
+  mix(n); mix(n_levels);
+  for (int lv = 0; lv < n_levels; lv++) {
+    mix(plan->level[lv].K); mix(plan->level[lv].b0);
+    for (int k = 0; k < plan->level[lv].K; k++) { mix(plan->level[lv].node[k].begin); mix(plan->level[lv].node[k].end); mix(plan->level[lv].node[k].leaf_lo); mix(plan->level[lv].node[k].leaf_hi); }
+  }
+  if (sig == ws->sig && !ws->launch.empty()) return MSFM_OK;
+  ws->launch.clear();
+  std::vector<int> table;
+  const int root_begin = n_levels ? plan->level[n_levels - 1].b0 : 0;
+  const int nt16 = ws->npad / 16;
+  for (int lv = 0; lv <= n_levels; lv++) {
+    ChainLaunch L;
+    ChainJobs& J = L.jobs;
+    memset(&J, 0, sizeof J);
+    int wg = 0, maxp = 0;
+    if (lv < n_levels) {
+      const msfm_chol_level& PL = plan->level[lv];
+      for (int k = 0; k < PL.K; k++) {
+        const msfm_chol_node& nd = PL.node[k];
+        const int P = (nd.end - nd.begin) / NB;
+        if (P <= 0) continue;
+        ChainJob& jb = J.job[J.count];
+        jb.begin = nd.begin; jb.P = P; jb.nA64 = P;
+        jb.nseg = 0;
+        int rows16 = 0;
+        for (int h = lv + 1; h < n_levels; h++)
+          for (int q = 0; q < plan->level[h].K; q++) {
+            const msfm_chol_node& a = plan->level[h].node[q];
+            if (a.leaf_lo <= nd.leaf_lo && a.leaf_hi >= nd.leaf_hi) { jb.sb0[jb.nseg] = a.begin; jb.sn16[jb.nseg] = (a.end - a.begin) / 16; rows16 += jb.sn16[jb.nseg]; jb.nseg++; }
+          }
+        jb.sb0[jb.nseg] = root_begin; jb.sn16[jb.nseg] = cdiv(nrows - root_begin, 16); rows16 += jb.sn16[jb.nseg]; jb.nseg++;
+        jb.nb16 = rows16; jb.nB64 = cdiv(rows16, 4);
+        jb.nrt = 4 * P + rows16;
+        jb.ncw = std::max(1, cdiv(jb.nrt - 4, 3));
+        jb.wg0 = wg; wg += jb.ncw;
+        jb.flag0 = J.count * nt16;
+        if (jb.nrt > nt16) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: chain job larger than the flag table");
+        maxp = std::max(maxp, P);
+        J.count++;
+      }
+    } else {
+      const int t_first = root_begin;
+      if (t_first < n) {
+        ChainJob& jb = J.job[0];
+        jb.begin = t_first; jb.P = cdiv(n - t_first, NB); jb.nA64 = cdiv(nrows - t_first, NB);
+        jb.nseg = 0; jb.nb16 = 0; jb.nB64 = 0;
+        jb.nrt = cdiv(nrows - t_first, 16);
+        jb.ncw = std::max(1, cdiv(jb.nrt - 4, 3));
+        jb.wg0 = 0; wg = jb.ncw; jb.flag0 = 0;
+        maxp = jb.P;
+        J.count = 1;
+      }
+    }
+    J.n_row_wg = wg;
+    J.n_steps = std::max(0, maxp - 1);
+    L.steps = maxp;
+    L.task_off = (int)table.size();
+    int t = 0, max_step_tasks = 0;
+    for (int l = 1; l <= J.n_steps; l++) {
+      int step_tasks = 0;
+      for (int k = 0; k < 8; k++) {
+        table.push_back(t);
+        if (k < J.count && l < J.job[k].P) {
+          const int nA = J.job[k].nA64 - l;
+          const int c = nA * (nA - 1) / 2 + J.job[k].nB64 * (nA - 1);
+          t += c; step_tasks += c;
+        }
+      }
+      max_step_tasks = std::max(max_step_tasks, step_tasks);
+    }
+    table.push_back(t);
+    // bulk workgroups: what the device holds beside the row owners, at most one per tile of the busiest step
+    const int room = ws->capacity - wg;
+    J.n_bulk_wg = std::max(1, std::min(room, max_step_tasks));
+    // usable: every row owner resident with room to spare (other processes may share the device), a bulk workgroup for
+    // every three tiles of the busiest step at least
+    static const bool force = getenv("MSFM_CHAIN_FORCE") != nullptr;   // (probes: take the chain whatever the tile count)
+    L.usable = J.count > 0 && wg <= ws->capacity / 2 && (max_step_tasks == 0 || 3 * room >= max_step_tasks || force) && maxp < 4000;
+    ws->launch.push_back(L);
+  }
+  HIP_TRY(ctx, ws->task_first.alloc(std::max<size_t>(1, table.size())));
+  HIP_TRY(ctx, hipMemcpyAsync(ws->task_first.p, table.data(), sizeof(int) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (the host table goes away on return; built once per plan)
+  ws->sig = sig;
+  return MSFM_OK;
+}
+
+static unsigned chain_spin_limit() {
+  static const unsigned v = [] {
+    const char* e = getenv("MSFM_SYNC_TIMEOUT_S");
+    const double s = e ? atof(e) : 120.0;
+    return (unsigned)std::min(4.0e9, std::max(1.0e4, (s > 0 ? s : 120.0) * 3.0e6));
+  }();
+  return v;
+}
+
+static int chain_launch(msfm_chol_ws* ws, const ChainLaunch& L, double* M, int npad, int n, double* Dinv, double* Ldiag, int* fail) {
+  msfm_ctx* ctx = ws->ctx;
+  ChainCtl c;
+  const size_t nt16 = npad / 16, nb = npad / NB;
+  c.rowflag = ws->flags.p;
+  c.tileflag = ws->flags.p + 8 * nt16;
+  const unsigned par = ws->epoch & 1u;
+  c.hb = ws->hb.p + (size_t)par * npad * NB;
+  c.hb_next = reinterpret_cast<unsigned long long*>(ws->hb.p + (size_t)(par ^ 1u) * npad * NB);
+  const unsigned slot = ws->n_launch++ & 7u;
+  c.ticket = ws->tickets.p + slot;
+  c.ticket_next = ws->tickets.p + ((slot + 1) & 7u);
+  c.task_first = ws->task_first.p + L.task_off;
+  c.base = (++ws->flag_epoch & 0xFFFFFu) << 12;   // per LAUNCH: the launches of one solve reuse the rowflag slots of their jobs
+  c.spin_limit = chain_spin_limit();
+  c.nblk = (int)nb;
+  c.dbg = ws->tickets.p + 8;
+  hipLaunchKernelGGL(k_chain, dim3(L.jobs.n_row_wg + L.jobs.n_bulk_wg), dim3(256), 0, ctx->stream, M, npad, n, Dinv, Ldiag, fail, L.jobs, c);
+  return MSFM_OK;
+}
+
 // z_next (optional): a second solution buffer of npad doubles.  With it the caller promises that `z` already holds
 // MSFM_Z_PENDING everywhere (msfm_chol_fill_pending once, afterwards the previous call's z_next) and gets z_next back in that
 // state - the two buffers alternate from solve to solve and no fill launch sits on the critical path.  Without it the
 // function fills z itself first.
 int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z, int* fail,
-                           const msfm_chol_plan* plan, double* z_next) {
+                           const msfm_chol_plan* plan, double* z_next, msfm_chol_ws* ws) {
   if (!M || !work || !w || !z || !fail || npad % NB != 0 || n < 1 || n + 1 > npad)
     return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad workspace (null buffer or size)");
   hipStream_t s = ctx->stream;
@@ -1129,6 +1856,23 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   double* Ldiag = work + (size_t)npad * 80;
   int t_first = 0;
   const int n_levels = plan ? plan->n_levels : 0;
+  // the persistent chain (one launch per tree level) when the caller keeps a workspace for it; MSFM_CHOL_LAUNCHES=1: the
+  // round-3 chain of one launch per 64-column panel, for comparison
+  const bool chol_launches_env = getenv("MSFM_CHOL_LAUNCHES") != nullptr;   // (read per call: the tests switch it between solves)
+  bool use_chain = ws && !chol_launches_env && ws->npad == npad && ws->capacity > 0 && (size_t)npad * npad * sizeof(double) < 0xFFFFFFFFull;   // (32-bit buffer offsets)
+  if (use_chain) {
+    MSFM_TRY(chain_build(ws, n, plan));
+    if ((int)ws->launch.size() != n_levels + 1) use_chain = false;
+  }
+  if (use_chain) {
+    ws->epoch++;
+    if (ws->dirty) {
+      MSFM_TRY(msfm_chol_fill_pending(ctx, ws->hb.p, 2 * npad * NB));
+      HIP_TRY(ctx, hipMemsetAsync(ws->tickets.p, 0, sizeof(int) * 8, s));
+      ws->n_launch = 0;
+      ws->dirty = false;
+    }
+  }
   if (n_levels > 0) {
     if (n_levels > 3 || !plan->corners) return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: bad plan");
     // every level is checked before the first launch: a refusal must not leave half a factorisation behind
@@ -1164,7 +1908,12 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
       for (int k = 0; k < K; k++) maxp = std::max(maxp, (L.node[k].end - L.node[k].begin) / NB);
       KTimer chain_timer(ctx, "chol_panel_mfma");   // the level's chain of panel launches as a whole
       chain_timer.count = 0;
-      for (int l = 0; l < maxp; l++) {
+      const bool lv_chain = use_chain && ws->launch[lv].usable;
+      if (lv_chain) {
+        MSFM_TRY(chain_launch(ws, ws->launch[lv], M, npad, n, Dinv, Ldiag, fail));
+        chain_timer.count = ws->launch[lv].steps;   // (counted in panel steps, so that a step's time compares with the launch chain's)
+      }
+      for (int l = 0; l < maxp && !lv_chain; l++) {
         PanelJobs jobs;
         jobs.count = 0;
         int wg = 0;
@@ -1240,7 +1989,12 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   }
   KTimer root_timer(ctx, "chol_panel_mfma");
   root_timer.count = 0;
-  for (int t0 = t_first; t0 < n; t0 += NB) {
+  const bool root_chain = use_chain && ws->launch[n_levels].usable;
+  if (root_chain) {
+    MSFM_TRY(chain_launch(ws, ws->launch[n_levels], M, npad, n, Dinv, Ldiag, fail));
+    root_timer.count = ws->launch[n_levels].steps;
+  }
+  for (int t0 = t_first; t0 < n && !root_chain; t0 += NB) {
     // the separator (or the whole matrix): one job per launch, its first block has nothing left to apply
     const int j0 = t0 > t_first ? t0 - NB : -1;
     PanelJobs jobs;
@@ -1345,6 +2099,9 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     }
   }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "cholesky launch: %s", hipGetErrorString(e));
+  if (e != hipSuccess) {
+    if (ws) ws->dirty = true;
+    return msfm_set_error(ctx, MSFM_E_DEVICE, "cholesky launch: %s", hipGetErrorString(e));
+  }
   return MSFM_OK;
 }

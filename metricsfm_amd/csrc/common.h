@@ -212,6 +212,9 @@ struct msfm_chol_plan {
   double* corners = nullptr;
   int ldc = 0;
 };
+struct msfm_chol_ws;   // hand-off state of the persistent panel chain (chol.hip): flags, hand-off buffers, ticket counters
+int msfm_chol_ws_create(msfm_ctx* ctx, int npad, msfm_chol_ws** out);
+void msfm_chol_ws_destroy(msfm_chol_ws* ws);
 int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* work, double* w, double* z, int* fail,
-                           const msfm_chol_plan* plan, double* z_next = nullptr);
+                           const msfm_chol_plan* plan, double* z_next = nullptr, msfm_chol_ws* ws = nullptr);
 int msfm_chol_fill_pending(msfm_ctx* ctx, double* z, int npad);   // "not solved yet" marks of k_backsolve_chain

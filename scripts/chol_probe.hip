@@ -8,11 +8,13 @@ __device__ int g_probe_wg = 0;
 __device__ volatile int g_probe_on = 0;
 #define MSFM_PROBE_ARM(j0v) do { if (threadIdx.x == 0 && (int)blockIdx.x == g_probe_wg) g_probe_on = ((j0v) == g_probe_j0); } while (0)
 #define MSFM_PROBE(i) do { if (threadIdx.x == 0 && (int)blockIdx.x == g_probe_wg && g_probe_on) g_probe[i] = clock64(); } while (0)
+#define MSFM_CHAIN_STAMPS 1
 #include "../metricsfm_amd/csrc/chol.hip"
 #include <cstdio>
 #include <vector>
 #include <random>
 #include <cmath>
+#include <cstring>
 #include <algorithm>
 
 int main(int argc, char** argv) {
@@ -42,32 +44,74 @@ int main(int argc, char** argv) {
   hipMemcpyToSymbol(HIP_SYMBOL(g_probe_j0), &pj0, sizeof(int));
   hipMemcpyToSymbol(HIP_SYMBOL(g_probe_wg), &pwg, sizeof(int));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 3; rep++) {
-    hipMemcpy(M, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
-    hipDeviceSynchronize();
-    hipEventRecord(e0, ctx->stream);
-    int rc = msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, nullptr);
-    hipEventRecord(e1, ctx->stream);
-    hipDeviceSynchronize();
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    long long pr[32];
-    hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof pr);
-    int hf; hipMemcpy(&hf, fail, 4, hipMemcpyDeviceToHost);
-    printf("rep %d rc %d fail %d total %.3f ms; probes (cycles since p0):", rep, rc, hf, ms);
-    for (int i = 0; i < 16; i++) printf(" [%d]%lld", i, pr[i] ? pr[i] - pr[0] : -1);
-    printf("\n");
-    if (rep == 0) {
-      std::vector<double> zh(npad);
-      hipMemcpy(zh.data(), z, sizeof(double) * npad, hipMemcpyDeviceToHost);
-      double rmax = 0, bmax = 0;
-      for (int r = 0; r < n; r++) {
-        double acc = 0;
-        for (int c = 0; c < n; c++) acc += (c <= r ? h[(size_t)r * npad + c] : h[(size_t)c * npad + r]) * zh[c];
-        rmax = std::max(rmax, std::fabs(acc - h[(size_t)n * npad + r]));
-        bmax = std::max(bmax, std::fabs(h[(size_t)n * npad + r]));
+  msfm_chol_ws* ws = nullptr;
+  if (msfm_chol_ws_create(ctx, npad, &ws) != 0) { printf("no ws\n"); return 1; }
+  printf("k_chain resident workgroups: %d\n", ws->capacity);
+  std::vector<double> Mref, Mnew((size_t)npad * npad), zref(npad), znew(npad), wk_ref, wk_new((size_t)npad * 144);
+  for (int mode = 0; mode < 2; mode++) {   // 0: one launch per panel (round 3), 1: the persistent chain
+    for (int rep = 0; rep < 4; rep++) {
+      hipMemcpy(M, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+      hipMemset(fail, 0, 16);
+      hipDeviceSynchronize();
+      hipEventRecord(e0, ctx->stream);
+      int rc = msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, nullptr, nullptr, mode ? ws : nullptr);
+      hipEventRecord(e1, ctx->stream);
+      hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      int hf; hipMemcpy(&hf, fail, 4, hipMemcpyDeviceToHost);
+      printf("mode %d rep %d rc %d fail %d total %.3f ms\n", mode, rep, rc, hf, ms);
+      fflush(stdout);
+      if (hf & (1 << 20)) {
+        int dbg[8];
+        hipMemcpy(dbg, ws->tickets.p + 8, sizeof dbg, hipMemcpyDeviceToHost);
+        printf("SYNC failure: site %d workgroup %d step %d need %d seen %d index %d thread %d - stopping\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+        return 2;
       }
-      printf("residual max |S z - b| = %.3e (|b|max %.3e)\n", rmax, bmax);
     }
+    std::vector<double>& Mh = mode ? Mnew : (Mref.resize((size_t)npad * npad), Mref);
+    std::vector<double>& zh = mode ? znew : zref;
+    std::vector<double>& wk = mode ? wk_new : (wk_ref.resize((size_t)npad * 144), wk_ref);
+    hipMemcpy(Mh.data(), M, sizeof(double) * Mh.size(), hipMemcpyDeviceToHost);
+    hipMemcpy(zh.data(), z, sizeof(double) * npad, hipMemcpyDeviceToHost);
+    hipMemcpy(wk.data(), work, sizeof(double) * wk.size(), hipMemcpyDeviceToHost);
+    double rmax = 0, bmax = 0;
+    for (int r = 0; r < n; r++) {
+      double acc = 0;
+      for (int c = 0; c < n; c++) acc += (c <= r ? h[(size_t)r * npad + c] : h[(size_t)c * npad + r]) * zh[c];
+      rmax = std::max(rmax, std::fabs(acc - h[(size_t)n * npad + r]));
+      bmax = std::max(bmax, std::fabs(h[(size_t)n * npad + r]));
+    }
+    printf("mode %d residual max |S z - b| = %.3e (|b|max %.3e)\n", mode, rmax, bmax);
   }
-  return 0;
+  {
+    // cycle stamps of the last row owner (alive for every step): wait for the updated tiles, wait for L[t, t-1], operands
+    // in LDS, pivot chain, tail (X_3, stores, flag) - and the step period
+    const int nrtp = (n + 1 + 15) / 16, ncwp = std::max(1, (nrtp - 4 + 2) / 3);
+    int wgp = argc > 2 ? atoi(argv[2]) : ncwp - 1;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamp_wg), &wgp, sizeof(int));
+    hipMemcpy(M, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+    msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, nullptr, nullptr, ws);
+    hipDeviceSynchronize();
+    static long long st[256][8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_chain_stamp), sizeof st);
+    const int P = (n + 63) / 64;
+    printf("stamps of row owner %d: step | L wait (pivot wave) | helper at S1 (since step start) | S1 + syrk + S2 | pivots | X3 + hb put (h) | M stores (h) | period\n", wgp);
+    for (int l = 0; l < P && l < 256; l++)
+      printf("  %3d | %6lld | %6lld | %6lld | %6lld | %6lld | %6lld | %6lld\n", l, st[l][2] - st[l][0], st[l][5] - st[l][0], st[l][3] - st[l][2], st[l][4] - st[l][3],
+             st[l][6] - st[l][4], st[l][7] - st[l][6], l ? st[l][0] - st[l - 1][0] : 0);
+  }
+  // the factor: blocks below the diagonal blocks in M, the diagonal blocks and the 16 x 16 inverses in the workspace
+  size_t nd = 0; double dmax = 0;
+  for (int r = 0; r <= n; r++)
+    for (int c = 0; c < (r / 64) * 64 && c < n; c++) {
+      const double a = Mref[(size_t)r * npad + c], b = Mnew[(size_t)r * npad + c];
+      if (memcmp(&a, &b, 8)) { nd++; dmax = std::max(dmax, std::fabs(a - b)); }
+    }
+  size_t nw = 0;
+  for (size_t i = 0; i < (size_t)npad * 16; i++) nw += memcmp(&wk_ref[i], &wk_new[i], 8) != 0;
+  for (size_t i = (size_t)npad * 80; i < (size_t)npad * 144; i++) nw += memcmp(&wk_ref[i], &wk_new[i], 8) != 0;
+  size_t nz = 0;
+  for (int i = 0; i < n; i++) nz += memcmp(&zref[i], &znew[i], 8) != 0;
+  printf("factor: %zu entries differ (max %.3e); Dinv / Ldiag: %zu differ; solution: %zu differ\n", nd, dmax, nw, nz);
+  return (nd || nw || nz) ? 3 : 0;
 }

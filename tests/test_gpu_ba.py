@@ -497,3 +497,48 @@ def test_ba_small_angle_branch_cameras(ctx, oracle):
     r, _, a = check_parity(ctx, oracle, lambda: A.BaArrays.from_scene(sc), dict(max_num_iterations=6))
     assert r["iterations"]["cost"][-1] < r["iterations"]["cost"][0]
     assert np.abs(a.cam_pose[:5, :3]).max() > 1e-7             # the adjusted cameras have left the branch
+
+
+@pytest.mark.parametrize("domains", ["0", "1", "2"])
+def test_ba_persistent_panel_chain_is_bit_identical_to_the_launch_chain(ctx, monkeypatch, domains):
+    """Round 4: the panel chain of a tree level runs as ONE persistent launch (k_chain: row owners keep their rows in
+    registers from step to step, L[t, t-1] travels through a self-tagged hand-off buffer, bulk tiles by ticket).  Same
+    arithmetic in the same order as one launch per 64-column panel (MSFM_CHOL_LAUNCHES=1): every cost, gradient norm and
+    parameter of the trajectory is bit-identical - dense order, one bisection (2 leaves | root) and two (4 | 2 | root),
+    with GPS rows, and twice in a row on the same resident problem (the hand-off buffers alternate from solve to solve)."""
+    from metricsfm_amd import capi
+    sc = scene.make_aerial_scene(168, 6000, seed=5, gps_sigma=0.5)
+    kw = dict(gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams))
+    monkeypatch.setenv("MSFM_CHOL_DOMAINS", domains)
+    opts = capi.default_options(max_num_iterations=9)
+    out = {}
+    for mode in ("launches", "chain"):
+        if mode == "launches":
+            monkeypatch.setenv("MSFM_CHOL_LAUNCHES", "1")
+        else:
+            monkeypatch.delenv("MSFM_CHOL_LAUNCHES")
+        a = A.BaArrays.from_scene(sc, **kw)
+        r = ctx.ba_solve(a, opts)
+        out[mode] = (r, a)
+    (r0, a0), (r1, a1) = out["launches"], out["chain"]
+    assert r0["num_iterations"] == r1["num_iterations"] >= 5
+    for key in ("cost", "gradient_max_norm", "step_norm", "step_is_successful"):
+        np.testing.assert_array_equal(r0["iterations"][key], r1["iterations"][key])
+    for name in ("cam_pose", "cam_model", "point"):
+        np.testing.assert_array_equal(getattr(a0, name), getattr(a1, name))
+    # a resident problem solved twice: the second run starts from the first one's result and must agree with the launch chain too
+    res = {}
+    for mode in ("launches", "chain"):
+        if mode == "launches":
+            monkeypatch.setenv("MSFM_CHOL_LAUNCHES", "1")
+        else:
+            monkeypatch.delenv("MSFM_CHOL_LAUNCHES")
+        ba = ctx.ba(A.BaArrays.from_scene(sc, **kw))
+        ra = ba.run(capi.default_options(max_num_iterations=3))
+        rb = ba.run(capi.default_options(max_num_iterations=3))
+        res[mode] = (ra["iterations"]["cost"], rb["iterations"]["cost"], ba.download())
+        ba.close()
+    np.testing.assert_array_equal(res["launches"][0], res["chain"][0])
+    np.testing.assert_array_equal(res["launches"][1], res["chain"][1])
+    for x, y in zip(res["launches"][2], res["chain"][2]):
+        np.testing.assert_array_equal(x, y)
