@@ -660,9 +660,17 @@ __global__ __launch_bounds__(256) void k_panel_v2(double* __restrict__ M, int ld
 #ifdef MSFM_CHAIN_STAMPS
 __device__ long long g_chain_stamp[256][8];
 __device__ int g_chain_stamp_wg = 0;
-#define CSTAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x == g_chain_stamp_wg && l < 256) g_chain_stamp[l][i] = (long long)__builtin_readcyclecounter(); } while (0)
-#define CSTAMP_H(i) do { if (threadIdx.x == 64 && (int)blockIdx.x == g_chain_stamp_wg && l < 256) g_chain_stamp[l][i] = (long long)__builtin_readcyclecounter(); } while (0)
+__device__ int g_chain_stamp_jobs = 0;        // stamp only launches with this many jobs (0: all)
+__device__ volatile int g_chain_stamp_on = 0;
+__device__ long long g_chain_task_t[8192][4];   // per ticket: taken, counters there, products done / stored, published (wall clock, 10 ns)
+__device__ long long g_chain_row_t[256][2];     // per step of the stamped row owner: step start, pivots done (wall clock)
+#define BSTAMP(tk, i) do { if (threadIdx.x == 0 && g_chain_stamp_on && (tk) >= 0 && (tk) < 8192) g_chain_task_t[tk][i] = (long long)wall_clock64(); } while (0)
+#define RSTAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x == g_chain_stamp_wg && l < 256 && g_chain_stamp_on) g_chain_row_t[l][i] = (long long)wall_clock64(); } while (0)
+#define CSTAMP(i) do { if (threadIdx.x == 0 && (int)blockIdx.x == g_chain_stamp_wg && l < 256 && g_chain_stamp_on) g_chain_stamp[l][i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CSTAMP_H(i) do { if (threadIdx.x == 64 && (int)blockIdx.x == g_chain_stamp_wg && l < 256 && g_chain_stamp_on) g_chain_stamp[l][i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
+#define BSTAMP(tk, i) do {} while (0)
+#define RSTAMP(i) do {} while (0)
 #define CSTAMP(i) do {} while (0)
 #define CSTAMP_H(i) do {} while (0)
 #endif
@@ -680,6 +688,7 @@ struct ChainJobs {
   int count, n_row_wg, n_bulk_wg, n_steps;   // n_steps: entries of task_first / 8
   ChainJob job[8];
 };
+struct ChainTask { short l, k, I, J; };   // launch step, job, 64-row blocks behind the diagonal block of step l (I >= J >= 1)
 struct ChainCtl {
   unsigned* rowflag;          // [jobs][tiles]
   unsigned* tileflag;         // [nblk][nblk] by absolute 64-blocks of M
@@ -687,7 +696,8 @@ struct ChainCtl {
   unsigned long long* hb_next;
   int* ticket;                // this launch's counter (zero when the launch starts)
   int* ticket_next;           // zeroed here for the next launch
-  const int* task_first;      // [(n_steps + 1) * 8]: first ticket of (launch step l = 1 + i / 8, job i % 8)
+  const ChainTask* tasks;     // the launch's tiles in ticket order
+  int n_tasks;
   unsigned base;              // epoch << 12
   unsigned spin_limit;
   int nblk;                   // npad / 64
@@ -789,8 +799,9 @@ __device__ __forceinline__ double hb_safe(double v) {   // (no arithmetic produc
 //  * the next step's tiles of the diagonal block and of the own rows are fetched DURING the current step, at the start of a
 //    helper phase, once their counters (asked for one phase earlier, tested without waiting) say that the bulk workgroups
 //    are done with them; wave 1 also fetches tile (0, 0) for the pivot wave and hands it over through LDS;
-//  * the rows of the new panel go out without waiting; the counter that releases them to the bulk workgroups is written a
-//    step later, behind the first poll of the hand-off buffer (memory operations complete in issue order), or on exit.
+//  * the rows of the new panel go out sixteen columns at a time, each block in the helper phase in which it becomes final
+//    (only X_3 is left for the tail), and without waiting; the counter that releases them to the bulk workgroups is written
+//    behind the next step's poll of the hand-off buffer (an explicit s_waitcnt there costs nothing by then), or on exit.
 struct ChainWave {
   int b, at;        // workgroup of the job, the wave's row tile counted from the node's first row
   size_t r0;        // first row of that tile in M
@@ -809,6 +820,7 @@ __device__ __forceinline__ void chain_pivot_step(const ChainJob& jb, const Chain
   const int ncol = min(NB, n - t0);
   const int tb = t0 / NB;
   CSTAMP(0);
+  RSTAMP(0);
   if (upd) {
     d2 pv[8];
     hb_poll(cH, (size_t)tb, tid, 16 * min(4, jb.nrt - 4 * l), pv, ctl.spin_limit, fail, ctl.dbg, l);
@@ -838,6 +850,7 @@ __device__ __forceinline__ void chain_pivot_step(const ChainJob& jb, const Chain
   else potrf16_skip<3>(dinv, lane);
   __syncthreads();
   CSTAMP(4);
+  RSTAMP(1);
 }
 
 // what a helper wave carries from step to step
@@ -847,23 +860,55 @@ struct ChainCarry {
   bool have_next;         // ... are in the registers above
   unsigned fd, fo;        // the two counters they depend on, as last read
   bool polled;
-  int store_step;         // > 0: the rows of step store_step - 1 (in xr) have not been written to M yet
   int flag_step;          // > 0: rowflag[at] = base + flag_step is still to be written (the rows went out without waiting)
 };
-// a helper wave's rows of the panel of step `step` (in xr) to M - for the bulk tiles; nobody on the chain waits for them
-__device__ __forceinline__ void chain_store_rows(coh_buf cM, int ld, const ChainJob& jb, size_t r0, int step, const double (&xr)[16], int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  const size_t dst = (r0 + lr) * ld + jb.begin + NB * step;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const d2 lo = {xr[4 * q], xr[4 * q + 1]}, hi = {xr[4 * q + 2], xr[4 * q + 3]};
-    st_coh2(cM, dst + 16 * q + 4 * lk, lo);
-    st_coh2(cM, dst + 16 * q + 4 * lk + 2, hi);
+// Sixteen columns (block q) of a helper wave's rows of the new panel, the moment they are final: to M for the bulk tiles and,
+// when they are rows of the next diagonal block, to the hand-off buffer.  Spread over the helper phases (X_0 .. X_2 are final
+// one phase each before the step ends), only X_3 is left for the tail.
+__device__ __forceinline__ void chain_emit(coh_buf cM, coh_buf cH, int ld, size_t mrow, bool to_hb, size_t hrow, int q, d4 x, int lk) {
+  const d2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
+  if (to_hb) {
+    const d2 slo = {hb_safe(x[0]), hb_safe(x[1])}, shi = {hb_safe(x[2]), hb_safe(x[3])};
+    st_coh2(cH, hrow + 16 * q + 4 * lk, slo);
+    st_coh2(cH, hrow + 16 * q + 4 * lk + 2, shi);
   }
+  st_coh2(cM, mrow + 16 * q + 4 * lk, lo);
+  st_coh2(cM, mrow + 16 * q + 4 * lk + 2, hi);
 }
 __device__ __forceinline__ void chain_release_rows(const ChainJob& jb, const ChainCtl& ctl, int at, int flag_step, int lane) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have reached the coherence point before the counter moves
   if (lane == 0) __hip_atomic_store(&ctl.rowflag[jb.flag0 + at], ctl.base + (unsigned)flag_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The operands of step `lt` of a helper wave (its rows of column lt, its tiles of the diagonal block; wave 1: tile (0, 0) for
+// the pivot wave), fetched as soon as their counters allow, never waiting: a call either looks at the counters it asked for
+// in the call before and, if they are there, issues the loads - or asks for the counters again.
+__device__ __forceinline__ void chain_fetch_ahead(coh_buf cM, int ld, const ChainJob& jb, const ChainCtl& ctl, const ChainWave& W, int lt, ChainCarry& C) {
+  if (C.have_next || !chain_alive(jb, W.b, lt)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  const int t1 = jb.begin + NB * lt, tb1 = t1 / NB;
+  const bool own_n = W.at >= 4 * (lt + 1) && W.at < jb.nrt;
+  const unsigned need_n = lt >= 2 ? (unsigned)(lt - 1) : 0u;
+  const int ta = wave, tb2 = wave == 1 ? 2 : 3, tc = wave == 3 ? 3 : 2;
+  if (need_n == 0 || (C.polled && count_ready(C.fd, ctl.base, need_n) && (!own_n || count_ready(C.fo, ctl.base, need_n)))) {
+    if (own_n) {
+      const size_t src = (W.r0 + lr) * ld;
+#pragma unroll
+      for (int q = 0; q < 4; q++) C.Tn[q] = ld_coh4(cM, src + t1 + 16 * q + 4 * lk);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      C.Dn0[i] = ld_coh(cM, (size_t)(t1 + 16 * wave + lk + 4 * i) * ld + t1 + lr);
+      C.Dn1[i] = ld_coh(cM, (size_t)(t1 + 16 * ta + lk + 4 * i) * ld + t1 + 16 + lr);
+      C.Dn2[i] = ld_coh(cM, (size_t)(t1 + 16 * tb2 + lk + 4 * i) * ld + t1 + 16 * tc + lr);
+      if (wave == 1) C.Dn00[i] = ld_coh(cM, (size_t)(t1 + lk + 4 * i) * ld + t1 + lr);
+    }
+    C.have_next = true;
+  } else {
+    C.fd = __hip_atomic_load(&ctl.tileflag[(size_t)tb1 * ctl.nblk + tb1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    C.fo = own_n ? __hip_atomic_load(&ctl.tileflag[(size_t)(W.r0 / NB) * ctl.nblk + tb1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    C.polled = true;
+  }
 }
 
 template <bool FULL>
@@ -883,65 +928,30 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
   double* const pub_out = Dinv + (size_t)tb * 1024;
   const int plr = 4 * (lr & 3) + (lr >> 2);
   const int ta = wave, tb2 = wave == 1 ? 2 : 3, tc = wave == 3 ? 3 : 2;
+  const size_t mrow = (r0 + lr) * ld + t0;                                        // the lane's row of the new panel in M
+  const bool to_hb = own && at < 4 * (l + 2) && l + 1 < jb.P;                     // ... a row of the next diagonal block
+  const size_t hrow = (size_t)(tb + 1) * NB * NB + (size_t)(16 * (at & 3) + lr) * NB;
   d4 T[4], D0, D1, D2, D00;
-  if (C.have_next) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) T[q] = C.Tn[q];
-    D0 = C.Dn0; D1 = C.Dn1; D2 = C.Dn2; D00 = C.Dn00;
-  } else {
-    // not fetched ahead (first step; or the bulk workgroups were late): wait for the counters here
+  // this step's operands: fetched during the step before; or now, under the poll below, when their counters (asked for at the
+  // end of the step before) have arrived since; or, failing that, behind a wait
+  chain_fetch_ahead(cM, ld, jb, ctl, W, l, C);
+  d2 pv[8];
+  if (upd) hb_poll(cH, (size_t)tb, tid, 16 * min(4, jb.nrt - 4 * l), pv, ctl.spin_limit, fail, ctl.dbg, l);
+  if (C.flag_step > 0) { chain_release_rows(jb, ctl, at, C.flag_step, lane); C.flag_step = 0; }   // the rows of the step before are out
+  if (upd) p0_store(Bs, tid, pv);
+  if (!C.have_next) {
     const unsigned need = l >= 2 ? (unsigned)(l - 1) : 0u;
     if (need) wait_count(&ctl.tileflag[(size_t)tb * ctl.nblk + tb], ctl.base, need, ctl.spin_limit, fail, ctl.dbg, 1, l, tb * ctl.nblk + tb);
-    if (own) {
-      if (need) wait_count(&ctl.tileflag[(size_t)(r0 / NB) * ctl.nblk + tb], ctl.base, need, ctl.spin_limit, fail, ctl.dbg, 2, l, (int)(r0 / NB) * ctl.nblk + tb);
-      const size_t src = (r0 + lr) * ld;
-#pragma unroll
-      for (int q = 0; q < 4; q++) T[q] = ld_coh4(cM, src + t0 + 16 * q + 4 * lk);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      D0[i] = ld_coh(cM, (size_t)(t0 + 16 * wave + lk + 4 * i) * ld + t0 + lr);
-      D1[i] = ld_coh(cM, (size_t)(t0 + 16 * ta + lk + 4 * i) * ld + t0 + 16 + lr);
-      D2[i] = ld_coh(cM, (size_t)(t0 + 16 * tb2 + lk + 4 * i) * ld + t0 + 16 * tc + lr);
-      if (wave == 1) D00[i] = ld_coh(cM, (size_t)(t0 + lk + 4 * i) * ld + t0 + lr);
-    }
+    if (own && need) wait_count(&ctl.tileflag[(size_t)(r0 / NB) * ctl.nblk + tb], ctl.base, need, ctl.spin_limit, fail, ctl.dbg, 2, l, (int)(r0 / NB) * ctl.nblk + tb);
+    C.polled = true; C.fd = C.fo = ctl.base + 4095u;   // (the counters are there now)
+    chain_fetch_ahead(cM, ld, jb, ctl, W, l, C);
   }
+#pragma unroll
+  for (int q = 0; q < 4; q++) T[q] = C.Tn[q];
+  D0 = C.Dn0; D1 = C.Dn1; D2 = C.Dn2; D00 = C.Dn00;
   C.have_next = false;
   C.polled = false;
-  // next step's operands: which, and behind which counters
-  const bool want_next = chain_alive(jb, W.b, l + 1);
-  const bool own_n = at >= 4 * (l + 2) && at < jb.nrt;
-  const unsigned need_n = l + 1 >= 2 ? (unsigned)l : 0u;
-  const int t1 = t0 + NB;
-  const unsigned* const fdp = &ctl.tileflag[(size_t)(tb + 1) * ctl.nblk + tb + 1];
-  const unsigned* const fop = &ctl.tileflag[(size_t)(r0 / NB) * ctl.nblk + tb + 1];
-  auto fetch_ahead = [&]() {
-    if (!want_next || C.have_next) return;
-    if (need_n == 0 || (C.polled && count_ready(C.fd, ctl.base, need_n) && (!own_n || count_ready(C.fo, ctl.base, need_n)))) {
-      if (own_n) {
-        const size_t src = (r0 + lr) * ld;
-#pragma unroll
-        for (int q = 0; q < 4; q++) C.Tn[q] = ld_coh4(cM, src + t1 + 16 * q + 4 * lk);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        C.Dn0[i] = ld_coh(cM, (size_t)(t1 + 16 * wave + lk + 4 * i) * ld + t1 + lr);
-        C.Dn1[i] = ld_coh(cM, (size_t)(t1 + 16 * ta + lk + 4 * i) * ld + t1 + 16 + lr);
-        C.Dn2[i] = ld_coh(cM, (size_t)(t1 + 16 * tb2 + lk + 4 * i) * ld + t1 + 16 * tc + lr);
-        if (wave == 1) C.Dn00[i] = ld_coh(cM, (size_t)(t1 + lk + 4 * i) * ld + t1 + lr);
-      }
-      C.have_next = true;
-    } else {
-      C.fd = __hip_atomic_load(fdp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      C.fo = own_n ? __hip_atomic_load(fop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      C.polled = true;
-    }
-  };
-  if (upd) {
-    d2 pv[8];
-    hb_poll(cH, (size_t)tb, tid, 16 * min(4, jb.nrt - 4 * l), pv, ctl.spin_limit, fail, ctl.dbg, l);
-    p0_store(Bs, tid, pv);
-  }
+  auto fetch_ahead = [&]() { chain_fetch_ahead(cM, ld, jb, ctl, W, l + 1, C); };
   if (wave == 1) {
 #pragma unroll
     for (int i = 0; i < 4; i++) d00s[4 * lane + i] = D00[i];
@@ -955,11 +965,6 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
   __syncthreads();   // S2
   d4 X[4];
   // ---- B0 ----
-  if (C.store_step > 0) {   // the rows of the previous step, now that nobody on the chain waits for this wave
-    chain_store_rows(cM, ld, jb, r0, C.store_step - 1, C.xr, lane);
-    C.flag_step = C.store_step;
-    C.store_step = 0;
-  }
   fetch_ahead();
   if (upd) D1 = mm_nt_neg<16>(Bs, 16 * ta, Bs, 16, 0, lr, lk, D1);
   tile_st(Ls, ta, 1, lr, lk, D1);
@@ -972,7 +977,6 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
   tile_st(Ls, ta, 1, lr, lk, mm_nt_neg<4>(Ls, 16 * ta, Ls, 16, 0, lr, lk, tile_ld(Ls, ta, 1, lr, lk)));
   __syncthreads();
   // ---- B1 ----
-  if (C.flag_step > 0) { chain_release_rows(jb, ctl, at, C.flag_step, lane); C.flag_step = 0; }
   fetch_ahead();
   if (upd) D2 = mm_nt_neg<16>(Bs, 16 * tb2, Bs, 16 * tc, 0, lr, lk, D2);
   D2 = mm_nt_neg<4>(Ls, 16 * tb2, Ls, 16 * tc, 0, lr, lk, D2);
@@ -982,6 +986,7 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
 #pragma unroll
     for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[plr * DV + 4 * lk + s], T[0][s], Y, 0, 0, 0);
     X[0] = Y;
+    chain_emit(cM, cH, ld, mrow, to_hb, hrow, 0, Y, lk);
     if (upd) {
 #pragma unroll
       for (int s = 0; s < 16; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(16 + plr) * LDT + MSFM_KC(s)], C.xr[s], T[1], 0, 0, 0);
@@ -1002,6 +1007,7 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
 #pragma unroll
     for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(16 + plr) * DV + 4 * lk + s], T[1][s], Y, 0, 0, 0);
     X[1] = Y;
+    chain_emit(cM, cH, ld, mrow, to_hb, hrow, 1, Y, lk);
     if (upd) {
 #pragma unroll
       for (int s = 0; s < 16; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(32 + plr) * LDT + MSFM_KC(s)], C.xr[s], T[2], 0, 0, 0);
@@ -1023,6 +1029,7 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
 #pragma unroll
     for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(32 + plr) * DV + 4 * lk + s], T[2][s], Y, 0, 0, 0);
     X[2] = Y;
+    chain_emit(cM, cH, ld, mrow, to_hb, hrow, 2, Y, lk);
     if (upd) {
 #pragma unroll
       for (int s = 0; s < 16; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[(48 + plr) * LDT + MSFM_KC(s)], C.xr[s], T[3], 0, 0, 0);
@@ -1041,22 +1048,15 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
 #pragma unroll
     for (int s = 0; s < 4; s++) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[(48 + plr) * DV + 4 * lk + s], T[3][s], Y, 0, 0, 0);
     X[3] = Y;
-    if (at < 4 * (l + 2) && l + 1 < jb.P) {
-      const size_t hrow = (size_t)(tb + 1) * NB * NB + (size_t)(16 * (at & 3) + lr) * NB;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const d2 lo = {hb_safe(X[q][0]), hb_safe(X[q][1])}, hi = {hb_safe(X[q][2]), hb_safe(X[q][3])};
-        st_coh2(cH, hrow + 16 * q + 4 * lk, lo);
-        st_coh2(cH, hrow + 16 * q + 4 * lk + 2, hi);
-      }
-    }
+    chain_emit(cM, cH, ld, mrow, to_hb, hrow, 3, Y, lk);   // the last sixteen columns: everybody's next step waits for them
     CSTAMP_H(6);
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
       for (int j = 0; j < 4; j++) C.xr[4 * q + j] = X[q][j];
-    C.store_step = l + 1;   // to M during the next step (or on exit)
+    C.flag_step = l + 1;   // released behind the next poll (or on exit)
   }
+  fetch_ahead();
   CSTAMP_H(7);
 #undef MSFM_KC
   if (is_pub) {
@@ -1071,11 +1071,187 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
   }
 }
 
+// Bulk workgroup (and every row owner after its last step): 64 x 64 tiles of the trailing updates, taken by ticket from a
+// list the host has put in PRIORITY order (chain_build): tile (I, J) of launch step l - "apply the panel of step l - 1" -
+// has the key 0.4 l + 0.6 J, so the tiles of the column right behind the diagonal block (what the next step's row owners
+// wait for) come before the far columns of the step before, and a far tile receives its panels a little later, in order.
+// The key grows by less than 1 per step for one tile and every task's inputs have smaller keys: the list is a linear
+// extension of the dependencies, whoever holds the lowest open ticket can always finish.
+// The loop keeps the next tile's operands in flight under the products of the current one: the next ticket and its counters
+// are asked for before the MFMAs and looked at after them; a tile that is not urgent publishes its counter one task later
+// (when the next task's loads have come back, memory operations of a wave completing in issue order, its own stores are out).
+__device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, int ld, int* fail, const ChainJobs& jobs, const ChainCtl& ctl, double* As,
+                                           double* Bs, int* task, int bi) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (bi >= 0) {
+    // the other hand-off buffer becomes "pending" for the blocks of this launch; the next launch's ticket counter zero
+    for (int k = 0; k < jobs.count; k++) {
+      unsigned long long* dst = ctl.hb_next + (size_t)(jobs.job[k].begin / NB) * NB * NB;
+      const size_t cnt = (size_t)jobs.job[k].P * NB * NB;
+      for (size_t e = (size_t)bi * 256 + tid; e < cnt; e += (size_t)jobs.n_bulk_wg * 256) dst[e] = MSFM_Z_PENDING;
+    }
+    if (bi == 0 && tid == 0) *ctl.ticket_next = 0;
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;
+  const int total = ctl.n_tasks;
+  int* const tkt = task + 13;   // the tickets of the three slots (stamps only)
+  struct Tile { int l, ri, rj, j0, urgent, flag0, ti, tj, nrt, tk; };
+  auto take = [&](int slot) {   // thread 0: next ticket -> task[slot * 4 ..]
+    const int t = atomicAdd(ctl.ticket, 1);
+    ChainTask q = {-1, 0, 0, 0};
+    if (t < total) q = ctl.tasks[t];
+    task[4 * slot] = q.l; task[4 * slot + 1] = q.k; task[4 * slot + 2] = q.I; task[4 * slot + 3] = q.J;
+    tkt[slot] = t;
+    BSTAMP(t < total ? t : -1, 0);
+  };
+  auto decode = [&](int slot, Tile& T) {
+    T.l = task[4 * slot];
+    T.tk = tkt[slot];
+    if (T.l < 0) return;
+    const ChainJob& jb = jobs.job[task[4 * slot + 1]];
+    T.ti = 4 * (task[4 * slot + 2] + T.l); T.tj = 4 * (task[4 * slot + 3] + T.l);
+    T.ri = chain_row16(jb, T.ti); T.rj = chain_row16(jb, T.tj);
+    T.j0 = jb.begin + NB * (T.l - 1);
+    T.urgent = task[4 * slot + 3] == 1;
+    T.flag0 = jb.flag0; T.nrt = jb.nrt;
+  };
+  // the counters a tile waits for: the eight row tiles of its panel (lanes 0..7 of wave 0) and its own history (lane 8)
+  auto flag_ptr = [&](const Tile& T, unsigned& need) -> const unsigned* {
+    need = 0u;
+    if (lane < 8) {
+      const int tt = (lane < 4 ? T.ti : T.tj) + (lane & 3);
+      if (tt < T.nrt) { need = (unsigned)T.l; return &ctl.rowflag[T.flag0 + tt]; }
+    } else if (lane == 8 && T.l >= 2) {
+      need = (unsigned)(T.l - 1);
+      return &ctl.tileflag[(size_t)(T.ri / NB) * ctl.nblk + T.rj / NB];
+    }
+    return nullptr;
+  };
+  d2 va[8], vb[8];
+  d4 c00, c01, c10, c11;
+  auto fetch = [&](const Tile& T) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+      va[it] = ld_coh2(cM, (size_t)(T.ri + r) * ld + T.j0 + c2);
+      vb[it] = ld_coh2(cM, (size_t)(T.rj + r) * ld + T.j0 + c2);
+    }
+    const size_t C = (size_t)T.ri * ld + T.rj;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
+      const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
+      c00[i] = ld_coh(cM, p0); c01[i] = ld_coh(cM, p0 + 16); c10[i] = ld_coh(cM, p1); c11[i] = ld_coh(cM, p1 + 16);
+    }
+  };
+  auto wait_flags = [&](const Tile& T) {   // wave 0, blocking
+    unsigned need;
+    const unsigned* f = flag_ptr(T, need);
+    if (f) wait_count(f, ctl.base, need, ctl.spin_limit, fail, ctl.dbg, lane < 8 ? 4 : 5, T.l, lane);
+  };
+  // Three tasks in flight: `cur` (operands in registers, then in LDS under the products), `nxt` (known; its counters asked
+  // for a round earlier; fetched under cur's products when they are there) and `nn` (ticket taken, counters asked for).
+  Tile cur, nxt, nn;
+  int pending = -1, pending_l = 0;   // (thread 0) tileflag index whose counter is still to be written
+  unsigned fneed = 0u, fval = 0u;    // (wave 0) the counter of nxt this lane looks at, as read a round ago
+  const unsigned* fp = nullptr;
+  auto ask = [&](const Tile& T) {     // wave 0: read the lane's counter of T without waiting for it
+    fp = nullptr; fneed = 0u; fval = 0u;
+    if (T.l >= 0) {
+      fp = flag_ptr(T, fneed);
+      if (fp) fval = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  if (tid == 0) { take(0); take(1); }
+  __syncthreads();
+  decode(0, cur);
+  decode(1, nxt);
+  if (cur.l < 0) return;
+  if (wave == 0) { wait_flags(cur); ask(nxt); }
+  __syncthreads();
+  BSTAMP(cur.tk, 1);
+  fetch(cur);
+  for (;;) {
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
+      As[r * LDT + c2] = -va[it].x;
+      As[r * LDT + c2 + 1] = -va[it].y;
+      Bs[r * LDT + c2] = vb[it].x;
+      Bs[r * LDT + c2 + 1] = vb[it].y;
+    }
+    d4 a00 = c00, a01 = c01, a10 = c10, a11 = c11;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's loads are back; so are its stores of the tile before
+    if (wave == 0) {
+      const bool ok = nxt.l < 0 || !fp || count_ready(fval, ctl.base, fneed);
+      const bool all = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+      if (lane == 0) {
+        task[12] = all ? 1 : 0;
+        // a third ticket only when the second one can go ahead: a workgroup that is going to wait for its next tile must not
+        // sit on another one meanwhile (-2: not taken yet)
+        if (all && nxt.l >= 0) take(2); else task[8] = nxt.l >= 0 ? -2 : -1;
+      }
+    }
+    __syncthreads();   // B1: the operands are in LDS; the stores of the tile before are out (every wave waited above)
+    if (tid == 0 && pending >= 0) {
+      __hip_atomic_store(&ctl.tileflag[pending], ctl.base + (unsigned)pending_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pending = -1;
+    }
+    const bool ready = task[12] != 0 && nxt.l >= 0;
+    if (ready) { fetch(nxt); BSTAMP(nxt.tk, 1); }   // in flight under the products below
+    decode(2, nn);
+    if (wave == 0 && nn.l >= 0) ask(nn);
+    quad_abt(As, Bs, wr, wc, lr, lk, a00, a01, a10, a11);
+    {
+      const size_t C = (size_t)cur.ri * ld + cur.rj;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
+        const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
+        st_coh(cM, p0, a00[i]); st_coh(cM, p0 + 16, a01[i]); st_coh(cM, p1, a10[i]); st_coh(cM, p1 + 16, a11[i]);
+      }
+    }
+    const bool last = nxt.l < 0;
+    if (cur.urgent || last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's row owners wait for this tile
+    __syncthreads();   // B2: every wave's part of the tile is issued (urgent: out); everybody is done with As / Bs and task[]
+    BSTAMP(cur.tk, 2);
+    if (tid == 0) {
+      const int fi = (cur.ri / NB) * ctl.nblk + cur.rj / NB;
+      if (cur.urgent || last) __hip_atomic_store(&ctl.tileflag[fi], ctl.base + (unsigned)cur.l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else { pending = fi; pending_l = cur.l; }
+    }
+    if (last) break;
+    if (!ready) {   // (uniform) the counters were not there a round ago: wait for them now
+      // ... but never with a counter of our own unpublished: what nxt waits for may hang on it (the same tile a step later)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0 && pending >= 0) {
+        __hip_atomic_store(&ctl.tileflag[pending], ctl.base + (unsigned)pending_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = -1;
+      }
+      if (wave == 0) wait_flags(nxt);
+      __syncthreads();
+      BSTAMP(nxt.tk, 1);
+      fetch(nxt);
+    }
+    cur = nxt;
+    if (nn.l == -2) {   // the third ticket, now that the second one is on its way
+      if (tid == 0) take(2);
+      __syncthreads();
+      decode(2, nn);
+      if (wave == 0) ask(nn);
+    }
+    nxt = nn;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, int n, double* __restrict__ Dinv, double* __restrict__ Ldiag,
                                                 int* fail, ChainJobs jobs, ChainCtl ctl) {
   __shared__ double sm[80 + 64 * DV + 2 * 64 * LDT];
   __shared__ double d00s[256];
-  __shared__ int task[8];
+  __shared__ int task[16];
   double* As = sm + 80 + 64 * DV;
   double* Bs = As + 64 * LDT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1088,6 +1264,9 @@ __global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, i
       if ((int)blockIdx.x >= jobs.job[k].wg0) ji = k;
     const ChainJob& jb = jobs.job[ji];
     const int b = blockIdx.x - jb.wg0;
+#ifdef MSFM_CHAIN_STAMPS
+    if (tid == 0 && (int)blockIdx.x == g_chain_stamp_wg) g_chain_stamp_on = g_chain_stamp_jobs == 0 || jobs.count == g_chain_stamp_jobs;
+#endif
     if (wave == 0) {
       for (int l = 0; chain_alive(jb, b, l); l++) {
         if (n - (jb.begin + NB * l) >= NB) chain_pivot_step<true>(jb, ctl, cH, l, n, fail, Bs, As, sm + 80, sm, d00s);
@@ -1101,102 +1280,20 @@ __global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, i
       ChainCarry C;
 #pragma unroll
       for (int i = 0; i < 16; i++) C.xr[i] = 0.0;
-      C.have_next = false; C.polled = false; C.fd = C.fo = 0u; C.flag_step = 0; C.store_step = 0;
+      C.have_next = false; C.polled = false; C.fd = C.fo = 0u; C.flag_step = 0;
       for (int l = 0; chain_alive(jb, b, l); l++) {
         if (n - (jb.begin + NB * l) >= NB) chain_helper_step<true>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C);
         else chain_helper_step<false>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C);
       }
-      if (C.store_step > 0) { chain_store_rows(cM, ld, jb, W.r0, C.store_step - 1, C.xr, lane); C.flag_step = C.store_step; }
       if (C.flag_step > 0) chain_release_rows(jb, ctl, W.at, C.flag_step, lane);
     }
+    // a row owner whose rows have all passed the diagonal takes bulk tiles for the rest of the launch
+    __syncthreads();
+    chain_bulk(M, cM, ld, fail, jobs, ctl, As, Bs, task, -1);
     return;
   }
   // ---------------- bulk: tiles of the trailing updates, by ticket ----------------
-  const int bi = blockIdx.x - jobs.n_row_wg;
-  {
-    // the other hand-off buffer becomes "pending" for the blocks of this launch; the next launch's ticket counter zero
-    for (int k = 0; k < jobs.count; k++) {
-      unsigned long long* dst = ctl.hb_next + (size_t)(jobs.job[k].begin / NB) * NB * NB;
-      const size_t cnt = (size_t)jobs.job[k].P * NB * NB;
-      for (size_t e = (size_t)bi * 256 + tid; e < cnt; e += (size_t)jobs.n_bulk_wg * 256) dst[e] = MSFM_Z_PENDING;
-    }
-    if (bi == 0 && tid == 0) *ctl.ticket_next = 0;
-  }
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-  const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;
-  const int total = ctl.task_first[jobs.n_steps * 8];
-  int cur = 0;   // (thread 0) position in task_first
-  for (;;) {
-    if (tid == 0) {
-      const int t = atomicAdd(ctl.ticket, 1);
-      int l = -1, k = 0, I = 0, J = 0;
-      if (t < total) {
-        while (t >= ctl.task_first[cur + 1]) cur++;
-        l = 1 + cur / 8; k = cur % 8;
-        int q = t - ctl.task_first[cur];
-        const ChainJob& jb = jobs.job[k];
-        const int nA = jb.nA64 - l;                    // 64-row blocks of range A from the diagonal block on
-        // column-major over the columns 1 .. nA - 1 behind the diagonal block: the rows of A from the column on, then range B
-        J = 1;
-        for (;;) { const int c = nA - J + jb.nB64; if (q < c) break; q -= c; J++; }
-        I = q < nA - J ? J + q : nA + (q - (nA - J));
-      }
-      task[0] = l; task[1] = k; task[2] = I; task[3] = J;
-    }
-    __syncthreads();
-    const int l = task[0], k = task[1], I = task[2], J = task[3];
-    if (l < 0) break;
-    const ChainJob& jb = jobs.job[k];
-    const int j0 = jb.begin + NB * (l - 1);             // the panel to apply
-    const int ti = 4 * (I + l), tj = 4 * (J + l);      // first row tiles of the two 64-row blocks, counted from the node's first row
-    const int ri = chain_row16(jb, ti), rj = chain_row16(jb, tj);
-    const size_t C = (size_t)ri * ld + rj;
-    if (wave == 0) {
-      // the eight row tiles of the panel, and the tile's own history
-      if (lane < 8) {
-        const int tt = (lane < 4 ? ti : tj) + (lane & 3);
-        if (tt < jb.nrt) wait_count(&ctl.rowflag[jb.flag0 + tt], ctl.base, (unsigned)l, ctl.spin_limit, fail, ctl.dbg, 4, l, tt);
-      } else if (lane == 8 && l >= 2) {
-        wait_count(&ctl.tileflag[(size_t)(ri / NB) * ctl.nblk + rj / NB], ctl.base, (unsigned)(l - 1), ctl.spin_limit, fail, ctl.dbg, 5, l, (ri / NB) * ctl.nblk + rj / NB);
-      }
-    }
-    __syncthreads();
-    d4 c00, c01, c10, c11;
-    d2 va[8], vb[8];
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
-      va[it] = ld_coh2(cM, (size_t)(ri + r) * ld + j0 + c2);
-      vb[it] = ld_coh2(cM, (size_t)(rj + r) * ld + j0 + c2);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
-      const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
-      c00[i] = ld_coh(cM, p0); c01[i] = ld_coh(cM, p0 + 16); c10[i] = ld_coh(cM, p1); c11[i] = ld_coh(cM, p1 + 16);
-    }
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int e = tid + 256 * it, r = e >> 5, c2 = (e & 31) * 2;
-      As[r * LDT + c2] = -va[it].x;
-      As[r * LDT + c2 + 1] = -va[it].y;
-      Bs[r * LDT + c2] = vb[it].x;
-      Bs[r * LDT + c2 + 1] = vb[it].y;
-    }
-    __syncthreads();
-    quad_abt(As, Bs, wr, wc, lr, lk, c00, c01, c10, c11);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
-      const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
-      st_coh(cM, p0, c00[i]); st_coh(cM, p0 + 16, c01[i]); st_coh(cM, p1, c10[i]); st_coh(cM, p1 + 16, c11[i]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // every wave's part of the tile is out (and everybody is done with As / Bs and task[])
-    if (tid == 0)
-      __hip_atomic_store(&ctl.tileflag[(size_t)(ri / NB) * ctl.nblk + rj / NB], ctl.base + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  chain_bulk(M, cM, ld, fail, jobs, ctl, As, Bs, task, (int)blockIdx.x - jobs.n_row_wg);
 }
 
 // The separator x separator part of the domain chains' trailing updates, all at once:  corner_r[I][J] = -sum_p X_I,p X_J,p^T
@@ -1683,7 +1780,7 @@ int msfm_chol_fill_pending(msfm_ctx* ctx, double* z, int npad) {
 // ---- host side of the persistent chain ----
 struct ChainLaunch {
   ChainJobs jobs;
-  int task_off = 0;     // first entry of the launch's table in ws->task_first
+  int task_off = 0, n_tasks = 0;   // the launch's tiles in ws->tasks
   int steps = 0;        // panel steps on its critical path (for the timers)
   bool usable = false;
 };
@@ -1693,7 +1790,7 @@ struct msfm_chol_ws {
   DevBuf<unsigned> flags;     // rowflag [8][npad / 16], then tileflag [(npad / 64)^2]
   DevBuf<double> hb;          // two hand-off buffers of npad x 64
   DevBuf<int> tickets;        // [8]
-  DevBuf<int> task_first;
+  DevBuf<ChainTask> tasks;
   unsigned epoch = 0, n_launch = 0, flag_epoch = 0;   // solves (hand-off buffer parity), launches (ticket slot), launches (counter tag)
   bool dirty = true;          // the hand-off buffers and tickets must be (re)initialised before the next use
   // launches of the plan they were built for (levels in order, then the root chain)
@@ -1731,7 +1828,7 @@ static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
   }
   if (sig == ws->sig && !ws->launch.empty()) return MSFM_OK;
   ws->launch.clear();
-  std::vector<int> table;
+  std::vector<ChainTask> table;
   const int root_begin = n_levels ? plan->level[n_levels - 1].b0 : 0;
   const int nt16 = ws->npad / 16;
   for (int lv = 0; lv <= n_levels; lv++) {
@@ -1781,20 +1878,29 @@ static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
     J.n_steps = std::max(0, maxp - 1);
     L.steps = maxp;
     L.task_off = (int)table.size();
-    int t = 0, max_step_tasks = 0;
-    for (int l = 1; l <= J.n_steps; l++) {
-      int step_tasks = 0;
-      for (int k = 0; k < 8; k++) {
-        table.push_back(t);
-        if (k < J.count && l < J.job[k].P) {
-          const int nA = J.job[k].nA64 - l;
-          const int c = nA * (nA - 1) / 2 + J.job[k].nB64 * (nA - 1);
-          t += c; step_tasks += c;
+    int max_step_tasks = 0;
+    {
+      // every tile of every launch step, in priority order: key = l + 0.6 (J - 1) (see chain_bulk)
+      struct Keyed { int key; ChainTask t; };
+      std::vector<Keyed> lt;
+      static const int slope = getenv("MSFM_CHAIN_SLOPE") ? std::max(0, std::min(9, atoi(getenv("MSFM_CHAIN_SLOPE")))) : 6;   // tenths; 0: step by step
+      for (int l = 1; l <= J.n_steps; l++) {
+        int step_tasks = 0;
+        for (int k = 0; k < J.count; k++) {
+          if (l >= J.job[k].P) continue;
+          const int nA = J.job[k].nA64 - l, nB = J.job[k].nB64;
+          for (int Jc = 1; Jc < nA; Jc++)
+            for (int I = Jc; I < nA + nB; I++) {
+              lt.push_back(Keyed{10 * l + slope * (Jc - 1), ChainTask{(short)l, (short)k, (short)I, (short)Jc}});
+              step_tasks++;
+            }
         }
+        max_step_tasks = std::max(max_step_tasks, step_tasks);
       }
-      max_step_tasks = std::max(max_step_tasks, step_tasks);
+      std::stable_sort(lt.begin(), lt.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+      for (const Keyed& q : lt) table.push_back(q.t);
+      L.n_tasks = (int)lt.size();
     }
-    table.push_back(t);
     // bulk workgroups: what the device holds beside the row owners, at most one per tile of the busiest step
     const int room = ws->capacity - wg;
     J.n_bulk_wg = std::max(1, std::min(room, max_step_tasks));
@@ -1804,8 +1910,8 @@ static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
     L.usable = J.count > 0 && wg <= ws->capacity / 2 && (max_step_tasks == 0 || 3 * room >= max_step_tasks || force) && maxp < 4000;
     ws->launch.push_back(L);
   }
-  HIP_TRY(ctx, ws->task_first.alloc(std::max<size_t>(1, table.size())));
-  HIP_TRY(ctx, hipMemcpyAsync(ws->task_first.p, table.data(), sizeof(int) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, ws->tasks.alloc(std::max<size_t>(1, table.size())));
+  HIP_TRY(ctx, hipMemcpyAsync(ws->tasks.p, table.data(), sizeof(ChainTask) * table.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (the host table goes away on return; built once per plan)
   ws->sig = sig;
   return MSFM_OK;
@@ -1832,7 +1938,8 @@ static int chain_launch(msfm_chol_ws* ws, const ChainLaunch& L, double* M, int n
   const unsigned slot = ws->n_launch++ & 7u;
   c.ticket = ws->tickets.p + slot;
   c.ticket_next = ws->tickets.p + ((slot + 1) & 7u);
-  c.task_first = ws->task_first.p + L.task_off;
+  c.tasks = ws->tasks.p + L.task_off;
+  c.n_tasks = L.n_tasks;
   c.base = (++ws->flag_epoch & 0xFFFFFu) << 12;   // per LAUNCH: the launches of one solve reuse the rowflag slots of their jobs
   c.spin_limit = chain_spin_limit();
   c.nblk = (int)nb;

@@ -28,10 +28,33 @@ int main(int argc, char** argv) {
   std::vector<double> h((size_t)npad * npad, 0.0);
   std::mt19937_64 g(7);
   std::uniform_real_distribution<double> U(-1, 1);
-  (void)K;   // (dense order only: the multilevel plans are exercised through msfm_ba_*)
+  (void)K;
+  // argv[3] = "plan": config 3's elimination tree (4 leaves of 5 / 10 / 8 / 10 blocks | 2 separators of 4 | root), n = 2624 + root
+  const bool with_plan = argc > 3 && !strcmp(argv[3], "plan");
+  msfm_chol_plan plan;
+  std::vector<int> node_of(n + 1, 6);   // 0..3 leaves, 4..5 separators, 6 root
+  if (with_plan) {
+    const int lb[5] = {0, 320, 960, 1472, 2112}, sb[3] = {2112, 2368, 2624};
+    if (n <= 2624) { printf("plan needs n > 2624\n"); return 1; }
+    plan.n_levels = 2;
+    plan.level[0].K = 4; plan.level[0].begin = 0; plan.level[0].b0 = 2112;
+    for (int k = 0; k < 4; k++) plan.level[0].node[k] = msfm_chol_node{lb[k], lb[k + 1], k, k};
+    plan.level[1].K = 2; plan.level[1].begin = 2112; plan.level[1].b0 = 2624;
+    for (int k = 0; k < 2; k++) plan.level[1].node[k] = msfm_chol_node{sb[k], sb[k + 1], 2 * k, 2 * k + 1};
+    for (int c = 0; c < n; c++) { int nd = 6; for (int k = 0; k < 4; k++) if (c >= lb[k] && c < lb[k + 1]) nd = k; for (int k = 0; k < 2; k++) if (c >= sb[k] && c < sb[k + 1]) nd = 4 + k; node_of[c] = nd; }
+    plan.ldc = 64 * ((n + 1 - 2112 + 63) / 64);
+    hipMalloc(&plan.corners, sizeof(double) * 8 * (size_t)plan.ldc * plan.ldc);
+  }
+  auto coupled = [&](int r, int c) {   // r > c: a leaf couples to itself, its separator and the root; a separator to itself and the root
+    if (!with_plan) return true;
+    const int a = node_of[r], b = node_of[c];
+    if (a == b || a == 6) return true;
+    if (a >= 4 && b < 4) return b / 2 == a - 4;
+    return false;
+  };
   for (int r = 0; r < n; r++) {
     for (int c = 0; c < r; c++) {
-      h[(size_t)r * npad + c] = U(g);
+      h[(size_t)r * npad + c] = coupled(r, c) ? U(g) : 0.0;
     }
     h[(size_t)r * npad + r] = n + 1.0;
   }
@@ -54,7 +77,7 @@ int main(int argc, char** argv) {
       hipMemset(fail, 0, 16);
       hipDeviceSynchronize();
       hipEventRecord(e0, ctx->stream);
-      int rc = msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, nullptr, nullptr, mode ? ws : nullptr);
+      int rc = msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, with_plan ? &plan : nullptr, nullptr, mode ? ws : nullptr);
       hipEventRecord(e1, ctx->stream);
       hipDeviceSynchronize();
       float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -87,18 +110,43 @@ int main(int argc, char** argv) {
     // cycle stamps of the last row owner (alive for every step): wait for the updated tiles, wait for L[t, t-1], operands
     // in LDS, pivot chain, tail (X_3, stores, flag) - and the step period
     const int nrtp = (n + 1 + 15) / 16, ncwp = std::max(1, (nrtp - 4 + 2) / 3);
-    int wgp = argc > 2 ? atoi(argv[2]) : ncwp - 1;
+    int wgp = argc > 2 && atoi(argv[2]) >= 0 ? atoi(argv[2]) : ncwp - 1;
     hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamp_wg), &wgp, sizeof(int));
+    const int sj = argc > 4 ? atoi(argv[4]) : 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamp_jobs), &sj, sizeof(int));
     hipMemcpy(M, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
-    msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, nullptr, nullptr, ws);
+    msfm_chol_factor_solve(ctx, M, npad, n, work, w, z, fail, with_plan ? &plan : nullptr, nullptr, ws);
     hipDeviceSynchronize();
     static long long st[256][8];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_chain_stamp), sizeof st);
-    const int P = (n + 63) / 64;
+    const int P = with_plan ? 10 : (n + 63) / 64;   // (with the plan the stamps are those of the last launch that reached the stamped workgroup index)
     printf("stamps of row owner %d: step | L wait (pivot wave) | helper at S1 (since step start) | S1 + syrk + S2 | pivots | X3 + hb put (h) | M stores (h) | period\n", wgp);
     for (int l = 0; l < P && l < 256; l++)
       printf("  %3d | %6lld | %6lld | %6lld | %6lld | %6lld | %6lld | %6lld\n", l, st[l][2] - st[l][0], st[l][5] - st[l][0], st[l][3] - st[l][2], st[l][4] - st[l][3],
              st[l][6] - st[l][4], st[l][7] - st[l][6], l ? st[l][0] - st[l - 1][0] : 0);
+    if (with_plan && ws->launch.size() > 0) {
+      // the bulk side of the stamped launch: per launch step, when its tiles were taken / had their counters / were done,
+      // relative to the end of the pivot chain of row step l - 1 (the moment the panel of step l - 1 exists)
+      static long long tt[8192][4], rt[256][2];
+      hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_chain_task_t), sizeof tt);
+      hipMemcpyFromSymbol(rt, HIP_SYMBOL(g_chain_row_t), sizeof rt);
+      const ChainLaunch& L = ws->launch[0];
+      std::vector<ChainTask> th(L.n_tasks);
+      hipMemcpy(th.data(), ws->tasks.p + L.task_off, sizeof(ChainTask) * L.n_tasks, hipMemcpyDeviceToHost);
+      printf("level 0: %d tasks, %d row owners, %d bulk workgroups\n", L.n_tasks, L.jobs.n_row_wg, L.jobs.n_bulk_wg);
+      printf("launch step | urgent tiles: n, taken / counters / done (us after the pivots of step l-1 ended; mean, max) | other tiles: n, done mean, max\n");
+      for (int l = 1; l < 10; l++) {
+        double su[3] = {0, 0, 0}, mu[3] = {-1e9, -1e9, -1e9}, so = 0, mo = -1e9; int nu = 0, no = 0;
+        const double T = (double)rt[l - 1][1];
+        for (int t = 0; t < L.n_tasks && t < 8192; t++) {
+          if (th[t].l != l || th[t].k != 2) continue;   // the stamped row owner's job
+          if (th[t].J == 1) { nu++; for (int i = 0; i < 3; i++) { const double d = (tt[t][i] - T) * 0.01; su[i] += d; mu[i] = std::max(mu[i], d); } }
+          else { no++; const double d = (tt[t][2] - T) * 0.01; so += d; mo = std::max(mo, d); }
+        }
+        if (nu) printf("  %2d | %3d  %6.1f %6.1f | %6.1f %6.1f | %6.1f %6.1f || %4d %6.1f %6.1f   (step %d lasted %.1f us)\n", l, nu, su[0] / nu, mu[0], su[1] / nu, mu[1], su[2] / nu, mu[2], no,
+                       no ? so / no : 0.0, mo, l, (rt[l][1] - rt[l - 1][1]) * 0.01);
+      }
+    }
   }
   // the factor: blocks below the diagonal blocks in M, the diagonal blocks and the 16 x 16 inverses in the workspace
   size_t nd = 0; double dmax = 0;
