@@ -68,7 +68,7 @@ struct BaPtrs {
   const double* rot;               // msfm_rot_prepare of `cam` ([Nc][4])
   const int *o_cam, *o_model, *o_pt, *o_cb, *o_mb, *o_pb, *o_cpos, *o_pm;
   const double *o_x, *o_y, *o_w;
-  double *lin_r, *lin_Jc, *lin_Jm, *camrow;   // lin_*: the rows [AE, A) only
+  double *lin_r, *lin_Jc, *lin_Jm;   // the rows [AE, A) only
   const double *scale_c, *scale_m, *scale_p;
   double huber;
 };
@@ -80,6 +80,34 @@ struct BaPtrs {
 // parameters than to write once and read twice: 0.75 GB per LM iteration at config 3).
 // Rows of frozen blocks come out as zeros (their scales are 0).
 // --------------------------------------------------------------------------------------
+// The arithmetic of obs_linearize on values already in registers (k_ftf evaluates it camera by camera: pose, rotation cache,
+// intrinsics and their column scales are the same for a whole chunk of rows).
+__device__ __forceinline__ double linearize_core(const double (&pose)[6], const double (&rc)[4], const double (&cm)[3], const double (&X)[3], double ox,
+                                                 double oy, double ow, const double (&sc)[6], const double (&sm)[3], const double (&sp)[3], double huber,
+                                                 double& r0, double& r1, double (&jc)[12], double (&jm)[6], double (&jp)[6]) {
+  double r[2], J[24];
+  msfm_reproj(pose, rc, cm, X, ox, oy, ow, r, J);
+  double rho0, rho1;
+  msfm_huber(huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
+  const double sq = sqrt(rho1);
+  r0 = sq * r[0]; r1 = sq * r[1];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const double s = sq * sc[j];
+    jc[j] = s * J[j];
+    jc[6 + j] = s * J[12 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const double s = sq * sm[j];
+    jm[j] = s * J[6 + j];
+    jm[3 + j] = s * J[12 + 6 + j];
+    const double spj = sq * sp[j];
+    jp[j] = spj * J[9 + j];
+    jp[3 + j] = spj * J[12 + 9 + j];
+  }
+  return 0.5 * rho0;
+}
 __device__ __forceinline__ double obs_linearize(const BaPtrs& P, int i, double& r0, double& r1, double (&jc)[12], double (&jm)[6], double (&jp)[6]) {
   const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
   const int cb = P.o_cb[i], mb = P.o_mb[i], pb = P.o_pb[i];
@@ -121,16 +149,6 @@ __device__ __forceinline__ double obs_linearize(const BaPtrs& P, int i, double& 
   }
   return 0.5 * rho0;
 }
-// the camera-major copy of a row (160-byte rows: ten 16-byte stores), read by k_ftf
-__device__ __forceinline__ void store_camrow(double* __restrict__ camrow, int cp, const double (&jc)[12], const double (&jm)[6], double r0, double r1) {
-  double2* row = reinterpret_cast<double2*>(camrow + 20 * (size_t)cp);
-#pragma unroll
-  for (int j = 0; j < 6; j++) row[j] = make_double2(jc[2 * j], jc[2 * j + 1]);
-#pragma unroll
-  for (int j = 0; j < 3; j++) row[6 + j] = make_double2(jm[2 * j], jm[2 * j + 1]);
-  row[9] = make_double2(r0, r1);
-}
-
 // --------------------------------------------------------------------------------------
 // k_linearize: thread per active observation, rows [i0, A).  <false>: the cost only (trial points).  <true>: the stored
 // linearisation of the rows that belong to no eliminated point (i0 = AE; their point is frozen) - the rows of the
@@ -153,8 +171,6 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __r
       for (int j = 0; j < 12; j++) P.lin_Jc[(size_t)j * nt + it] = jc[j];
 #pragma unroll
       for (int j = 0; j < 6; j++) P.lin_Jm[(size_t)j * nt + it] = jm[j];
-      const int cp = P.o_cpos[i];
-      if (cp >= 0) store_camrow(P.camrow, cp, jc, jm, r0, r1);
     } else {
       const int c = P.o_cam[i], m = P.o_model[i], p = P.o_pt[i];
       double pose[6], rc[4], cm[3], X[3];
@@ -269,7 +285,7 @@ struct PointPtrs {
   double *ptL, *ptg, *T, *Tu, *Tm, *Tmu;
   double radius, dmin, dmax;
   int reuse_diag, mode;
-  int store_rows;      // first pass at this linearisation point: also write the camera-major rows (k_ftf) and the cost
+  int store_rows;      // first pass at this linearisation point: also the cost
   double* cost_partial;
   int* fail;
   // FoldTables (fold_wg nullptr: every product goes through the pair lists)
@@ -334,11 +350,7 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
       for (int k = 0; k < 12; k++) park[k * 256 + tid] = jcs[k];
 #pragma unroll
       for (int k = 0; k < 6; k++) { park[(12 + k) * 256 + tid] = jms[k]; park[(18 + k) * 256 + tid] = jps[k]; }
-      if (P.store_rows) {
-        cost += ci;
-        const int cp = P.B.o_cpos[i];
-        if (cp >= 0) store_camrow(P.B.camrow, cp, jcs, jms, r0, r1);
-      }
+      if (P.store_rows) cost += ci;
       const double a0 = jps[0], a1 = jps[1], a2 = jps[2], b0 = jps[3], b1 = jps[4], b2 = jps[5];
       V00 += a0 * a0 + b0 * b0; V10 += a1 * a0 + b1 * b0; V11 += a1 * a1 + b1 * b1;
       V20 += a2 * a0 + b2 * b0; V21 += a2 * a1 + b2 * b1; V22 += a2 * a2 + b2 * b2;
@@ -664,6 +676,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   k_point_body(P, gmax_partial, sh, park, ent_s);
 }
 
+// The static inputs of a row in camera-major order (k_ftf): built once per problem from the resident row arrays.
+__global__ __launch_bounds__(256) void k_cam_rows(int A, const int* __restrict__ o_cpos, const int* __restrict__ o_pt, const double* __restrict__ o_x,
+                                                   const double* __restrict__ o_y, const double* __restrict__ o_w, int* __restrict__ cm_pt,
+                                                   double* __restrict__ cm_x, double* __restrict__ cm_y, double* __restrict__ cm_w, int* __restrict__ cm_row) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A) return;
+  const int cp = o_cpos[i];
+  if (cp < 0) return;
+  cm_pt[cp] = o_pt[i]; cm_x[cp] = o_x[i]; cm_y[cp] = o_y[i]; cm_w[cp] = o_w[i]; cm_row[cp] = i;
+}
+__global__ __launch_bounds__(256) void k_chunk_cam(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ cm_row, const int* __restrict__ o_cam,
+                                                    const int* __restrict__ o_model, const int* __restrict__ o_cb, const int* __restrict__ o_mb,
+                                                    int4* __restrict__ chunk_cam) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= nchunk) return;
+  const int i = cm_row[ch_start[ch]];
+  chunk_cam[ch] = make_int4(o_cam[i], o_model[i], o_cb[i], o_mb[i]);
+}
+
 // --------------------------------------------------------------------------------------
 // k_ftf: one wave per chunk of a camera's (camera-major) observation rows.
 // partial[chunk][PSTRIDE]: Jc^T Jc | Jm^T Jc | Jm^T Jm | Jc^T r | Jm^T r | sum T.u
@@ -676,34 +707,53 @@ __device__ __forceinline__ void wave_reduce_store(double (&acc)[N], double* out,
   if (k >= 0) out[k] = v;   // one store instruction: every value ends in its own lane
 }
 
-__global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
-                                              const double* __restrict__ camrow, const double* __restrict__ Tu,
-                                              const int* __restrict__ cpos_pb, double* __restrict__ partial) {
+// Round 4: the rows are LINEARISED AGAIN here instead of being read back from a 160-byte camera-major copy that k_point
+// wrote (192 MB written + 258 MB read per LM iteration at config 3): per row the camera-major statics (point index and
+// x, y, weight: 28 bytes, coalesced) and the point (24 bytes, gathered); pose, rotation cache, intrinsics and their column
+// scales are those of the chunk's camera and live in scalar registers.  Same function, same inputs, same order of the sums
+// as before: the per-camera sums are what the stored rows gave.
+struct CamRows {
+  const int* pt;             // [NCR] point of the row at camera-major position e
+  const double *x, *y, *w;   // [NCR]
+  const int4* chunk_cam;     // [chunks] camera, intrinsics, camera block, intrinsics block (-1: frozen) of the chunk's rows
+};
+__global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end, BaPtrs P, CamRows R,
+                                              const double* __restrict__ Tu, const int* __restrict__ cpos_pb, double* __restrict__ partial) {
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (chunk >= nchunk) return;
   // Jc^T Jc and Jm^T Jm are symmetric: 21 + 6 of their 36 + 9 entries are accumulated (the mirrored ones are the same
-  // products in the other order, so the stored 78 values are what the full loops gave) - 60 accumulators leave room for
-  // the NEXT row's ten 16-byte loads to be in flight while this row is added.
+  // products in the other order, so the stored 78 values are what the full loops gave).
   // acc: Jc^T Jc lower triangle (21, row-wise) | Jm^T Jc (18) | Jm^T Jm lower (6) | Jc^T r (6) | Jm^T r (3) | sum T.u (6)
   constexpr int O_JC = 0, O_JMC = 21, O_JM = 39, O_CR = 45, O_MR = 51, O_TU = 54;
   double acc[60];
 #pragma unroll
   for (int k = 0; k < 60; k++) acc[k] = 0.0;
+  // the chunk's camera: uniform over the wave
+  const int4 cc = R.chunk_cam[chunk];
+  const int c = __builtin_amdgcn_readfirstlane(cc.x), m = __builtin_amdgcn_readfirstlane(cc.y);
+  const int cb = __builtin_amdgcn_readfirstlane(cc.z), mb = __builtin_amdgcn_readfirstlane(cc.w);
+  double pose[6], rc[4], cm[3], sc[6], sm[3];
+  const double sp[3] = {0.0, 0.0, 0.0};   // (the point columns are not needed here)
+#pragma unroll
+  for (int j = 0; j < 6; j++) { pose[j] = P.cam[6 * (size_t)c + j]; sc[j] = cb >= 0 ? P.scale_c[6 * cb + j] : 0.0; }
+#pragma unroll
+  for (int j = 0; j < 4; j++) rc[j] = P.rot[4 * (size_t)c + j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; sm[j] = mb >= 0 ? P.scale_m[3 * mb + j] : 0.0; }
   const int e1 = ch_end[chunk];
   int e = ch_start[chunk] + lane;
-  double2 nx[10];
-#pragma unroll
-  for (int k = 0; k < 10; k++) nx[k] = make_double2(0.0, 0.0);
+  // two rows ahead: the statics of row e + 128 and, with its point index known, the point of row e + 64
+  int pn = 0, pnn = 0;
+  double xn = 0, yn = 0, wn = 0, xnn = 0, ynn = 0, wnn = 0, Xn[3] = {0, 0, 0};
+  if (e < e1) { pn = R.pt[e]; xn = R.x[e]; yn = R.y[e]; wn = R.w[e]; }
+  if (e + 64 < e1) { pnn = R.pt[e + 64]; xnn = R.x[e + 64]; ynn = R.y[e + 64]; wnn = R.w[e + 64]; }
   if (e < e1) {
-    // rows are 160 bytes and 16-byte aligned: ten 16-byte loads instead of twenty 8-byte ones
-    const double2* row2 = reinterpret_cast<const double2*>(camrow + 20 * (size_t)e);
 #pragma unroll
-    for (int k = 0; k < 10; k++) nx[k] = row2[k];
+    for (int j = 0; j < 3; j++) Xn[j] = P.pt[3 * (size_t)pn + j];
   }
   for (; e < e1; e += 64) {
-    double rw[20];
-#pragma unroll
-    for (int k = 0; k < 10; k++) { rw[2 * k] = nx[k].x; rw[2 * k + 1] = nx[k].y; }
+    const double X[3] = {Xn[0], Xn[1], Xn[2]};
+    const double ox = xn, oy = yn, ow = wn;
     const bool has_tu = cpos_pb[e] >= 0;
     double2 tu2[3];
     if (has_tu) {
@@ -711,14 +761,17 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
 #pragma unroll
       for (int a = 0; a < 3; a++) tu2[a] = tp[a];
     }
+    // shift the pipeline: row e + 64 becomes "next" (its point is fetched now), row e + 128's statics are asked for
+    pn = pnn; xn = xnn; yn = ynn; wn = wnn;
     if (e + 64 < e1) {
-      const double2* row2 = reinterpret_cast<const double2*>(camrow + 20 * (size_t)(e + 64));
 #pragma unroll
-      for (int k = 0; k < 10; k++) nx[k] = row2[k];
+      for (int j = 0; j < 3; j++) Xn[j] = P.pt[3 * (size_t)pn + j];
     }
-    const double* jc = rw;
-    const double* jm = rw + 12;
-    const double r0 = rw[18], r1 = rw[19];
+    if (e + 128 < e1) { pnn = R.pt[e + 128]; xnn = R.x[e + 128]; ynn = R.y[e + 128]; wnn = R.w[e + 128]; }
+    double r0, r1, jcr[12], jmr[6], jpr[6];
+    linearize_core(pose, rc, cm, X, ox, oy, ow, sc, sm, sp, P.huber, r0, r1, jcr, jmr, jpr);
+    const double* jc = jcr;
+    const double* jm = jmr;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -1366,7 +1419,10 @@ struct msfm_ba {
   DevBuf<int> cb_cam, mb_model, pb_pt, cb_mb;
   DevBuf<int> o_cam, o_model, o_pt, o_cb, o_mb, o_pb, o_cpos, o_pm;
   DevBuf<double> o_x, o_y, o_w;
-  DevBuf<double> lin_r, lin_Jc, lin_Jm, camrow, T, Tu, Tm, Tmu, rot, rot_c;
+  DevBuf<double> lin_r, lin_Jc, lin_Jm, T, Tu, Tm, Tmu, rot, rot_c;
+  DevBuf<int> cm_pt;            // camera-major statics of the rows (k_ftf linearises them again)
+  DevBuf<double> cm_xyw;        // [3][NCR]
+  DevBuf<int4> chunk_cam;
   DevBuf<int> cpos_pb;
   DevBuf<double> scale_c, scale_m, scale_p, diag_c, diag_m, diag_p;
   DevBuf<int> pt_first, pm_first, pm_mb;
@@ -3219,7 +3275,8 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   AL(rot, 4 * (size_t)Nc); AL(rot_c, 4 * (size_t)Nc);
   const size_t Atail = (size_t)std::max(1, A - ba->AE);   // rows of frozen points: the only ones whose linearisation is stored
   AL(lin_r, 2 * Atail); AL(lin_Jc, 12 * Atail); AL(lin_Jm, 6 * Atail);
-  AL(camrow, 20 * (size_t)NCR); AL(T, 18 * (size_t)NCR); AL(Tu, 6 * (size_t)NCR);
+  AL(T, 18 * (size_t)NCR); AL(Tu, 6 * (size_t)NCR);
+  AL(cm_pt, (size_t)NCR); AL(cm_xyw, 3 * (size_t)NCR); AL(chunk_cam, (size_t)ba->n_fchunks);
   AL(Tm, 9 * (size_t)NPM); AL(Tmu, 3 * (size_t)NPM);
   AL(scale_c, 6 * (size_t)ncb); AL(scale_m, 3 * (size_t)nmb); AL(scale_p, 3 * (size_t)npb);
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
@@ -3241,7 +3298,7 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   {
     // every device buffer a kernel may dereference must exist before the first launch
     const void* must[] = {ba->cam.p, ba->model.p, ba->pt.p, ba->cam_c.p, ba->model_c.p, ba->pt_c.p, ba->lin_r.p, ba->lin_Jc.p,
-                          ba->lin_Jm.p, ba->camrow.p, ba->T.p, ba->Tu.p, ba->Tm.p, ba->Tmu.p, ba->scale_c.p,
+                          ba->lin_Jm.p, ba->cm_pt.p, ba->cm_xyw.p, ba->chunk_cam.p, ba->T.p, ba->Tu.p, ba->Tm.p, ba->Tmu.p, ba->scale_c.p,
                           ba->scale_m.p, ba->scale_p.p, ba->diag_c.p, ba->diag_m.p, ba->diag_p.p, ba->ptL.p, ba->ptg.p,
                           ba->f_partial.p, ba->camftf.p, ba->modelsum.p, ba->M.p, ba->Linv.p, ba->w.p, ba->z.p, ba->g_r.p,
                           ba->g_J.p, ba->partial.p, ba->partial2.p, ba->partial3.p, ba->gmax_buf.p, ba->scal.p, ba->fail.p};
@@ -3257,7 +3314,22 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ba->h_scal_dev, ba->h_scal, 0));
   HIP_TRY(ctx, hipHostMalloc((void**)&ba->h_fail, 4 * sizeof(int)));
   HIP_TRY(ctx, hipMemsetAsync(ba->z.p, 0, sizeof(double) * (size_t)(ba->npad + 8), s));  // tail entries are read (times zero) by frozen blocks
-  HIP_TRY(ctx, hipMemsetAsync(ba->camrow.p, 0, sizeof(double) * std::max<size_t>(1, 20 * (size_t)NCR), s));
+  {
+    // camera-major statics of the rows and the camera of every k_ftf chunk
+    DevBuf<int> cm_row;
+    HIP_TRY(ctx, cm_row.alloc((size_t)std::max(1, NCR)));
+    HIP_TRY(ctx, hipMemsetAsync(ba->cm_pt.p, 0, sizeof(int) * (size_t)std::max(1, NCR), s));
+    HIP_TRY(ctx, hipMemsetAsync(ba->cm_xyw.p, 0, sizeof(double) * 3 * (size_t)std::max(1, NCR), s));
+    HIP_TRY(ctx, hipMemsetAsync(cm_row.p, 0, sizeof(int) * (size_t)std::max(1, NCR), s));
+    const size_t ncr = (size_t)std::max(1, NCR);
+    if (A > 0)
+      hipLaunchKernelGGL(k_cam_rows, dim3(cdiv(A, 256)), dim3(256), 0, s, A, ba->o_cpos.p, ba->o_pt.p, ba->o_x.p, ba->o_y.p, ba->o_w.p, ba->cm_pt.p,
+                         ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, cm_row.p);
+    if (ba->n_fchunks)
+      hipLaunchKernelGGL(k_chunk_cam, dim3(cdiv(ba->n_fchunks, 256)), dim3(256), 0, s, ba->n_fchunks, ba->f_start.p, cm_row.p, ba->o_cam.p, ba->o_model.p,
+                         ba->o_cb.p, ba->o_mb.p, ba->chunk_cam.p);
+    HIP_TRY(ctx, hipStreamSynchronize(s));   // (cm_row goes back to the pool)
+  }
   HIP_TRY(ctx, hipMemsetAsync(ba->T.p, 0, sizeof(double) * std::max<size_t>(1, 18 * (size_t)NCR), s));
   HIP_TRY(ctx, hipMemsetAsync(ba->Tu.p, 0, sizeof(double) * std::max<size_t>(1, 6 * (size_t)NCR), s));
   HIP_TRY(ctx, hipMemcpyAsync(ba->cam.p, P->cam_pose, sizeof(double) * 6 * (size_t)Nc, hipMemcpyHostToDevice, s));
@@ -3338,7 +3410,7 @@ static BaPtrs make_ptrs(msfm_ba* ba, bool candidate, double huber) {
   P.o_cam = ba->o_cam.p; P.o_model = ba->o_model.p; P.o_pt = ba->o_pt.p; P.o_cb = ba->o_cb.p; P.o_mb = ba->o_mb.p;
   P.o_pb = ba->o_pb.p; P.o_cpos = ba->o_cpos.p; P.o_pm = ba->o_pm.p;
   P.o_x = ba->o_x.p; P.o_y = ba->o_y.p; P.o_w = ba->o_w.p;
-  P.lin_r = ba->lin_r.p; P.lin_Jc = ba->lin_Jc.p; P.lin_Jm = ba->lin_Jm.p; P.camrow = ba->camrow.p;
+  P.lin_r = ba->lin_r.p; P.lin_Jc = ba->lin_Jc.p; P.lin_Jm = ba->lin_Jm.p;
   P.scale_c = ba->scale_c.p; P.scale_m = ba->scale_m.p; P.scale_p = ba->scale_p.p;
   P.huber = huber;
   return P;
@@ -3492,8 +3564,12 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   {
     KTimer t(ctx, "ba_ftf");
     if (ba->n_fchunks)
+    {
+      const size_t ncr = (size_t)std::max(1, ba->NCR);
+      const CamRows R{ba->cm_pt.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
       hipLaunchKernelGGL(k_ftf, dim3(cdiv(ba->n_fchunks, 4)), dim3(256), 0, s, ba->n_fchunks, ba->f_start.p, ba->f_end.p,
-                         ba->camrow.p, ba->Tu.p, ba->cpos_pb.p, ba->f_partial.p);
+                         make_ptrs(ba, false, ba->lin_huber), R, ba->Tu.p, ba->cpos_pb.p, ba->f_partial.p);
+    }
     if (ncb)
       hipLaunchKernelGGL(k_camftf, dim3(ncb), dim3(128), 0, s, ncb, ba->cam_chunk_first.p, ba->f_partial.p, ba->camftf.p,
                          ba->g_r.p, ba->g_J.p, (ba->has_gps && lead) ? 1 : 0, ctx->world <= 1 ? 1 : 0, ba->diag_c.p, ba->scale_c.p,
