@@ -52,6 +52,13 @@ def ba_algorithmic_bytes(n_obs, n_pts, n_cams, n_red):
     return jac + trial + 2 * n_red * n_red * 8
 
 
+def ba_schur_build_flops(k, b=9):
+    """SURVEY.md §8d Schur-build flops per LM iteration: sum over the points of
+    k_p (2*2*b^2/2 + 2*2*b*3 + 2*2*9/2) + k_p^2 (2*b*3*3 + 2*b*3*b), k = observations per point (array), b = 9."""
+    k = np.asarray(k, dtype=np.float64)
+    return float((k * (2 * 2 * b * b / 2 + 2 * 2 * b * 3 + 2 * 2 * 9 / 2) + k * k * (2 * b * 3 * 3 + 2 * b * 3 * b)).sum())
+
+
 def kernel_source_hash():
     """Identifies the kernels a PMC collection was made with (profiles/pmc_traffic.json carries the same hash): the GPU box
     has no git history, so the sources themselves are hashed."""
@@ -129,6 +136,9 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
+    if world > max(1, torch.cuda.device_count()):
+        # a rehearsal with more ranks than GPUs: tell the library how many contexts launch on this device at the same time
+        os.environ["MSFM_DEVICE_SHARE"] = str(-(-world // max(1, torch.cuda.device_count())))
 
     ctx = capi.Context(local_rank)
     collective = "none (1 rank)"
@@ -288,17 +298,45 @@ def main():
         cc_live = fold.get("cc_entries", n_pairs_cc) - fold.get("cc_entries_folded", 0)
         mc_live = fold.get("mc_entries", sc.n_obs) - fold.get("mc_entries_folded", 0)
         fold_bytes = fold.get("slots", 0) * 288 + fold.get("mc_slots", 0) * 144
-        add("ba_point", "hbm", sc.n_obs * (52 + 160 + 144 + 48) + sc.n_points * (24 + 96) + fold_bytes,
-            "row data + point in; camera-major row (160 B), T (144 B), T.u (48 B) per observation and L, g, diagonal per point out"
+        impl_bytes = sc.n_obs * (52 + 144 + 48) + sc.n_points * (24 + 96) + fold_bytes
+        add("ba_point", "hbm", impl_bytes,
+            "row data + point in; T (144 B), T.u (48 B) per observation and L, g, diagonal per point out"
             + ("; %d + %d slot partials of the Schur products formed in the kernel (%.1f MB)" % (fold.get("slots", 0), fold.get("mc_slots", 0), fold_bytes / 1e6)
                if fold_bytes else ""))
+        if "ba_point" in rooflines:
+            # SURVEY.md 8d accounting for the Jacobian / Schur-build pass (what the contract's `frac` is): the pass's algorithmic
+            # bytes No*24 + Np*56 + Nc*96 against HBM, its Schur-build flops against the FP64 roof, `frac` = the larger of the two.
+            # The bytes the IMPLEMENTATION moves by design (intermediates it writes for later kernels included) stay beside it as
+            # frac_impl_bytes, and `traffic_ratio` (measured HBM bytes / 8d bytes) is added where the PMC counters are attached.
+            rl = rooflines["ba_point"]
+            t_pt = rl["avg_launch_us"] * 1e-6
+            b8d = sc.n_obs * 24 + sc.n_points * 56 + sc.n_cams * 96
+            folded = (fold.get("cc_entries_folded", 0) / max(1, fold.get("cc_entries", 1))) if fold else 0.0
+            f8d = ba_schur_build_flops(k) * (folded if fold else 0.0)   # the share of the Schur build that this kernel executes
+            f8d_self = float((k * (2 * 2 * 81 / 2 + 2 * 2 * 9 * 3 + 2 * 2 * 9 / 2)).sum())   # the per-observation part is always here
+            f8d = max(f8d, f8d_self)
+            frac_b, frac_f = b8d / t_pt / 1e9 / HBM_PEAK_GBS, f8d / t_pt / 1e12 / FP64_PEAK_TFLOPS
+            rl["frac_impl_bytes"] = rl["frac"]
+            rl["achieved_impl_GBs"] = rl["achieved"]
+            rl["bytes_8d"] = b8d
+            rl["flops_8d"] = f8d
+            rl["frac_bytes_8d"] = frac_b
+            rl["frac_flops_8d"] = frac_f
+            if frac_f >= frac_b:
+                rl.update(bound="mfma", achieved=f8d / t_pt / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=frac_f)
+            else:
+                rl.update(bound="hbm", achieved=b8d / t_pt / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=frac_b)
+            rl["note"] = ("SURVEY 8d: max(%.1f MB of algorithmic bytes, %.2f GFLOP of Schur build - %.1f %% of the camera x camera products fold "
+                          "into this kernel) / launch time against the respective roof (FP64 vector = matrix rate, %.1f TFLOP/s); "
+                          "frac_impl_bytes = the bytes the kernel moves by design (%.1f MB: %s) / time / HBM peak"
+                          % (b8d / 1e6, f8d / 1e9, 100 * folded, FP64_PEAK_TFLOPS, impl_bytes / 1e6, rl["note"]))
         add("ba_schur_pairs", "hbm", (cc_live + mc_live) * 288 + sc.n_points * 144,
             "two 144-byte T records gathered per pair entry that is not folded into k_point (%d of %d camera x camera, %d of %d intrinsics x camera)"
             % (cc_live, fold.get("cc_entries", n_pairs_cc), mc_live, fold.get("mc_entries", sc.n_obs)))
         add("ba_assemble", "hbm", fold_bytes + (cc_live + mc_live > 0) * 0 + lay["reduced_order"] ** 2 * 4,
             "slot partials in, lower triangle of the reduced system out")
         add("ba_backsub", "hbm", sc.n_obs * 52 + sc.n_points * 12 * 8, "row data, point and its 3x3 factor in, candidate point out")
-        add("ba_ftf", "hbm", sc.n_obs * 26 * 8, "camera-major rows in")
+        add("ba_ftf", "hbm", sc.n_obs * (28 + 24 + 48 + 4), "camera-major statics (28 B), point (24 B), T.u (48 B) per row in; the rows are linearised again")
     dom = kernels[0]
     step_bw = alg_bytes / (ba_s / args.steps) / 1e9
     whole = dict(bound="hbm", achieved=step_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=step_bw / HBM_PEAK_GBS, traffic=None,
@@ -315,6 +353,8 @@ def main():
             if pmc.get("_kernel_source_hash") == kernel_source_hash() and roofline.get("kernel") in pmc:
                 roofline["traffic"] = pmc[roofline["kernel"]]["bytes_per_launch"]
                 roofline["traffic_source"] = pmc[roofline["kernel"]].get("source")
+                if roofline.get("bytes_8d"):
+                    roofline["traffic_ratio"] = roofline["traffic"] / roofline["bytes_8d"]
             elif roofline.get("kernel") in pmc:
                 roofline["traffic_note"] = "profiles/pmc_traffic.json was collected with other kernel sources (%s); not attached" % pmc.get("_kernel_source_hash")
         except Exception:

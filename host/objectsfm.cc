@@ -100,6 +100,23 @@ msfm_ctx* Context() {
 static void check(int rc, const char* what) {
   if (rc != MSFM_OK) throw std::runtime_error(std::string(what) + ": " + msfm_last_error(g_ctx));
 }
+// Several GPUs from the one process the reference is (test_sfm.cc:22-70 `main`): msfm_ctx_create_multi owns a context and a
+// host thread per device and the communicator; the calls below that shard (matching, triangulation / reprojection, bundle
+// adjustment) go through it, everything else through its rank-0 context.
+static msfm_multi* g_multi = nullptr;
+static void destroy_multi() { if (g_multi) msfm_multi_destroy(g_multi); g_multi = nullptr; g_ctx = nullptr; }
+void UseGpus(int n_gpus, bool share_device_0) {
+  if (g_multi || g_ctx) throw std::runtime_error("UseGpus: call before the first GPU call");
+  if (n_gpus <= 1) return;
+  std::vector<int> dev(n_gpus);
+  for (int i = 0; i < n_gpus; i++) dev[i] = share_device_0 ? 0 : i;
+  if (msfm_ctx_create_multi(n_gpus, dev.data(), &g_multi) != MSFM_OK) throw std::runtime_error("msfm_ctx_create_multi failed");
+  g_ctx = msfm_multi_ctx(g_multi, 0);
+  std::atexit(destroy_multi);
+}
+static void check_multi(int rc, const char* what) {
+  if (rc != MSFM_OK) throw std::runtime_error(std::string(what) + ": " + msfm_multi_last_error(g_multi));
+}
 
 // ---- Point3D ------------------------------------------------------------------------------------
 void Point3D::AddObservation(Camera* cam, double x, double y, int idx) {
@@ -151,9 +168,14 @@ void TrianglateBatch(const std::vector<Point3D*>& pts, double th_error, double t
   std::vector<double> X(3 * pts.size()), mse(pts.size());
   std::vector<uint8_t> okv(pts.size());
   for (size_t i = 0; i < pts.size(); i++) for (int k = 0; k < 3; k++) X[3 * i + k] = pts[i]->data[k];
-  check(dlt ? msfm_triangulate_dlt_batch(Context(), &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data())
-            : msfm_triangulate_midpoint_batch(Context(), &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data()),
-        "triangulate");
+  if (g_multi)
+    check_multi(dlt ? msfm_multi_triangulate_dlt_batch(g_multi, &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data())
+                    : msfm_multi_triangulate_midpoint_batch(g_multi, &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data()),
+                "triangulate");
+  else
+    check(dlt ? msfm_triangulate_dlt_batch(Context(), &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data())
+              : msfm_triangulate_midpoint_batch(Context(), &F.tr, th_error, th_angle, X.data(), mse.data(), okv.data()),
+          "triangulate");
   if (ok) ok->assign(pts.size(), 0);
   for (size_t i = 0; i < pts.size(); i++) {
     for (int k = 0; k < 3; k++) pts[i]->data[k] = X[3 * i + k];
@@ -166,7 +188,8 @@ void ReprojectionBatch(const std::vector<Point3D*>& pts) {
   Flat F(pts);
   std::vector<double> X(3 * pts.size()), mse(pts.size());
   for (size_t i = 0; i < pts.size(); i++) for (int k = 0; k < 3; k++) X[3 * i + k] = pts[i]->data[k];
-  check(msfm_reproject_mse_batch(Context(), &F.tr, X.data(), mse.data()), "reproject");
+  if (g_multi) check_multi(msfm_multi_reproject_mse_batch(g_multi, &F.tr, X.data(), mse.data()), "reproject");
+  else check(msfm_reproject_mse_batch(Context(), &F.tr, X.data(), mse.data()), "reproject");
   for (size_t i = 0; i < pts.size(); i++) pts[i]->mse_ = mse[i];
 }
 
@@ -280,7 +303,9 @@ void BundleAdjuster::RunOptimizetion(bool is_initial_run, double weight) {
   iterations_.assign((size_t)options_.max_num_iterations + 2, msfm_ba_iteration());
   summary_.iterations = iterations_.data();
   summary_.iterations_capacity = (int)iterations_.size();
-  check(msfm_ba_solve(Context(), &P, &options_, &summary_), "msfm_ba_solve");  // == ceres::Solve, optimizer.cc:133
+  // == ceres::Solve, optimizer.cc:133 (several GPUs: the same call with the points split inside the library)
+  if (g_multi) check_multi(msfm_multi_ba_solve(g_multi, &P, &options_, &summary_), "msfm_multi_ba_solve");
+  else check(msfm_ba_solve(Context(), &P, &options_, &summary_), "msfm_ba_solve");
   // Ceres writes through the data blocks; so do we
   for (size_t i = 0; i < cams_.size(); i++) for (int k = 0; k < 6; k++) cams_[i]->data[k] = cam_pose[6 * i + k];
   for (size_t i = 0; i < cam_models_.size(); i++) for (int k = 0; k < 3; k++) cam_models_[i]->data[k] = cam_model[3 * i + k];
@@ -428,6 +453,31 @@ void SLAMGPS::FullBundleAdjustment() {
 // ---- matching -----------------------------------------------------------------------------------
 std::vector<PairMatches> MatchImagePairs(const std::vector<std::vector<float>>& descriptors,
                                          const std::vector<std::pair<int, int>>& pairs, float thRatio_good, float thRatio_all) {
+  if (g_multi) {
+    // the pair list split over the contexts inside the library (fine_matching_graph.cc:87: the pairs are independent)
+    const int n_img = (int)descriptors.size();
+    std::vector<const float*> dp(n_img);
+    std::vector<int> cnt(n_img), flat;
+    for (int i = 0; i < n_img; i++) { dp[i] = descriptors[i].data(); cnt[i] = (int)(descriptors[i].size() / 128); }
+    for (auto& p : pairs) { flat.push_back(p.first); flat.push_back(p.second); }
+    std::vector<std::vector<int32_t>> codes(pairs.size());
+    std::vector<int32_t*> cp(pairs.size());
+    for (size_t p = 0; p < pairs.size(); p++) { codes[p].assign((size_t)std::max(1, cnt[pairs[p].second]), -1); cp[p] = codes[p].data(); }
+    check_multi(msfm_multi_match_pairs(g_multi, n_img, dp.data(), cnt.data(), 128, flat.data(), (int)pairs.size(), thRatio_good, thRatio_all, cp.data(),
+                                       nullptr, nullptr), "multi_match_pairs");
+    std::vector<PairMatches> out(pairs.size());
+    for (size_t p = 0; p < pairs.size(); p++) {
+      out[p].idx1 = pairs[p].first; out[p].idx2 = pairs[p].second;
+      for (int m = 0; m < cnt[pairs[p].second]; m++) {
+        const int32_t code = codes[p][m];
+        if (code < 0) continue;
+        const int id1 = code & MSFM_MATCH_ID_MASK;
+        if (code & MSFM_MATCH_GOOD) out[p].matches_good.push_back(std::make_pair(id1, m));
+        if (!(code & MSFM_MATCH_NOT_ALL)) out[p].matches_all.push_back(std::make_pair(id1, m));
+      }
+    }
+    return out;
+  }
   msfm_descset* set = nullptr;
   check(msfm_descset_create(Context(), (int)descriptors.size(), 128, &set), "descset_create");
   for (size_t i = 0; i < descriptors.size(); i++)

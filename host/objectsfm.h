@@ -116,6 +116,9 @@ class Point3D {  // structure.h:29-72
 
 // One GPU context per process; created on first use, destroyed at exit.
 msfm_ctx* Context();
+// `n_gpus` contexts in this one process (msfm_ctx_create_multi); share_device_0: all of them on device 0 (a one-GPU box).
+// Call before the first GPU call.  Matching, triangulation / reprojection and the bundle adjustment then split inside the library.
+void UseGpus(int n_gpus, bool share_device_0 = false);
 
 // Batched forms the pipeline should prefer (IncrementalSfM::GenerateNew3DPoints /
 // RemovePointOutliers, sfm_incremental.cc:755-915,1831-1863): one kernel launch for all points.

@@ -15,7 +15,16 @@
 
 using namespace objectsfm;
 
-int main() {
+int main(int argc, char** argv) {
+  // --gpus N [--share-device]: N contexts in THIS process (the reference's entry point stays one `main`); --share-device puts
+  // all of them on device 0, which is how the multi-GPU path runs on a one-GPU box
+  int gpus = 1;
+  bool share = false;
+  for (int a = 1; a < argc; a++) {
+    if (!std::strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = std::atoi(argv[++a]);
+    else if (!std::strcmp(argv[a], "--share-device")) share = true;
+  }
+  if (gpus > 1) { UseGpus(gpus, share); std::printf("contexts: %d%s\n", gpus, share ? " (one device)" : ""); }
   const int n_cams = 10, n_pts = 2000, W = 4000, H = 3000;
   const double f = 1.2 * W;  // f_hyp_ convention, basic_structs.h:56
   std::mt19937_64 gen(0x4D53464DULL + 1);
@@ -215,6 +224,13 @@ int main() {
   ba.UpdateParameters();
   std::printf("BA: %d iterations, cost %.6e -> %.6e, termination %d, f = %.3f k1 = %.3e k2 = %.3e\n", ba.summary_.num_iterations,
               ba.summary_.initial_cost, ba.summary_.final_cost, ba.summary_.termination, model.f_, model.k1_, model.k2_);
+  {
+    // full-precision figures for the tests that compare runs with different numbers of contexts
+    double sc = 0, sp = 0;
+    for (auto& c : cams) for (int k = 0; k < 6; k++) sc += std::fabs(c.data[k]);
+    for (Point3D* p : pp) for (int k = 0; k < 3; k++) sp += std::fabs(p->data[k]);
+    std::printf("ba_final %.17g %.17g %.17g %.17g %.17g %d\n", ba.summary_.final_cost, model.f_, model.k1_, sc, sp, ba.summary_.num_iterations);
+  }
   // --- stage 4: RemovePointOutliers (sfm_incremental.cc:1831-1863), th_mse_outliers = 3.0 ---
   std::vector<Point3D*> live;
   for (Point3D* p : pp) if (!p->is_bad_estimated_) live.push_back(p);

@@ -488,6 +488,44 @@ int msfm_relpose_5pt_batch(msfm_ctx* ctx, int n_pairs, const int* offsets, const
                            const double* pts_cur, const double* f_ref, const double* f_cur, int ransac_times,
                            uint64_t seed, double* E, double* R, double* t, uint8_t* ok, int* n_candidates);
 
+/* ==================================================================================== *
+ *  Single-process multi-GPU context
+ * ==================================================================================== */
+
+/* ---- one process, several GPUs (threading row: "multi-GPU context msfm_ctx_create_multi(n_gpus) owns the
+ * communicator") ----
+ * The reference's entry point is ONE process (SfM/test/test_sfm/test_sfm.cc:22-70 `main`; BundleAdjuster::RunOptimizetion,
+ * optimizer.cc:59-133, is called from a single thread).  A multi context keeps that shape: it owns one msfm_ctx per device,
+ * a host thread per device inside the library, and the communicator between them - RCCL's ncclCommInitAll over xGMI when
+ * the devices are distinct, an in-process reduction (host barrier + a device-side sum in rank order) when the contexts share
+ * one device (`devices` may name the same device more than once: how the path is tested on a one-GPU box).
+ *   devices == NULL: devices 0 .. n_gpus-1.
+ * The msfm_multi_* calls below are the single-context calls with the split inside: same arguments, same results
+ * (bundle adjustment to 1e-9 of the one-context solve - the sums are formed in another order; everything else bit for bit). */
+typedef struct msfm_multi msfm_multi;
+int msfm_ctx_create_multi(int n_gpus, const int* devices, msfm_multi** out);
+void msfm_multi_destroy(msfm_multi* mc);
+int msfm_multi_size(const msfm_multi* mc);
+msfm_ctx* msfm_multi_ctx(msfm_multi* mc, int rank);          /* the context of rank r (rank 0: where single-context work goes) */
+const char* msfm_multi_last_error(const msfm_multi* mc);
+/* ceres::Solve (optimizer.cc:133) with the points - and all their observations - split over the contexts in contiguous
+ * ranges balanced by the work the mutability masks leave, cameras and intrinsics replicated, three reductions per linear
+ * solve over the communicator.  Arguments and results as msfm_ba_solve. */
+int msfm_multi_ba_solve(msfm_multi* mc, msfm_ba_problem* problem, const msfm_ba_options* options, msfm_ba_summary* summary);
+/* Point3D::Trianglate2 / Trianglate / Reprojection (structure.cc:163-300) with the tracks split by observation count; no
+ * collective (tracks are independent). */
+int msfm_multi_triangulate_midpoint_batch(msfm_multi* mc, const msfm_tracks* tracks, double th_error, double th_angle, double* X,
+                                          double* mse, uint8_t* ok);
+int msfm_multi_triangulate_dlt_batch(msfm_multi* mc, const msfm_tracks* tracks, double th_error, double th_angle, double* X, double* mse,
+                                     uint8_t* ok);
+int msfm_multi_reproject_mse_batch(msfm_multi* mc, const msfm_tracks* tracks, const double* X, double* mse);
+/* The matching loop of FineMatchingGraph::BuildMatchGraph (fine_matching_graph.cc:87-133) over a pair list, the idx1-major
+ * list cut into contiguous slices balanced by M1 * M2, one per context; no collective (pairs are independent).
+ *   desc[i]: [count[i]][dim] float descriptors of image i (host); pairs [n_pairs][2] = (idx1, idx2);
+ *   code[p]: count[idx2 of pair p] match codes (MSFM_MATCH_*), n_all / n_good [n_pairs] (either may be NULL). */
+int msfm_multi_match_pairs(msfm_multi* mc, int n_images, const float* const* desc, const int* count, int dim, const int* pairs, int n_pairs,
+                           float ratio_good, float ratio_all, int32_t* const* code, int* n_all, int* n_good);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,8 @@ SYMBOLS = [
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
     "msfm_epipolar_filter_batch", "msfm_tracks_build", "msfm_tracks_build_device", "msfm_track_set_size", "msfm_track_set_fetch", "msfm_track_set_destroy",
     "msfm_epnp_ransac_batch", "msfm_relpose_5pt_batch", "msfm_rccl_get_unique_id", "msfm_ctx_init_rccl", "msfm_ctx_allreduce",
+    "msfm_ctx_create_multi", "msfm_multi_destroy", "msfm_multi_size", "msfm_multi_ctx", "msfm_multi_last_error", "msfm_multi_ba_solve",
+    "msfm_multi_triangulate_midpoint_batch", "msfm_multi_triangulate_dlt_batch", "msfm_multi_reproject_mse_batch", "msfm_multi_match_pairs",
 ]
 
 
@@ -121,6 +123,19 @@ def lib():
     L.msfm_chain_fetch_point_tracks.argtypes = [vp, A.c_int_p]
     L.msfm_chain_destroy.argtypes = [vp]
     L.msfm_chain_destroy.restype = None
+    L.msfm_ctx_create_multi.argtypes = [i, A.c_int_p, C.POINTER(vp)]
+    L.msfm_multi_destroy.argtypes = [vp]
+    L.msfm_multi_destroy.restype = None
+    L.msfm_multi_size.argtypes = [vp]
+    L.msfm_multi_ctx.argtypes = [vp, i]
+    L.msfm_multi_ctx.restype = vp
+    L.msfm_multi_last_error.argtypes = [vp]
+    L.msfm_multi_last_error.restype = C.c_char_p
+    L.msfm_multi_ba_solve.argtypes = [vp, C.POINTER(A.BaProblem), C.POINTER(A.BaOptions), C.POINTER(A.BaSummary)]
+    L.msfm_multi_triangulate_midpoint_batch.argtypes = [vp, C.POINTER(A.Tracks), d, d, A.c_double_p, A.c_double_p, A.c_u8_p]
+    L.msfm_multi_triangulate_dlt_batch.argtypes = [vp, C.POINTER(A.Tracks), d, d, A.c_double_p, A.c_double_p, A.c_u8_p]
+    L.msfm_multi_reproject_mse_batch.argtypes = [vp, C.POINTER(A.Tracks), A.c_double_p, A.c_double_p]
+    L.msfm_multi_match_pairs.argtypes = [vp, i, C.POINTER(A.c_float_p), A.c_int_p, i, A.c_int_p, i, f, f, C.POINTER(A.c_int_p), A.c_int_p, A.c_int_p]
     _lib = L
     return L
 
@@ -627,6 +642,72 @@ class BaResident:
     def close(self):
         if self._h:
             lib().msfm_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiContext:
+    """msfm_ctx_create_multi: one process, several GPUs - the library owns a context and a host thread per device and the
+    communicator between them (ncclCommInitAll over xGMI; an in-process reduction when `devices` names one device several
+    times, which is how the path runs on a one-GPU box).  The calls take the whole problem; the split is inside."""
+
+    def __init__(self, n_gpus, devices=None):
+        self._h = C.c_void_p()
+        dev = None if devices is None else A.as_c(np.asarray(devices, dtype=np.int32), np.int32)
+        rc = lib().msfm_ctx_create_multi(n_gpus, None if dev is None else A.ptr(dev, A.c_int_p), C.byref(self._h))
+        if rc != 0:
+            raise MsfmError(rc, "msfm_ctx_create_multi failed")
+        self.n = lib().msfm_multi_size(self._h)
+
+    def check(self, rc):
+        if rc != 0:
+            raise MsfmError(rc, lib().msfm_multi_last_error(self._h).decode())
+
+    def ba_solve(self, arrays: A.BaArrays, options=None, capacity=512):
+        options = options or default_options()
+        buf = A.SummaryBuf(capacity)
+        self.check(lib().msfm_multi_ba_solve(self._h, C.byref(arrays.struct), C.byref(options), C.byref(buf.struct)))
+        return buf.result()
+
+    def _tri(self, fn, tracks, th_error, th_angle):
+        n = tracks.struct.n_tracks
+        X, mse, ok = np.zeros((n, 3)), np.zeros(n), np.zeros(n, dtype=np.uint8)
+        self.check(fn(self._h, C.byref(tracks.struct), th_error, th_angle, A.ptr(X, A.c_double_p), A.ptr(mse, A.c_double_p), A.ptr(ok, A.c_u8_p)))
+        return X, mse, ok
+
+    def triangulate_midpoint(self, tracks, th_error, th_angle):
+        return self._tri(lib().msfm_multi_triangulate_midpoint_batch, tracks, th_error, th_angle)
+
+    def triangulate_dlt(self, tracks, th_error, th_angle):
+        return self._tri(lib().msfm_multi_triangulate_dlt_batch, tracks, th_error, th_angle)
+
+    def reproject_mse(self, tracks, X):
+        X = A.as_c(X, np.float64)
+        mse = np.zeros(tracks.struct.n_tracks)
+        self.check(lib().msfm_multi_reproject_mse_batch(self._h, C.byref(tracks.struct), A.ptr(X, A.c_double_p), A.ptr(mse, A.c_double_p)))
+        return mse
+
+    def match_pairs(self, descs, pairs, ratio_good=0.6, ratio_all=0.85):
+        """codes per pair, n_all, n_good - what DescSet.match_pairs + fetch give, with the pair list split over the contexts."""
+        descs = [A.as_c(d, np.float32) for d in descs]
+        pairs = A.as_c(np.asarray(pairs, dtype=np.int32).reshape(-1, 2), np.int32)
+        count = np.array([len(d) for d in descs], dtype=np.int32)
+        dp = (A.c_float_p * len(descs))(*[A.ptr(d, A.c_float_p) if len(d) else None for d in descs])
+        codes = [np.zeros(max(1, int(count[j])), np.int32) for _, j in pairs]
+        cp = (A.c_int_p * max(1, len(pairs)))(*[A.ptr(c, A.c_int_p) for c in codes])
+        na, ng = np.zeros(max(1, len(pairs)), np.int32), np.zeros(max(1, len(pairs)), np.int32)
+        self.check(lib().msfm_multi_match_pairs(self._h, len(descs), dp, A.ptr(count, A.c_int_p), 128, A.ptr(pairs, A.c_int_p), len(pairs),
+                                                ratio_good, ratio_all, cp, A.ptr(na, A.c_int_p), A.ptr(ng, A.c_int_p)))
+        return [c[:count[j]] for c, (_, j) in zip(codes, pairs)], na[:len(pairs)], ng[:len(pairs)]
+
+    def close(self):
+        if self._h:
+            lib().msfm_multi_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

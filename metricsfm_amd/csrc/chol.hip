@@ -1907,7 +1907,11 @@ static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
     // usable: every row owner resident with room to spare (other processes may share the device), a bulk workgroup for
     // every three tiles of the busiest step at least
     static const bool force = getenv("MSFM_CHAIN_FORCE") != nullptr;   // (probes: take the chain whatever the tile count)
-    L.usable = J.count > 0 && wg <= ws->capacity / 2 && (max_step_tasks == 0 || 3 * room >= max_step_tasks || force) && maxp < 4000;
+    // (a device shared with other contexts that launch the same kernel at the same time - ranks are synchronised by the
+    //  reduction in front of the factorisation - must hold the row owners of all of them, or none makes progress)
+    const int share = std::max(1, ctx->device_share);
+    const bool fits = share == 1 ? wg <= ws->capacity / 2 : (long)wg * share <= 3L * ws->capacity / 4;
+    L.usable = J.count > 0 && fits && (max_step_tasks == 0 || 3 * room >= max_step_tasks || force) && maxp < 4000;
     ws->launch.push_back(L);
   }
   HIP_TRY(ctx, ws->tasks.alloc(std::max<size_t>(1, table.size())));

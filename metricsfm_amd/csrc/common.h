@@ -29,6 +29,10 @@ struct msfm_ctx {
   msfm_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
   int rank = 0, world = 1;
+  // contexts (of this or of other processes) that use this device at the same time, as far as the host has said so
+  // (msfm_ctx_create_multi with a shared device; MSFM_DEVICE_SHARE for several processes on one GPU): kernels whose workgroups
+  // wait for each other inside a launch must leave room for the others' resident workgroups
+  int device_share = 1;
   // per-kernel-class timing (HIP events on `stream`)
   bool profile = false;
   struct Stat { std::string name; uint64_t launches = 0; double ms = 0; };

@@ -28,6 +28,10 @@ MSFM_API int msfm_ctx_create(int device, msfm_ctx** out) {
     return MSFM_E_DEVICE;
   }
   ctx->device = device;
+  {
+    const char* e = getenv("MSFM_DEVICE_SHARE");   // several processes on this device (the multi-rank tests on a one-GPU box)
+    ctx->device_share = e ? std::max(1, atoi(e)) : 1;
+  }
   *out = ctx;
   return MSFM_OK;
 }
@@ -268,6 +272,20 @@ MSFM_API int msfm_ctx_init_rccl(msfm_ctx* ctx, const unsigned char id[MSFM_RCCL_
   }
   ctx->rccl_comm = comm;
   return msfm_ctx_set_allreduce(ctx, rccl_hook, ctx, rank, world_size);
+}
+
+// A communicator created elsewhere (msfm_ctx_create_multi: ncclCommInitAll makes one per device in a single call): the
+// context takes it over - ncclAllReduce on its stream becomes the reduction hook, msfm_ctx_destroy releases it.
+int msfm_ctx_adopt_rccl(msfm_ctx* ctx, void* lib, void* comm, int rank, int world) {
+  if (!ctx || !lib || !comm) return MSFM_E_INVAL;
+  if (ctx->rccl_comm) return msfm_set_error(ctx, MSFM_E_INVAL, "this context already owns a communicator");
+  ctx->rccl_lib = lib;
+  ctx->rccl_allreduce = dlsym(lib, "ncclAllReduce");
+  ctx->rccl_comm_destroy = dlsym(lib, "ncclCommDestroy");
+  ctx->rccl_error_string = dlsym(lib, "ncclGetErrorString");
+  if (!ctx->rccl_allreduce || !ctx->rccl_comm_destroy) return msfm_set_error(ctx, MSFM_E_DEVICE, "librccl lacks an entry point");
+  ctx->rccl_comm = comm;
+  return msfm_ctx_set_allreduce(ctx, rccl_hook, ctx, rank, world);
 }
 
 MSFM_API int msfm_ctx_allreduce(msfm_ctx* ctx, double* buf_dev, size_t count, int op) {

@@ -94,3 +94,33 @@ def test_window_driver_matches_the_python_host(tmp_path, ctx):
     np.testing.assert_array_equal(st2["model"], arr2.cam_model)
     np.testing.assert_array_equal(st2["point"], pt2)
     assert st2["it"][0] == r2["num_iterations"] and st2["cost"][1] == r2["final_cost"] < r2["initial_cost"]
+
+
+def test_test_sfm_driver_with_several_contexts_in_one_process():
+    """SURVEY 8b (threading row): `msfm_ctx_create_multi(n_gpus)` - the reference's entry point stays ONE process
+    (test_sfm.cc:22-70), the library owns a context and a host thread per device and the communicator, and matching,
+    triangulation / reprojection and the bundle adjustment split inside it.  On the one-GPU test box the contexts share the
+    device (in-process reduction in rank order instead of ncclCommInitAll): `host/test_sfm --gpus N --share-device` with
+    N = 2 and 3 reproduces the one-context run - matching, verification, tracks and triangulation line for line, the bundle
+    adjustment to 1e-9 (its sums are formed in another order)."""
+    import re
+    exe = os.path.join(ROOT, "host", "test_sfm")
+    assert os.path.exists(exe), "host/test_sfm not built (run __graft_entry__.build())"
+
+    def run(n):
+        args = [exe] if n == 1 else [exe, "--gpus", str(n), "--share-device"]
+        out = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "test_sfm ok" in out.stdout, out.stdout + out.stderr
+        lines = out.stdout.splitlines()
+        final = [float(x) for x in next(l for l in lines if l.startswith("ba_final")).split()[1:]]
+        stages = [l for l in lines if re.match(r"(matching|verification|tracks|triangulation|seed pair|localisation):", l)]
+        return final, stages, out.stdout
+
+    ref, stages_ref, _ = run(1)
+    for n in (2, 3):
+        got, stages, text = run(n)
+        assert "contexts: %d (one device)" % n in text
+        assert stages == stages_ref                     # everything without a collective is bit for bit what one context gives
+        assert got[5] == ref[5]                         # the same number of LM iterations
+        for a, b in zip(got[:5], ref[:5]):
+            assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), (n, got, ref)

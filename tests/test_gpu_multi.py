@@ -1,0 +1,83 @@
+"""msfm_ctx_create_multi: several contexts in one process (include/msfm.h, last section) against the single context."""
+import numpy as np
+import pytest
+
+from metricsfm_amd import _abi as A
+from metricsfm_amd import capi, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_multi_ba_solve_matches_the_single_context(ctx, n):
+    """The points split inside the library over n contexts that share the test GPU (in-process reduction in rank order):
+    same accept / reject sequence, costs to 1e-8 (the run has rejected trial steps, whose costs amplify the order of the sums a
+    few hundred times; accepted ones agree to 1e-9), parameters to 1e-7 - on an aerial scene with GPS rows, frozen cameras and
+    points (window masks) and an elimination tree (168 cameras: the persistent panel chain runs on every context)."""
+    sc = scene.make_aerial_scene(168, 6000, seed=5, gps_sigma=0.5)
+    cm = np.ones(sc.n_cams, np.uint8); cm[::7] = 0
+    pm = np.ones(sc.n_points, np.uint8); pm[::11] = 0
+    kw = dict(gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams), cam_mutable=cm, pt_mutable=pm)
+    opts = capi.default_options(max_num_iterations=10)
+    a1 = A.BaArrays.from_scene(sc, **kw)
+    r1 = ctx.ba_solve(a1, opts)
+    mc = capi.MultiContext(n, devices=[0] * n)
+    assert mc.n == n
+    an = A.BaArrays.from_scene(sc, **kw)
+    rn = mc.ba_solve(an, opts)
+    assert rn["num_iterations"] == r1["num_iterations"] >= 5
+    np.testing.assert_array_equal(rn["iterations"]["step_is_successful"], r1["iterations"]["step_is_successful"])
+    np.testing.assert_allclose(rn["iterations"]["cost"], r1["iterations"]["cost"], rtol=1e-8)
+    assert (rn["iterations"]["step_is_successful"] == 0).any()
+    for name in ("cam_pose", "cam_model", "point"):
+        assert _rel(getattr(an, name), getattr(a1, name)) < 1e-7, name
+    # a second solve on the same multi context (hand-off state, scratch and barriers are reused)
+    an2 = A.BaArrays.from_scene(sc, **kw)
+    rn2 = mc.ba_solve(an2, opts)
+    np.testing.assert_array_equal(rn2["iterations"]["cost"], rn["iterations"]["cost"])
+    mc.close()
+
+
+def test_multi_tracks_and_matching_are_bit_identical(ctx):
+    """Triangulation / reprojection (tracks split by observation count) and matching (pair list split by M1 * M2) have no
+    collective: three contexts give exactly the arrays of one."""
+    sc = scene.add_features(scene.config_scene(1), 700)
+    R, t, c, fk = scene.cameras_for_tracks(sc)
+    order = np.argsort(sc.obs_pt, kind="stable")
+    k = np.bincount(sc.obs_pt, minlength=sc.n_points)
+    off = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
+    tr = A.TrackArrays(off, sc.obs_cam[order], sc.obs_xy[order], R, t, c, fk)
+    X1, mse1, ok1 = ctx.triangulate_midpoint(tr, 7.0, np.deg2rad(3.0))
+    D1, dm1, dk1 = ctx.triangulate_dlt(tr, 7.0, np.deg2rad(3.0))
+    m1 = ctx.reproject_mse(tr, X1)
+    mc = capi.MultiContext(3, devices=[0, 0, 0])
+    X3, mse3, ok3 = mc.triangulate_midpoint(tr, 7.0, np.deg2rad(3.0))
+    D3, dm3, dk3 = mc.triangulate_dlt(tr, 7.0, np.deg2rad(3.0))
+    m3 = mc.reproject_mse(tr, X1)
+    for a, b in ((X1, X3), (mse1, mse3), (ok1, ok3), (D1, D3), (dm1, dm3), (dk1, dk3), (m1, m3)):
+        np.testing.assert_array_equal(a, b)
+    assert ok1.sum() > 0.9 * len(ok1)
+    # matching: ragged images, an empty one
+    descs = [d.copy() for d in sc.desc[:6]]
+    descs[2] = descs[2][:311]
+    descs[5] = descs[5][:0]
+    pairs = np.array([(i, j) for i in range(5) for j in range(6) if i != j], np.int32)
+    ds = ctx.descset(descs)
+    res = ds.match_pairs(pairs, 0.6, 0.85)
+    na1, ng1 = res.counts()
+    codes, na3, ng3 = mc.match_pairs(descs, pairs, 0.6, 0.85)
+    np.testing.assert_array_equal(na1, na3); np.testing.assert_array_equal(ng1, ng3)
+    for p in range(len(pairs)):
+        np.testing.assert_array_equal(res.fetch(p)[0], codes[p])
+    assert ng1.sum() > 1000
+    res.close(); ds.close(); mc.close()
+
+
+def test_multi_refuses_mixed_device_lists():
+    with pytest.raises(capi.MsfmError) as e:
+        capi.MultiContext(3, devices=[0, 0, 1])
+    assert e.value.code == A.MSFM_E_INVAL

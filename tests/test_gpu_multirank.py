@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_sharded_ba_matches_single_rank(tmp_path, world, which, port):
     out = tmp_path / "mr.npz"
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env["MSFM_DEVICE_SHARE"] = str(world)   # the ranks share the one GPU of the test box: the persistent kernels leave each other room
     if which == "domains":
         env["MSFM_CHOL_DOMAINS"] = "2"
     if which.endswith("+fold"):   # the Schur products formed inside k_point (FoldTables) also on these small problems
