@@ -8,7 +8,7 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsfm.so")
+LIB_PATH = os.environ.get("MSFM_LIB") or os.path.join(_HERE, "libmsfm.so")   # (MSFM_LIB: a differently built libmsfm, for A/B timing)
 _lib = None
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)

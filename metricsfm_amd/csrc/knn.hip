@@ -311,6 +311,13 @@ __global__ __launch_bounds__(256, 2) void k_knn2_bf16(const PairTask* __restrict
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef MSFM_KNN_HITSTATS
+__device__ unsigned long long g_knn_hits[8][8];   // [train tile / 8][slots of a group of four with a candidate under the threshold]
+extern "C" __attribute__((visibility("default"))) int msfm_dbg_knn_hits(unsigned long long* out, int reset) {
+  if (reset) { static unsigned long long z[64]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_hits), z, sizeof z); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_knn_hits), 64 * sizeof(unsigned long long));
+}
+#endif
 struct PairTask8 {
   const signed char* train;  // [n_train][128]  a - 128
   const signed char* query;  // [n_query][128]  127 - b
@@ -328,7 +335,7 @@ __device__ __forceinline__ void flush_window8(u32& k0, u32& k1, u32& D0, int& I0
   k0 = k1 = 0xffffffffu;
 }
 
-__global__ __launch_bounds__(256, 3) void k_knn2_i8(const PairTask8* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+__global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
                                                      float ratio_good, float ratio_all, int32_t* __restrict__ code,
                                                      int* __restrict__ ids, float* __restrict__ sqd, int* __restrict__ n_all,
                                                      int* __restrict__ n_good) {
@@ -404,13 +411,18 @@ __global__ __launch_bounds__(256, 3) void k_knn2_i8(const PairTask8* __restrict_
     const unsigned char* la = lds_a[cur];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
-      i32x16 acca, accb, cc;
+      i32x16 acca, accb;
+#if defined(MSFM_KNN_NOFILTER) || !defined(MSFM_KNN_CC_LDS)
+      i32x16 cc;
+#endif
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const i32x4 nv = *reinterpret_cast<const i32x4*>(&lds_cin[cur][st * 32 + 8 * g + 4 * h]);
-        const i32x4 cv = *reinterpret_cast<const i32x4*>(&lds_c[cur][st * 32 + 8 * g + 4 * h]);
         acca[4 * g + 0] = nv.x; acca[4 * g + 1] = nv.y; acca[4 * g + 2] = nv.z; acca[4 * g + 3] = nv.w;
+#if defined(MSFM_KNN_NOFILTER) || !defined(MSFM_KNN_CC_LDS)
+        const i32x4 cv = *reinterpret_cast<const i32x4*>(&lds_c[cur][st * 32 + 8 * g + 4 * h]);
         cc[4 * g + 0] = cv.x; cc[4 * g + 1] = cv.y; cc[4 * g + 2] = cv.z; cc[4 * g + 3] = cv.w;
+#endif
       }
       accb = acca;
       const int row = st * 32 + r;
@@ -421,6 +433,91 @@ __global__ __launch_bounds__(256, 3) void k_knn2_i8(const PairTask8* __restrict_
         acca = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bqa[ks], acca, 0, 0, 0);
         accb = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bqb[ks], accb, 0, 0, 0);
       }
+      // Round 4: one compare per candidate.  A candidate whose m exceeds the m of the lane's current second best - of the
+      // window (ak1) and of the list over all rows so far (aD1) - cannot enter the top two, whatever its low bits: its key is
+      // not formed at all.  The thresholds are taken once per 32-row step (a stale threshold is only larger: conservative);
+      // the three selection operations run for a register slot only when some lane of the wave has a candidate under its
+      // threshold in one of the two query sets - late in the sweep that is one slot in five (a row enters a lane's top two
+      // with probability 2 / (rows seen + 1)).  MSFM_KNN_NOFILTER (compile time) keeps the unconditional form.
+#ifndef MSFM_KNN_NOFILTER
+#ifndef MSFM_KNN_GROUP
+#define MSFM_KNN_GROUP 4
+#endif
+      u32 thra = min(ak1 >> 9, aD1 >> 1), thrb = min(bk1 >> 9, bD1 >> 1);
+      // all the compares of a group of register slots first (their results are wave masks in scalar registers - no compare ->
+      // branch latency per slot), then the selection for the slots whose mask is not empty.  The key formation is volatile
+      // assembly so that it stays inside the conditional block (the compiler would otherwise hoist it in front of the tests).
+#ifdef MSFM_KNN_SPLIT_SETS
+      // (variant: one test per query set and slot - half the candidates per test, twice the tests)
+#pragma unroll
+      for (int g = 0; g < 16 / MSFM_KNN_GROUP; g++) {
+        unsigned long long ha[MSFM_KNN_GROUP], hb[MSFM_KNN_GROUP];
+#pragma unroll
+        for (int j = 0; j < MSFM_KNN_GROUP; j++) {
+          ha[j] = __builtin_amdgcn_ballot_w64((u32)acca[MSFM_KNN_GROUP * g + j] <= thra);
+          hb[j] = __builtin_amdgcn_ballot_w64((u32)accb[MSFM_KNN_GROUP * g + j] <= thrb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MSFM_KNN_GROUP; j++) {
+          const int reg = MSFM_KNN_GROUP * g + j;
+          if (ha[j] != 0ull) {
+            u32 keya;
+            asm volatile("v_lshl_or_b32 %0, %1, 9, %2" : "=v"(keya) : "v"(acca[reg]), "v"(cc[reg]));
+            const u32 na0 = min(ak0, keya);
+            ak1 = umed3(ak0, ak1, keya);
+            ak0 = na0;
+          }
+          if (hb[j] != 0ull) {
+            u32 keyb;
+            asm volatile("v_lshl_or_b32 %0, %1, 9, %2" : "=v"(keyb) : "v"(accb[reg]), "v"(cc[reg]));
+            const u32 nb0 = min(bk0, keyb);
+            bk1 = umed3(bk0, bk1, keyb);
+            bk0 = nb0;
+          }
+        }
+      }
+#else
+#pragma unroll
+      for (int g = 0; g < 16 / MSFM_KNN_GROUP; g++) {
+        unsigned long long hm[MSFM_KNN_GROUP];
+#ifdef MSFM_KNN_THR_GROUP
+        if (g > 0) { thra = min(ak1 >> 9, aD1 >> 1); thrb = min(bk1 >> 9, bD1 >> 1); }
+#endif
+#pragma unroll
+        for (int j = 0; j < MSFM_KNN_GROUP; j++)
+          hm[j] = __builtin_amdgcn_ballot_w64((u32)acca[MSFM_KNN_GROUP * g + j] <= thra) | __builtin_amdgcn_ballot_w64((u32)accb[MSFM_KNN_GROUP * g + j] <= thrb);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MSFM_KNN_HITSTATS
+        if (lane == 0) {
+          int nh = 0;
+          for (int j = 0; j < MSFM_KNN_GROUP; j++) nh += hm[j] != 0ull;
+          atomicAdd(&g_knn_hits[min(tile >> 3, 7)][nh], 1ull);
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < MSFM_KNN_GROUP; j++) {
+          if (hm[j] == 0ull) continue;
+          const int reg = MSFM_KNN_GROUP * g + j;
+#ifndef MSFM_KNN_CC_LDS
+          const u32 cw = (u32)cc[reg];
+#else
+          // (MSFM_KNN_CC_LDS: the row word fetched only here - sixteen registers less in the loop; measured slower: 1 707 against 1 750)
+          const u32 cw = (u32)lds_c[cur][st * 32 + 8 * (reg >> 2) + 4 * h + (reg & 3)];
+#endif
+          u32 keya, keyb;
+          asm volatile("v_lshl_or_b32 %0, %1, 9, %2" : "=v"(keya) : "v"(acca[reg]), "v"(cw));
+          asm volatile("v_lshl_or_b32 %0, %1, 9, %2" : "=v"(keyb) : "v"(accb[reg]), "v"(cw));
+          const u32 na0 = min(ak0, keya);
+          ak1 = umed3(ak0, ak1, keya);
+          ak0 = na0;
+          const u32 nb0 = min(bk0, keyb);
+          bk1 = umed3(bk0, bk1, keyb);
+          bk0 = nb0;
+        }
+      }
+#endif
+#else
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
         const u32 keya = ((u32)acca[reg] << 9) | (u32)cc[reg];
@@ -432,6 +529,7 @@ __global__ __launch_bounds__(256, 3) void k_knn2_i8(const PairTask8* __restrict_
         bk1 = umed3(bk0, bk1, keyb);
         bk0 = nb0;
       }
+#endif
     }
     if ((tile & 3) == 3 || tile == n_tiles - 1) {
       const int base = (tile & ~3) * TT;
@@ -805,6 +903,34 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
         accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqb[ks], accb, 0, 0, 0);
       }
       const int wbase = ((tile & 3) * 2 + st) * 32;
+#ifdef MSFM_KNN_F16_FILTER   // measured SLOWER here (670 against 694 Mmatches/s on 4 032 pairs: four keys per lane double the hit rate,
+                             // half of the slots still run their ten operations, and the masks cost 8 registers at two waves per SIMD)
+      // Round 4: one compare per candidate (see k_knn2_i8).  A value above the lane's fourth smallest - of the window (a3) and
+      // of the list over all rows so far (gva[3]) - cannot enter either list: its key is not formed.  The accumulator bits are
+      // compared raw against the threshold key with its index byte filled (conservative); the thresholds are taken once per
+      // 32-row step.  The lists, hence the certification bound "every unlisted row is >= the list's fourth key", are what the
+      // unconditional form gives.
+      const u32 ta = min(a3, gva[3]) | 255u, tb = min(b3, gvb[3]) | 255u;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        unsigned long long hm[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          hm[j] = __builtin_amdgcn_ballot_w64(__float_as_uint(acca[4 * g + j]) <= ta) | __builtin_amdgcn_ballot_w64(__float_as_uint(accb[4 * g + j]) <= tb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (hm[j] == 0ull) continue;
+          const int reg = 4 * g + j;
+          const u32 idx = (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
+          u32 ka, kb;
+          asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(ka) : "v"(acca[reg]), "v"(keymask), "v"(idx));
+          asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(kb) : "v"(accb[reg]), "v"(keymask), "v"(idx));
+          a3 = umed3(a2, a3, ka); a2 = umed3(a1, a2, ka); a1 = umed3(a0, a1, ka); a0 = min(a0, ka);
+          b3 = umed3(b2, b3, kb); b2 = umed3(b1, b2, kb); b1 = umed3(b0, b1, kb); b0 = min(b0, kb);
+        }
+      }
+#else
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
         const u32 idx = (u32)(wbase + (reg & 3) + 8 * (reg >> 2));
@@ -815,6 +941,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
         a3 = umed3(a2, a3, ka); a2 = umed3(a1, a2, ka); a1 = umed3(a0, a1, ka); a0 = min(a0, ka);
         b3 = umed3(b2, b3, kb); b2 = umed3(b1, b2, kb); b1 = umed3(b0, b1, kb); b0 = min(b0, kb);
       }
+#endif
     }
     if ((tile & 3) == 3 || tile == n_tiles - 1) {
       const int base = (tile & ~3) * TT + 4 * h;
