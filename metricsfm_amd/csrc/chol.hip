@@ -688,7 +688,11 @@ struct ChainJobs {
   int count, n_row_wg, n_bulk_wg, n_steps;   // n_steps: entries of task_first / 8
   ChainJob job[8];
 };
-struct ChainTask { short l, k, I, J; };   // launch step, job, 64-row blocks behind the diagonal block of step l (I >= J >= 1)
+// A bulk task.  type 0: trailing tile - apply the panel of step l - 1 of job k to the tile at row tiles (ti, tj) of the job.
+// type 1: corner piece - add the product of the job's panel of step l, rows of the B blocks I and J, to split `piece` of the
+// level's corner tile (I, J) (what k_corner_syrk does after the chains; `seq` = panels the piece has received before).
+// type 2: merge - M[corner tile (I, J)] += the sum of its pieces (k_merge_corners); l = panels of the tile, piece = its splits.
+struct ChainTask { short type, k, l, ti, tj, I, J, piece, seq, urgent, pad0, pad1; };
 struct ChainCtl {
   unsigned* rowflag;          // [jobs][tiles]
   unsigned* tileflag;         // [nblk][nblk] by absolute 64-blocks of M
@@ -701,6 +705,10 @@ struct ChainCtl {
   unsigned base;              // epoch << 12
   unsigned spin_limit;
   int nblk;                   // npad / 64
+  // the level's corner update folded into the launch (corners == nullptr: done by launches behind it)
+  double* corners;            // [8][ldc][ldc] the pieces
+  unsigned* cornerflag;       // [tile (I, J) of the B square][8]: panels a piece has received
+  int ldc, corner_b0;         // leading dimension of a piece; first row of the B square
   int* dbg;                   // [8] the first poll that gave up: site, workgroup, step, awaited count, seen value, index
 };
 __device__ __forceinline__ void chain_note(int* dbg, int site, int step, unsigned need, unsigned seen, int index) {
@@ -1096,36 +1104,55 @@ __device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, i
   const int lr = lane & 15, lk = lane >> 4;
   const int qrow = 32 * wr + lk, qcol = 32 * wc + lr;
   const int total = ctl.n_tasks;
-  int* const tkt = task + 13;   // the tickets of the three slots (stamps only)
-  struct Tile { int l, ri, rj, j0, urgent, flag0, ti, tj, nrt, tk; };
-  auto take = [&](int slot) {   // thread 0: next ticket -> task[slot * 4 ..]
+  int* const tkt = task + 37;   // the tickets of the three slots (stamps only)
+  const coh_buf cC = coh_make(ctl.corners ? ctl.corners : M, ctl.corners ? (size_t)8 * ctl.ldc * ctl.ldc * sizeof(double) : 8);
+  // l < 0: none.  For the products (types 0, 1): rows ri / rj of the panel at column j0; the tile lives at coff in M (type 0) or in
+  // the corner pieces (type 1, leading dimension cld; zero: its first panel, nothing to load); the counters it waits for are
+  // the eight row tiles of the panel (>= rneed) and its own history (hist >= hneed); done = the value its history gets
+  struct Tile { int l, type, ri, rj, j0, urgent, flag0, ti, tj, nrt, tk, rneed, cld, zero, hneed, dval, I, J, piece; size_t coff; unsigned* hist; };
+  auto take = [&](int slot) {   // thread 0: next ticket -> task[slot * 12 ..]
     const int t = atomicAdd(ctl.ticket, 1);
-    ChainTask q = {-1, 0, 0, 0};
+    ChainTask q = {0, 0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (t < total) q = ctl.tasks[t];
-    task[4 * slot] = q.l; task[4 * slot + 1] = q.k; task[4 * slot + 2] = q.I; task[4 * slot + 3] = q.J;
+    int* o = task + 12 * slot;
+    o[0] = q.l; o[1] = q.k; o[2] = q.type; o[3] = q.ti; o[4] = q.tj; o[5] = q.I; o[6] = q.J; o[7] = q.piece; o[8] = q.seq; o[9] = q.urgent;
     tkt[slot] = t;
     BSTAMP(t < total ? t : -1, 0);
   };
   auto decode = [&](int slot, Tile& T) {
-    T.l = task[4 * slot];
+    const int* o = task + 12 * slot;
+    T.l = o[0];
     T.tk = tkt[slot];
     if (T.l < 0) return;
-    const ChainJob& jb = jobs.job[task[4 * slot + 1]];
-    T.ti = 4 * (task[4 * slot + 2] + T.l); T.tj = 4 * (task[4 * slot + 3] + T.l);
-    T.ri = chain_row16(jb, T.ti); T.rj = chain_row16(jb, T.tj);
-    T.j0 = jb.begin + NB * (T.l - 1);
-    T.urgent = task[4 * slot + 3] == 1;
+    const ChainJob& jb = jobs.job[o[1]];
+    T.type = o[2]; T.ti = o[3]; T.tj = o[4]; T.I = o[5]; T.J = o[6]; T.piece = o[7];
     T.flag0 = jb.flag0; T.nrt = jb.nrt;
+    if (T.type == 2) return;   // (merge: handled outside the pipeline)
+    T.ri = chain_row16(jb, T.ti); T.rj = chain_row16(jb, T.tj);
+    T.urgent = o[9];
+    if (T.type == 0) {
+      T.j0 = jb.begin + NB * (T.l - 1);
+      T.rneed = T.l;
+      T.coff = (size_t)T.ri * ld + T.rj; T.cld = ld; T.zero = 0;
+      T.hist = &ctl.tileflag[(size_t)(T.ri / NB) * ctl.nblk + T.rj / NB];
+      T.hneed = T.l - 1; T.dval = T.l;
+    } else {
+      T.j0 = jb.begin + NB * T.l;
+      T.rneed = T.l + 1;
+      T.coff = (size_t)T.piece * ctl.ldc * ctl.ldc + (size_t)(NB * T.I) * ctl.ldc + NB * T.J; T.cld = ctl.ldc; T.zero = o[8] == 0;
+      T.hist = &ctl.cornerflag[(size_t)(T.I * (T.I + 1) / 2 + T.J) * 8 + T.piece];
+      T.hneed = o[8]; T.dval = o[8] + 1;
+    }
   };
   // the counters a tile waits for: the eight row tiles of its panel (lanes 0..7 of wave 0) and its own history (lane 8)
   auto flag_ptr = [&](const Tile& T, unsigned& need) -> const unsigned* {
     need = 0u;
     if (lane < 8) {
       const int tt = (lane < 4 ? T.ti : T.tj) + (lane & 3);
-      if (tt < T.nrt) { need = (unsigned)T.l; return &ctl.rowflag[T.flag0 + tt]; }
-    } else if (lane == 8 && T.l >= 2) {
-      need = (unsigned)(T.l - 1);
-      return &ctl.tileflag[(size_t)(T.ri / NB) * ctl.nblk + T.rj / NB];
+      if (tt < T.nrt) { need = (unsigned)T.rneed; return &ctl.rowflag[T.flag0 + tt]; }
+    } else if (lane == 8 && T.hneed >= 1) {
+      need = (unsigned)T.hneed;
+      return T.hist;
     }
     return nullptr;
   };
@@ -1138,12 +1165,16 @@ __device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, i
       va[it] = ld_coh2(cM, (size_t)(T.ri + r) * ld + T.j0 + c2);
       vb[it] = ld_coh2(cM, (size_t)(T.rj + r) * ld + T.j0 + c2);
     }
-    const size_t C = (size_t)T.ri * ld + T.rj;
+    if (T.zero) {
+      c00 = d4{0, 0, 0, 0}; c01 = c00; c10 = c00; c11 = c00;
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
-      const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
-      c00[i] = ld_coh(cM, p0); c01[i] = ld_coh(cM, p0 + 16); c10[i] = ld_coh(cM, p1); c11[i] = ld_coh(cM, p1 + 16);
+      const size_t p0 = T.coff + (size_t)(qrow + 4 * i) * T.cld + qcol;
+      const size_t p1 = T.coff + (size_t)(qrow + 16 + 4 * i) * T.cld + qcol;
+      if (T.type == 0) { c00[i] = ld_coh(cM, p0); c01[i] = ld_coh(cM, p0 + 16); c10[i] = ld_coh(cM, p1); c11[i] = ld_coh(cM, p1 + 16); }
+      else { c00[i] = ld_coh(cC, p0); c01[i] = ld_coh(cC, p0 + 16); c10[i] = ld_coh(cC, p1); c11[i] = ld_coh(cC, p1 + 16); }
     }
   };
   auto wait_flags = [&](const Tile& T) {   // wave 0, blocking
@@ -1151,10 +1182,44 @@ __device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, i
     const unsigned* f = flag_ptr(T, need);
     if (f) wait_count(f, ctl.base, need, ctl.spin_limit, fail, ctl.dbg, lane < 8 ? 4 : 5, T.l, lane);
   };
+  // M[corner tile] += the sum of its pieces, once every piece has all its panels (k_merge_corners' sums, in its order)
+  auto merge = [&](const Tile& T) {
+    const int len = T.l, ns = T.piece;
+    if (wave == 0 && lane < ns) {
+      const int cnt = len > lane ? (len - lane - 1) / ns + 1 : 0;
+      if (cnt > 0)
+        wait_count(&ctl.cornerflag[(size_t)(T.I * (T.I + 1) / 2 + T.J) * 8 + lane], ctl.base, (unsigned)cnt, ctl.spin_limit, fail, ctl.dbg, 6, len, lane);
+    }
+    __syncthreads();
+    const size_t pl = (size_t)ctl.ldc * ctl.ldc;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int e = u * 256 + tid, r = NB * T.I + (e >> 6), c = NB * T.J + (e & 63);
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = k < ns ? ld_coh(cC, (size_t)k * pl + (size_t)r * ctl.ldc + c) : 0.0;
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) sacc += v[k];
+      M[(size_t)(ctl.corner_b0 + r) * ld + ctl.corner_b0 + c] += sacc;
+    }
+    __syncthreads();
+  };
+  // the merges sit behind every product in the list: from the first one on a workgroup only merges
+  auto merge_loop = [&](Tile T) {
+    for (;;) {
+      merge(T);
+      if (tid == 0) take(0);
+      __syncthreads();
+      decode(0, T);
+      if (T.l < 0) return;
+    }
+  };
   // Three tasks in flight: `cur` (operands in registers, then in LDS under the products), `nxt` (known; its counters asked
   // for a round earlier; fetched under cur's products when they are there) and `nn` (ticket taken, counters asked for).
   Tile cur, nxt, nn;
-  int pending = -1, pending_l = 0;   // (thread 0) tileflag index whose counter is still to be written
+  unsigned* pending = nullptr;
+  int pending_l = 0;   // (thread 0) the counter that is still to be written, and its value
   unsigned fneed = 0u, fval = 0u;    // (wave 0) the counter of nxt this lane looks at, as read a round ago
   const unsigned* fp = nullptr;
   auto ask = [&](const Tile& T) {     // wave 0: read the lane's counter of T without waiting for it
@@ -1164,12 +1229,19 @@ __device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, i
       if (fp) fval = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
-  if (tid == 0) { take(0); take(1); }
+  if (tid == 0) take(0);
   __syncthreads();
   decode(0, cur);
-  decode(1, nxt);
   if (cur.l < 0) return;
-  if (wave == 0) { wait_flags(cur); ask(nxt); }
+  if (cur.type == 2) { merge_loop(cur); return; }
+  if (tid == 0) take(1);
+  __syncthreads();
+  decode(1, nxt);
+  const auto is_product = [](const Tile& T) { return T.l >= 0 && T.type != 2; };
+  Tile mtask;          // the first merge task this workgroup drew (handled when the products before it are done)
+  mtask.l = -1;
+  if (nxt.l >= 0 && nxt.type == 2) { mtask = nxt; nxt.l = -1; }
+  if (wave == 0) { wait_flags(cur); if (is_product(nxt)) ask(nxt); }
   __syncthreads();
   BSTAMP(cur.tk, 1);
   fetch(cur);
@@ -1188,29 +1260,30 @@ __device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, i
       const bool ok = nxt.l < 0 || !fp || count_ready(fval, ctl.base, fneed);
       const bool all = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
       if (lane == 0) {
-        task[12] = all ? 1 : 0;
+        task[36] = all ? 1 : 0;
         // a third ticket only when the second one can go ahead: a workgroup that is going to wait for its next tile must not
         // sit on another one meanwhile (-2: not taken yet)
-        if (all && nxt.l >= 0) take(2); else task[8] = nxt.l >= 0 ? -2 : -1;
+        if (all && nxt.l >= 0) take(2); else task[24] = nxt.l >= 0 ? -2 : -1;
       }
     }
     __syncthreads();   // B1: the operands are in LDS; the stores of the tile before are out (every wave waited above)
-    if (tid == 0 && pending >= 0) {
-      __hip_atomic_store(&ctl.tileflag[pending], ctl.base + (unsigned)pending_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pending = -1;
+    if (tid == 0 && pending) {
+      __hip_atomic_store(pending, ctl.base + (unsigned)pending_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pending = nullptr;
     }
-    const bool ready = task[12] != 0 && nxt.l >= 0;
+    const bool ready = task[36] != 0 && nxt.l >= 0;
     if (ready) { fetch(nxt); BSTAMP(nxt.tk, 1); }   // in flight under the products below
     decode(2, nn);
+    if (nn.l >= 0 && nn.type == 2) { mtask = nn; nn.l = -1; }   // a merge: no more products for this workgroup
     if (wave == 0 && nn.l >= 0) ask(nn);
     quad_abt(As, Bs, wr, wc, lr, lk, a00, a01, a10, a11);
     {
-      const size_t C = (size_t)cur.ri * ld + cur.rj;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const size_t p0 = C + (size_t)(qrow + 4 * i) * ld + qcol;
-        const size_t p1 = C + (size_t)(qrow + 16 + 4 * i) * ld + qcol;
-        st_coh(cM, p0, a00[i]); st_coh(cM, p0 + 16, a01[i]); st_coh(cM, p1, a10[i]); st_coh(cM, p1 + 16, a11[i]);
+        const size_t p0 = cur.coff + (size_t)(qrow + 4 * i) * cur.cld + qcol;
+        const size_t p1 = cur.coff + (size_t)(qrow + 16 + 4 * i) * cur.cld + qcol;
+        if (cur.type == 0) { st_coh(cM, p0, a00[i]); st_coh(cM, p0 + 16, a01[i]); st_coh(cM, p1, a10[i]); st_coh(cM, p1 + 16, a11[i]); }
+        else { st_coh(cC, p0, a00[i]); st_coh(cC, p0 + 16, a01[i]); st_coh(cC, p1, a10[i]); st_coh(cC, p1 + 16, a11[i]); }
       }
     }
     const bool last = nxt.l < 0;
@@ -1218,18 +1291,17 @@ __device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, i
     __syncthreads();   // B2: every wave's part of the tile is issued (urgent: out); everybody is done with As / Bs and task[]
     BSTAMP(cur.tk, 2);
     if (tid == 0) {
-      const int fi = (cur.ri / NB) * ctl.nblk + cur.rj / NB;
-      if (cur.urgent || last) __hip_atomic_store(&ctl.tileflag[fi], ctl.base + (unsigned)cur.l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else { pending = fi; pending_l = cur.l; }
+      if (cur.urgent || last) __hip_atomic_store(cur.hist, ctl.base + (unsigned)cur.dval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else { pending = cur.hist; pending_l = cur.dval; }
     }
     if (last) break;
     if (!ready) {   // (uniform) the counters were not there a round ago: wait for them now
       // ... but never with a counter of our own unpublished: what nxt waits for may hang on it (the same tile a step later)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0 && pending >= 0) {
-        __hip_atomic_store(&ctl.tileflag[pending], ctl.base + (unsigned)pending_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending = -1;
+      if (tid == 0 && pending) {
+        __hip_atomic_store(pending, ctl.base + (unsigned)pending_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = nullptr;
       }
       if (wave == 0) wait_flags(nxt);
       __syncthreads();
@@ -1241,17 +1313,19 @@ __device__ __forceinline__ void chain_bulk(double* __restrict__ M, coh_buf cM, i
       if (tid == 0) take(2);
       __syncthreads();
       decode(2, nn);
-      if (wave == 0) ask(nn);
+      if (nn.l >= 0 && nn.type == 2) { mtask = nn; nn.l = -1; }
+      if (wave == 0 && nn.l >= 0) ask(nn);
     }
     nxt = nn;
   }
+  if (mtask.l >= 0) { __syncthreads(); merge_loop(mtask); }
 }
 
 __global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, int n, double* __restrict__ Dinv, double* __restrict__ Ldiag,
                                                 int* fail, ChainJobs jobs, ChainCtl ctl) {
   __shared__ double sm[80 + 64 * DV + 2 * 64 * LDT];
   __shared__ double d00s[256];
-  __shared__ int task[16];
+  __shared__ int task[40];   // three ticket slots of 12 words, the 'next is ready' word, the three tickets
   double* As = sm + 80 + 64 * DV;
   double* Bs = As + 64 * LDT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1783,7 +1857,55 @@ struct ChainLaunch {
   int task_off = 0, n_tasks = 0;   // the launch's tiles in ws->tasks
   int steps = 0;        // panel steps on its critical path (for the timers)
   bool usable = false;
+  bool corner_folded = false;   // the level's corner update runs as tasks of the launch
+  int corner_b0 = 0;
 };
+// The deferred corner update of a tree level: per 64-row block of the B square (rows from b0 on) the panels of the level that lie
+// under the block's node, and into how many pieces a tile's panels are cut (k_corner_syrk / the corner tasks of k_chain).
+struct CornerPlan { CornerRanges R; int nB64 = 0, target = 1, smax = 1, sb = 0; };
+static void corner_plan(const msfm_chol_plan* plan, int lv, int nrows, CornerPlan& C) {
+  const int n_levels = plan->n_levels;
+  const msfm_chol_level& L = plan->level[lv];
+  const int K = L.K, sb = L.b0;
+  C.sb = sb;
+  C.nB64 = cdiv(nrows - sb, 64);
+  const int nB64 = std::min(C.nB64, MSFM_CORNER_MAX_BLOCKS);
+  CornerRanges& R = C.R;
+  for (int I = 0; I < nB64; I++) {
+    const int row = sb + 64 * I;
+    int lo = 0, hi = 0x7fffffff;   // leaf interval of the block's node; the root covers everything
+    for (int h = lv + 1; h < n_levels; h++)
+      for (int q = 0; q < plan->level[h].K; q++)
+        if (row >= plan->level[h].node[q].begin && row < plan->level[h].node[q].end) { lo = plan->level[h].node[q].leaf_lo; hi = plan->level[h].node[q].leaf_hi; }
+    int plo = 0, phi = 0;
+    bool any = false;
+    for (int q = 0; q < K; q++)
+      if (L.node[q].leaf_lo >= lo && L.node[q].leaf_hi <= hi) { if (!any) plo = L.node[q].begin / NB; phi = L.node[q].end / NB; any = true; }
+    R.plo[I] = (short)plo; R.phi[I] = (short)phi;
+  }
+  // panels per piece: the smallest count with which the pieces cover the chip about once
+  int target = 1, smax = 1;
+  for (;; target++) {
+    long wgs = 0;
+    smax = 1;
+    for (int I = 0; I < nB64; I++)
+      for (int J = 0; J <= I; J++) {
+        const int sp = corner_splits(std::min((int)R.phi[I], (int)R.phi[J]) - std::max((int)R.plo[I], (int)R.plo[J]), target);
+        wgs += sp;
+        smax = std::max(smax, sp);
+      }
+    if (wgs <= 560 || target >= 64) break;
+  }
+  static const int target_env = getenv("MSFM_CORNER_TARGET") ? atoi(getenv("MSFM_CORNER_TARGET")) : 0;
+  if (target_env > 0) {
+    target = target_env; smax = 1;
+    for (int I = 0; I < nB64; I++)
+      for (int J = 0; J <= I; J++)
+        smax = std::max(smax, corner_splits(std::min((int)R.phi[I], (int)R.phi[J]) - std::max((int)R.plo[I], (int)R.plo[J]), target));
+  }
+  C.target = target; C.smax = smax;
+}
+
 struct msfm_chol_ws {
   msfm_ctx* ctx = nullptr;
   int npad = 0;
@@ -1804,7 +1926,7 @@ int msfm_chol_ws_create(msfm_ctx* ctx, int npad, msfm_chol_ws** out) {
   std::unique_ptr<msfm_chol_ws> w(new msfm_chol_ws());
   w->ctx = ctx; w->npad = npad;
   const size_t nt16 = npad / 16, nb = npad / NB;
-  HIP_TRY(ctx, w->flags.alloc(8 * nt16 + nb * nb));
+  HIP_TRY(ctx, w->flags.alloc(8 * nt16 + nb * nb + 8 * (nb * (nb + 1) / 2)));   // ... then cornerflag [tiles of the B square][8]
   HIP_TRY(ctx, w->hb.alloc(2 * (size_t)npad * NB));
   HIP_TRY(ctx, w->tickets.alloc(16));   // eight ticket counters, then the eight words of the give-up note
   HIP_TRY(ctx, hipMemsetAsync(w->tickets.p, 0, sizeof(int) * 16, ctx->stream));
@@ -1891,13 +2013,69 @@ static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
           const int nA = J.job[k].nA64 - l, nB = J.job[k].nB64;
           for (int Jc = 1; Jc < nA; Jc++)
             for (int I = Jc; I < nA + nB; I++) {
-              lt.push_back(Keyed{10 * l + slope * (Jc - 1), ChainTask{(short)l, (short)k, (short)I, (short)Jc}});
+              lt.push_back(Keyed{10 * l + slope * (Jc - 1), ChainTask{0, (short)k, (short)l, (short)(4 * (I + l)), (short)(4 * (Jc + l)), (short)I, (short)Jc, 0, 0,
+                                                                           (short)(Jc == 1 ? 1 : 0), 0, 0}});
               step_tasks++;
             }
         }
         max_step_tasks = std::max(max_step_tasks, step_tasks);
       }
+      // the level's corner update as tasks of the same launch (instead of k_corner_syrk / k_merge_corners behind it):
+      // for every tile of the B square and every piece of its panel list one task per panel, in the panel order of k_corner_syrk
+      // (the pieces' sums are then bit for bit those of the launches); a piece's tasks get non-decreasing keys, so the list stays
+      // a linear extension of the dependencies; the merges come last.
+      // Measured at config 3's tree (scripts/chol_probe 3137 . plan): 0.535 ms folded against 0.456 ms with the two launches - the
+      // 3 140 per-panel corner tasks (each reads and writes its 32 KB piece: k_corner_syrk keeps it in registers over a piece's
+      // panels) more than double the bulk work and sit in front of the next steps' urgent tiles.  So the launches stay the
+      // default; MSFM_CORNER_FOLD=1 takes this path (bit-identical factor, checked by the probe).
+      static const bool corner_launches = getenv("MSFM_CORNER_FOLD") == nullptr;
+      std::vector<Keyed> merges;
+      if (lv < n_levels && !corner_launches && plan->corners && J.count > 0) {
+        CornerPlan CP;
+        corner_plan(plan, lv, nrows, CP);
+        if (CP.nB64 <= MSFM_CORNER_MAX_BLOCKS && CP.nB64 <= 180) {
+          L.corner_folded = true;
+          L.corner_b0 = CP.sb;
+          auto job_of_panel = [&](int p, int& k, int& l) {
+            for (k = 0; k < J.count; k++)
+              if (64 * p >= J.job[k].begin && 64 * p < J.job[k].begin + 64 * J.job[k].P) { l = p - J.job[k].begin / 64; return true; }
+            return false;
+          };
+          auto row_tile = [&](const ChainJob& jb, int row) {   // the job's tile index of a row of range B (-1: not among its rows)
+            int t = 4 * jb.nA64;
+            for (int g = 0; g < jb.nseg; g++) {
+              if (row >= jb.sb0[g] && row < jb.sb0[g] + 16 * jb.sn16[g]) return t + (row - jb.sb0[g]) / 16;
+              t += jb.sn16[g];
+            }
+            return -1;
+          };
+          for (int I = 0; I < CP.nB64 && L.corner_folded; I++)
+            for (int Jc = 0; Jc <= I && L.corner_folded; Jc++) {
+              const int p_begin = std::max((int)CP.R.plo[I], (int)CP.R.plo[Jc]), np = std::min((int)CP.R.phi[I], (int)CP.R.phi[Jc]);
+              const int len = np - p_begin;
+              if (len <= 0) continue;
+              const int ns = corner_splits(len, CP.target);
+              for (int r = 0; r < ns; r++) {
+                int key = 0, seq = 0;
+                for (int pp = p_begin + r; pp < np; pp += ns, seq++) {
+                  int k = 0, l = 0;
+                  if (!job_of_panel(pp, k, l)) { L.corner_folded = false; break; }
+                  const int ti = row_tile(J.job[k], CP.sb + 64 * I), tj = row_tile(J.job[k], CP.sb + 64 * Jc);
+                  if (ti < 0 || tj < 0) { L.corner_folded = false; break; }
+                  key = std::max(key, 10 * (l + 1) + 14);
+                  lt.push_back(Keyed{key, ChainTask{1, (short)k, (short)l, (short)ti, (short)tj, (short)I, (short)Jc, (short)r, (short)seq, 0, 0, 0}});
+                }
+              }
+              merges.push_back(Keyed{0x7fffffff, ChainTask{2, 0, (short)len, 0, 0, (short)I, (short)Jc, (short)ns, 0, 0, 0, 0}});
+            }
+          if (!L.corner_folded) {   // (cannot happen with the trees choose_dissection builds; keep the launches then)
+            lt.erase(std::remove_if(lt.begin(), lt.end(), [](const Keyed& q) { return q.t.type != 0; }), lt.end());
+            merges.clear();
+          }
+        }
+      }
       std::stable_sort(lt.begin(), lt.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+      for (const Keyed& q : merges) lt.push_back(q);
       for (const Keyed& q : lt) table.push_back(q.t);
       L.n_tasks = (int)lt.size();
     }
@@ -1930,7 +2108,8 @@ static unsigned chain_spin_limit() {
   return v;
 }
 
-static int chain_launch(msfm_chol_ws* ws, const ChainLaunch& L, double* M, int npad, int n, double* Dinv, double* Ldiag, int* fail) {
+static int chain_launch(msfm_chol_ws* ws, const ChainLaunch& L, double* M, int npad, int n, double* Dinv, double* Ldiag, int* fail, double* corners,
+                        int ldc) {
   msfm_ctx* ctx = ws->ctx;
   ChainCtl c;
   const size_t nt16 = npad / 16, nb = npad / NB;
@@ -1947,6 +2126,9 @@ static int chain_launch(msfm_chol_ws* ws, const ChainLaunch& L, double* M, int n
   c.base = (++ws->flag_epoch & 0xFFFFFu) << 12;   // per LAUNCH: the launches of one solve reuse the rowflag slots of their jobs
   c.spin_limit = chain_spin_limit();
   c.nblk = (int)nb;
+  c.corners = L.corner_folded ? corners : nullptr;
+  c.cornerflag = ws->flags.p + 8 * nt16 + nb * nb;
+  c.ldc = ldc; c.corner_b0 = L.corner_b0;
   c.dbg = ws->tickets.p + 8;
   hipLaunchKernelGGL(k_chain, dim3(L.jobs.n_row_wg + L.jobs.n_bulk_wg), dim3(256), 0, ctx->stream, M, npad, n, Dinv, Ldiag, fail, L.jobs, c);
   return MSFM_OK;
@@ -2021,7 +2203,7 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
       chain_timer.count = 0;
       const bool lv_chain = use_chain && ws->launch[lv].usable;
       if (lv_chain) {
-        MSFM_TRY(chain_launch(ws, ws->launch[lv], M, npad, n, Dinv, Ldiag, fail));
+        MSFM_TRY(chain_launch(ws, ws->launch[lv], M, npad, n, Dinv, Ldiag, fail, plan->corners, ldc));
         chain_timer.count = ws->launch[lv].steps;   // (counted in panel steps, so that a step's time compares with the launch chain's)
       }
       for (int l = 0; l < maxp && !lv_chain; l++) {
@@ -2052,46 +2234,16 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
         chain_timer.count++;
       }
       chain_timer.stop();
-      if (maxp > 0) {
+      if (maxp > 0 && !(lv_chain && ws->launch[lv].corner_folded)) {
         KTimer t(ctx, "chol_corner_syrk");
         t.count = 2;
         const int nB64 = cdiv(nrows - sb, 64), ntile = nB64 * (nB64 + 1) / 2;
         if (nB64 > MSFM_CORNER_MAX_BLOCKS)   // (choose_dissection never picks such a tree: checked before anything is launched)
           return msfm_set_error(ctx, MSFM_E_INVAL, "cholesky: separator part too large for the corner update (%d blocks)", nB64);
-        // per 64-row block of the square: the panels of this level under the block's tree node (the root: all of them)
-        CornerRanges R;
-        for (int I = 0; I < nB64; I++) {
-          const int row = sb + 64 * I;
-          int lo = 0, hi = 0x7fffffff;   // leaf interval of the block's node; the root covers everything
-          for (int h = lv + 1; h < n_levels; h++)
-            for (int q = 0; q < plan->level[h].K; q++)
-              if (row >= plan->level[h].node[q].begin && row < plan->level[h].node[q].end) { lo = plan->level[h].node[q].leaf_lo; hi = plan->level[h].node[q].leaf_hi; }
-          int plo = 0, phi = 0;
-          bool any = false;
-          for (int q = 0; q < K; q++)
-            if (L.node[q].leaf_lo >= lo && L.node[q].leaf_hi <= hi) { if (!any) plo = L.node[q].begin / NB; phi = L.node[q].end / NB; any = true; }
-          R.plo[I] = (short)plo; R.phi[I] = (short)phi;
-        }
-        // panels per workgroup: the smallest count with which the pieces (two workgroups fit on a CU) cover the chip about once
-        int target = 1, smax = 1;
-        for (;; target++) {
-          long wgs = 0;
-          smax = 1;
-          for (int I = 0; I < nB64; I++)
-            for (int J = 0; J <= I; J++) {
-              const int sp = corner_splits(std::min((int)R.phi[I], (int)R.phi[J]) - std::max((int)R.plo[I], (int)R.plo[J]), target);
-              wgs += sp;
-              smax = std::max(smax, sp);
-            }
-          if (wgs <= 560 || target >= 64) break;
-        }
-        static const int target_env = getenv("MSFM_CORNER_TARGET") ? atoi(getenv("MSFM_CORNER_TARGET")) : 0;
-        if (target_env > 0) {
-          target = target_env; smax = 1;
-          for (int I = 0; I < nB64; I++)
-            for (int J = 0; J <= I; J++)
-              smax = std::max(smax, corner_splits(std::min((int)R.phi[I], (int)R.phi[J]) - std::max((int)R.plo[I], (int)R.plo[J]), target));
-        }
+        CornerPlan CP;
+        corner_plan(plan, lv, nrows, CP);
+        const CornerRanges& R = CP.R;
+        const int target = CP.target, smax = CP.smax;
         hipLaunchKernelGGL(k_corner_syrk, dim3(ntile * smax), dim3(256), 0, s, M, npad, sb, target, smax, plan->corners, ldc, R);
         hipLaunchKernelGGL(k_merge_corners, dim3(4 * ntile), dim3(256), 0, s, M, npad, sb, nB64, plan->corners, ldc, target, R);
       }
@@ -2102,7 +2254,7 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
   root_timer.count = 0;
   const bool root_chain = use_chain && ws->launch[n_levels].usable;
   if (root_chain) {
-    MSFM_TRY(chain_launch(ws, ws->launch[n_levels], M, npad, n, Dinv, Ldiag, fail));
+    MSFM_TRY(chain_launch(ws, ws->launch[n_levels], M, npad, n, Dinv, Ldiag, fail, nullptr, 0));
     root_timer.count = ws->launch[n_levels].steps;
   }
   for (int t0 = t_first; t0 < n && !root_chain; t0 += NB) {
