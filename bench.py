@@ -360,11 +360,11 @@ def main():
         except Exception:
             pass
 
-    # matrix-pipe utilisation from the SQ counter passes (scripts/mfma_util.sh -> profiles/r03_mfma_util.json): attached to the
+    # matrix-pipe utilisation from the SQ counter passes (scripts/mfma_util.sh -> profiles/r04_mfma_util.json): attached to the
     # rooflines of the MFMA kernels, with a note when the counters were collected with other kernel sources
     util = {}
     try:
-        util = json.load(open(os.path.join(ROOT, "profiles", "r03_mfma_util.json")))
+        util = json.load(open(os.path.join(ROOT, "profiles", "r04_mfma_util.json")))
     except Exception:
         pass
 
@@ -375,7 +375,7 @@ def main():
         for k in ("mfma_busy", "valu_busy", "valu_per_mfma"):
             if k in u:
                 rl[k] = u[k]
-        rl["mfma_busy_source"] = "profiles/r03_mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))" + (
+        rl["mfma_busy_source"] = "profiles/r04_mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))" + (
             "" if util.get("_kernel_source_hash") == kernel_source_hash() else "; collected with other kernel sources (%s)" % util.get("_kernel_source_hash"))
 
     attach_util(rooflines.get("chol_panel_mfma"), "ba")

@@ -1,4 +1,4 @@
-"""Summarises the SQ counter passes of scripts/mfma_util.sh into profiles/r03_mfma_util.json.
+"""Summarises the SQ counter passes of scripts/mfma_util.sh into profiles/r04_mfma_util.json.
 
 Per kernel (mean over its launches in each pass):
   cycles          = GRBM_GUI_ACTIVE / 8           (rocprofv3 sums the 8 XCDs; MI355X_MICROARCH.md "DVFS give-back")
@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-KERNELS = {"knn_i8": "k_knn2_i8", "knn_f16": "k_knn2_f16", "ba": "k_panel_v2"}
+KERNELS = {"knn_i8": "k_knn2_i8", "knn_f16": "k_knn2_f16", "ba": "k_chain"}
 
 
 def main():
@@ -49,7 +49,7 @@ def main():
         res[wl] = e
     res["_source"] = ("rocprofv3 --pmc passes of scripts/mfma_util.sh (one counter group per pass, program directly after --): "
                       "scripts/knn_only.py 48 (2256 pairs, int8), scripts/knn_float_only.py (552 pairs, f16), "
-                      "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-matching --no-extras (k_panel_v2)")
+                      "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-matching --no-extras (k_chain: the persistent panel chain)")
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metricsfm_amd", "csrc")

@@ -15,7 +15,7 @@ import shutil
 import sys
 
 CLASSES = {  # bench.py kernel class -> substrings of the kernel names it launches
-    "chol_panel_mfma": ["k_panel_v2"],
+    "chol_panel_mfma": ["k_chain", "k_panel_v2"],
     "ba_schur_pairs": ["k_pairs<"],          # (not devsetup::k_pairs_of_points, the list builders of msfm_ba_create)
     "ba_point": ["k_point("],                # (not devsetup::k_point_keys / k_point_lengths)
     "ba_backsub": ["k_backsub"],
