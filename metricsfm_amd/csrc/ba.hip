@@ -1479,17 +1479,88 @@ static void graph_levels(const CamGraph& G, const std::vector<char>& in, int sta
   }
 }
 
-// Splits the node set `in` into a, b, sep (no edge between a and b).  Nodes are ordered by the
-// difference of their hop distances to two far-apart nodes s and t; a prefix of that order is side a,
-// the rest side b, and the separator is the smaller of the two one-hop boundaries.  (Level sets of the
-// distance to ONE node give L-shaped cuts on grid-like camera graphs; the difference gives the
-// straight bisector.)  Among a few cut positions around the median the one with the smallest
-// max(|a|, |b|) + |sep| wins.  false when the set cannot be split.
-static bool graph_bisect(const CamGraph& G, const std::vector<char>& in, std::vector<char>& a, std::vector<char>& b, std::vector<char>& sep) {
+// Smallest vertex cover of the bipartite graph between the two one-hop boundaries L and R of a cut (Koenig: from a
+// maximum matching, found by augmenting paths; Z = what alternating paths reach from the unmatched nodes of L; the cover
+// is (L \ Z) + (R & Z)).  Removing the cover separates the sides, and it is never larger than the smaller boundary.
+static void boundary_cover(const CamGraph& G, const std::vector<int>& L, const std::vector<int>& R, const std::vector<int>& r_index /*node -> position in R or -1*/,
+                           std::vector<int>& cover) {
+  const int nl = (int)L.size(), nr = (int)R.size();
+  std::vector<std::vector<int>> e(nl);
+  for (int l = 0; l < nl; l++)
+    for (int v : G.adj[L[l]]) if (r_index[v] >= 0) e[l].push_back(r_index[v]);
+  std::vector<int> ml(nl, -1), mr(nr, -1), seen(nr, -1), par(nr, -1);
+  for (int l = 0; l < nl; l++)   // greedy start
+    for (int r : e[l]) if (mr[r] < 0) { mr[r] = l; ml[l] = r; break; }
+  std::vector<std::pair<int, size_t>> st;
+  int stamp = 0;   // what a failed search has visited stays dead until the matching changes
+  for (int l0 = 0; l0 < nl; l0++) {
+    if (ml[l0] >= 0) continue;
+    // iterative depth-first search for an augmenting path from l0; par[r] = the L node r was reached from
+    st.clear();
+    st.push_back({l0, 0});
+    int end = -1;
+    while (!st.empty() && end < 0) {
+      auto& top = st.back();
+      const int l = top.first;
+      if (top.second == e[l].size()) { st.pop_back(); continue; }
+      const int r = e[l][top.second++];
+      if (seen[r] == stamp) continue;
+      seen[r] = stamp;
+      par[r] = l;
+      if (mr[r] < 0) end = r; else st.push_back({mr[r], 0});
+    }
+    if (end >= 0) stamp++;
+    while (end >= 0) { const int l = par[end], prev = ml[l]; ml[l] = end; mr[end] = l; end = prev; }
+  }
+  std::vector<char> zl(nl, 0), zr(nr, 0);
+  std::vector<int> q;
+  for (int l = 0; l < nl; l++) if (ml[l] < 0) { zl[l] = 1; q.push_back(l); }
+  while (!q.empty()) {
+    const int l = q.back();
+    q.pop_back();
+    for (int r : e[l]) {
+      if (zr[r]) continue;
+      zr[r] = 1;
+      const int l2 = mr[r];
+      if (l2 >= 0 && !zl[l2]) { zl[l2] = 1; q.push_back(l2); }
+    }
+  }
+  cover.clear();
+  for (int l = 0; l < nl; l++) if (!zl[l]) cover.push_back(L[l]);
+  for (int r = 0; r < nr; r++) if (zr[r]) cover.push_back(R[r]);
+}
+
+static long steps64(double cams, int tail = 0) { return cdiv(6 * (long)std::ceil(cams) + tail, 64); }
+// Estimated chain (64-column steps, 3 per level for its corner update) of a node of k cameras that will be cut `d` more
+// times, if its separators shrink like those of a planar graph (the parent's, ns of total, scaled by sqrt(k / total)).
+static double chain_estimate(double k, int d, double ns, double total) {
+  if (d <= 0) return (double)steps64(k);
+  const double s = ns * std::sqrt(std::max(k, 1.0) / std::max(total, 1.0));
+  return chain_estimate(std::max((k - s) / 2, 1.0), d - 1, s, k) + (double)steps64(s) + 3;
+}
+
+// The cut order of a node set: nodes sorted by the difference of their hop distances to two far-apart nodes s and t,
+// smoothed twice over the neighbours (hop distances alone take a handful of values on camera graphs with long-range
+// overlap: the order inside a value would be arbitrary).  (Level sets of the distance to ONE node give L-shaped cuts on
+// grid-like camera graphs; the difference gives the straight bisector.)  pos = place in the order, lo / hi = smallest and
+// largest place among a node's neighbours in the set: a prefix [0, m) touches the rest through the nodes with hi >= m,
+// the rest touches the prefix through those with lo < m, so a cut position costs O(nodes + boundary edges), not O(edges).
+struct CutPrep {
+  std::vector<char> in;
+  int kind = 0;   // 0: cannot be split, 1: disconnected (a = the reached component, b = the rest, no separator), 2: ordered
+  std::vector<char> a, b;
+  std::vector<int> order, pos, lo, hi;
+  struct Cand { int na, nb, nsep; std::vector<signed char> lab; };   // a cut position, evaluated (0: a, 1: b, 2: separator)
+  std::vector<Cand> cands;
+  bool cands_done = false;
+};
+static void cut_prepare(const CamGraph& G, const std::vector<char>& in, CutPrep& P) {
   const int n = G.n;
+  P.in = in;
+  P.kind = 0;
   int start = -1, total = 0;
   for (int i = 0; i < n; i++) if (in[i]) { if (start < 0) start = i; total++; }
-  if (total < 3) return false;
+  if (total < 3) return;
   std::vector<int> ls(n), lt(n);
   for (int it = 0; it < 4; it++) {  // pseudo-peripheral node: walk to the farthest node a few times
     graph_levels(G, in, start, ls);
@@ -1497,61 +1568,111 @@ static bool graph_bisect(const CamGraph& G, const std::vector<char>& in, std::ve
     for (int i = 0; i < n; i++) if (in[i] && ls[i] > ls[far]) far = i;
     if (far == start) break;
     start = far;
+    if (it == 3) graph_levels(G, in, start, ls);
   }
-  graph_levels(G, in, start, ls);
   int t = start, unreached = 0;
   for (int i = 0; i < n; i++) if (in[i]) { if (ls[i] < 0) unreached++; else if (ls[i] > ls[t]) t = i; }
   if (unreached) {
-    // disconnected: the reached component and the rest need no separator at all
-    a.assign(n, 0); b.assign(n, 0); sep.assign(n, 0);
-    for (int i = 0; i < n; i++) if (in[i]) (ls[i] >= 0 ? a : b)[i] = 1;
-    return true;
+    P.a.assign(n, 0); P.b.assign(n, 0);
+    for (int i = 0; i < n; i++) if (in[i]) (ls[i] >= 0 ? P.a : P.b)[i] = 1;
+    P.kind = 1;
+    return;
   }
-  if (t == start) return false;
+  if (t == start) return;
   graph_levels(G, in, t, lt);
-  std::vector<int> order;
+  std::vector<int>& order = P.order;
+  order.clear();
   for (int i = 0; i < n; i++) if (in[i]) order.push_back(i);
+  std::vector<double> key(n, 0.0), key2(n, 0.0);
+  for (int i : order) key[i] = (double)(ls[i] - lt[i]);
+  for (int pass = 0; pass < 2; pass++) {
+    for (int i : order) {
+      double sum = 0;
+      int deg = 0;
+      for (int v : G.adj[i]) if (in[v]) { sum += key[v]; deg++; }
+      key2[i] = deg ? 0.5 * key[i] + 0.5 * sum / deg : key[i];
+    }
+    key.swap(key2);
+  }
   std::sort(order.begin(), order.end(), [&](int x, int y) {
-    const int kx = ls[x] - lt[x], ky = ls[y] - lt[y];
-    if (kx != ky) return kx < ky;
+    if (key[x] != key[y]) return key[x] < key[y];
     if (ls[x] != ls[y]) return ls[x] < ls[y];
     return x < y;
   });
-  long best = -1;
-  std::vector<char> ca, cb, cs;
-  for (int pct = 40; pct <= 60; pct += 5) {
+  P.pos.assign(n, -1);
+  for (int k = 0; k < total; k++) P.pos[order[k]] = k;
+  P.lo.assign(n, total);
+  P.hi.assign(n, -1);
+  for (int i : order)
+    for (int v : G.adj[i]) {
+      const int pv = P.pos[v];
+      if (pv < 0) continue;
+      P.lo[i] = std::min(P.lo[i], pv);
+      P.hi[i] = std::max(P.hi[i], pv);
+    }
+  P.kind = 2;
+}
+
+// Splits the node set of `P` into a, b, sep (no edge between a and b): a prefix of the cut order is side a, the rest side
+// b, and the separator is the smallest vertex cover of the edges between the two one-hop boundaries, thinned.  Among nine
+// cut positions between 34 % and 66 % (evaluated once per node set, whatever depth asks) the one with the shortest
+// estimated panel chain wins: this node's own separator (`tail_cols` more columns behind it for the root) + the larger
+// side, cut `depth_left - 1` more times; ties go to the smaller max(|a|, |b|) + |sep|.  false when the set cannot be split.
+static void cut_candidates(const CamGraph& G, CutPrep& P) {
+  const int n = G.n;
+  const std::vector<int>& order = P.order;
+  const int total = (int)order.size();
+  std::vector<signed char> lab(n, -1);
+  std::vector<int> La, Lb, r_index(n, -1), cover;
+  int last_m = -1;
+  for (int pct = 34; pct <= 66; pct += 4) {
     const int m = std::max(1, std::min(total - 1, (int)((long)total * pct / 100)));
-    ca.assign(n, 0); cb.assign(n, 0); cs.assign(n, 0);
-    for (int k = 0; k < total; k++) (k < m ? ca : cb)[order[k]] = 1;
-    int ba_ = 0, bb_ = 0;  // one-hop boundaries
-    for (int i : order) {
-      bool touch = false;
-      for (int v : G.adj[i]) touch = touch || (ca[i] ? cb[v] : ca[v]);
-      if (touch) (ca[i] ? ba_ : bb_)++;
+    if (m == last_m) continue;
+    last_m = m;
+    La.clear(); Lb.clear();   // one-hop boundaries
+    for (int k = 0; k < total; k++) {
+      const int i = order[k];
+      lab[i] = k < m ? 0 : 1;
+      if (k < m ? P.hi[i] >= m : P.lo[i] < m) (k < m ? La : Lb).push_back(i);
     }
-    const bool from_a = ba_ <= bb_;
-    for (int i : order) {
-      if ((ca[i] != 0) != from_a) continue;
-      bool touch = false;
-      for (int v : G.adj[i]) touch = touch || (from_a ? cb[v] : ca[v]);
-      if (touch) cs[i] = 1;
-    }
-    for (int i : order) if (cs[i]) { ca[i] = 0; cb[i] = 0; }
-    // thin the separator: a separator node without a neighbour on one side belongs to the other side
-    for (int i : order) {
-      if (!cs[i]) continue;
+    for (size_t k = 0; k < Lb.size(); k++) r_index[Lb[k]] = (int)k;
+    boundary_cover(G, La, Lb, r_index, cover);
+    for (int v : Lb) r_index[v] = -1;
+    for (int i : cover) lab[i] = 2;
+    // thin the separator (in cut order): a separator node without a neighbour on one side belongs to the other side
+    std::sort(cover.begin(), cover.end(), [&](int x, int y) { return P.pos[x] < P.pos[y]; });
+    for (int i : cover) {
       bool ta = false, tb = false;
-      for (int v : G.adj[i]) { ta = ta || ca[v]; tb = tb || cb[v]; }
-      if (!tb) { cs[i] = 0; ca[i] = 1; }
-      else if (!ta) { cs[i] = 0; cb[i] = 1; }
+      for (int v : G.adj[i]) { ta = ta || lab[v] == 0; tb = tb || lab[v] == 1; }
+      if (!tb) lab[i] = 0;
+      else if (!ta) lab[i] = 1;
     }
-    int na = 0, nb = 0, nsep = 0;
-    for (int i : order) { na += ca[i]; nb += cb[i]; nsep += cs[i]; }
-    if (na == 0 || nb == 0) continue;
-    const long cost = (long)std::max(na, nb) + nsep;
-    if (best < 0 || cost < best) { best = cost; a = ca; b = cb; sep = cs; }
+    int cnt[3] = {0, 0, 0};
+    for (int i : order) cnt[lab[i]]++;
+    if (cnt[0] == 0 || cnt[1] == 0) continue;
+    P.cands.push_back(CutPrep::Cand{cnt[0], cnt[1], cnt[2], lab});
   }
-  return best >= 0;
+  P.cands_done = true;
+}
+static bool graph_bisect(const CamGraph& G, CutPrep& P, int depth_left, int tail_cols, std::vector<char>& a, std::vector<char>& b,
+                         std::vector<char>& sep) {
+  const int n = G.n;
+  if (P.kind == 0) return false;
+  if (P.kind == 1) { a = P.a; b = P.b; sep.assign(n, 0); return true; }
+  if (!P.cands_done) cut_candidates(G, P);
+  const int total = (int)P.order.size();
+  double best = -1;
+  long best_tie = 0;
+  const CutPrep::Cand* pick = nullptr;
+  for (const CutPrep::Cand& c : P.cands) {
+    const double cost = (double)steps64(c.nsep, tail_cols) + chain_estimate(std::max(c.na, c.nb), depth_left - 1, c.nsep, total);
+    const long tie = (long)std::max(c.na, c.nb) + c.nsep;
+    if (best < 0 || cost < best || (cost == best && tie < best_tie)) { best = cost; best_tie = tie; pick = &c; }
+  }
+  if (!pick) return false;
+  a.assign(n, 0); b.assign(n, 0); sep.assign(n, 0);
+  for (int i : P.order) (pick->lab[i] == 0 ? a : pick->lab[i] == 1 ? b : sep)[i] = 1;
+  return true;
 }
 
 // Nested dissection of the camera graph to a given depth.  Leaves and separators are collected in tree order (the "a"
@@ -1561,10 +1682,22 @@ struct NdTree {
   std::vector<NdNode> leaves;
   std::vector<std::vector<NdNode>> seps;   // seps[d]: separators cut at depth d (seps[0][0] = root separator)
 };
-static void nd_split(const CamGraph& G, const std::vector<char>& in, int depth_left, int d, NdTree& T) {
+typedef std::vector<CutPrep> CutCache;   // the cut orders of the node sets met so far (the depths tried share most of them)
+static size_t cut_cached(const CamGraph& G, const std::vector<char>& in, CutCache& cache) {
+  for (size_t k = 0; k < cache.size(); k++) if (cache[k].in == in) return k;
+  cache.emplace_back();
+  cut_prepare(G, in, cache.back());
+  return cache.size() - 1;
+}
+static void nd_split(const CamGraph& G, const std::vector<char>& in, int depth_left, int d, int tail_cols, CutCache& cache, NdTree& T) {
   std::vector<char> a, b, s;
   auto members = [&](const std::vector<char>& m) { std::vector<int> v; for (int i = 0; i < G.n; i++) if (m[i]) v.push_back(i); return v; };
-  if (depth_left == 0 || !graph_bisect(G, in, a, b, s)) {
+  bool cut = false;
+  if (depth_left > 0) {
+    const size_t k = cut_cached(G, in, cache);
+    cut = graph_bisect(G, cache[k], depth_left, d == 0 ? tail_cols : 0, a, b, s);
+  }
+  if (!cut) {
     const int id = (int)T.leaves.size();
     T.leaves.push_back(NdNode{members(in), id, id});
     return;
@@ -1572,8 +1705,8 @@ static void nd_split(const CamGraph& G, const std::vector<char>& in, int depth_l
   if ((int)T.seps.size() <= d) T.seps.resize(d + 1);
   const size_t me = T.seps[d].size();
   T.seps[d].push_back(NdNode{members(s), (int)T.leaves.size(), -1});
-  nd_split(G, a, depth_left - 1, d + 1, T);
-  nd_split(G, b, depth_left - 1, d + 1, T);
+  nd_split(G, a, depth_left - 1, d + 1, tail_cols, cache, T);
+  nd_split(G, b, depth_left - 1, d + 1, tail_cols, cache, T);
   T.seps[d][me].leaf_hi = (int)T.leaves.size() - 1;
 }
 
@@ -1587,11 +1720,13 @@ static bool choose_dissection(const CamGraph& G, int tail_cols, int force_depth,
   const long dense = cdiv(6L * n + tail_cols, 64);
   long best = dense;
   bool found = false;
+  CutCache cache;
+  cache.reserve(16);
   for (int depth = 1; depth <= 3; depth++) {
     if (force_depth >= 0 && depth != force_depth) continue;
     NdTree T;
     std::vector<char> all(n, 1);
-    nd_split(G, all, depth, 0, T);
+    nd_split(G, all, depth, 0, tail_cols, cache, T);
     if (T.leaves.size() < 2 || T.leaves.size() > 8 || T.seps.empty()) continue;
     bool ok = true;
     for (size_t d = 1; d < T.seps.size(); d++) ok = ok && T.seps[d].size() <= 8;
