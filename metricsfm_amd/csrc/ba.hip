@@ -155,8 +155,9 @@ __device__ __forceinline__ double obs_linearize(const BaPtrs& P, int i, double& 
 // eliminated points are linearised inside k_point.
 // --------------------------------------------------------------------------------------
 template <bool WRITE_JAC>
-__global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __restrict__ cost_partial) {
+__global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __restrict__ cost_partial, const double* __restrict__ spec = nullptr) {
   __shared__ double sh[4];
+  if (spec && spec[0] == 0.0) return;   // (see PointPtrs::spec)
   const int i = i0 + blockIdx.x * 256 + threadIdx.x;
   double cost = 0.0;
   if (i < P.A) {
@@ -203,8 +204,9 @@ template <bool WRITE_JAC>
 __global__ __launch_bounds__(256) void k_gps(int ncb, const int* __restrict__ cb_cam, const double* __restrict__ cam,
                                               const double* __restrict__ gps, double w, double huber,
                                               const double* __restrict__ scale_c, double* __restrict__ g_r,
-                                              double* __restrict__ g_J, double* __restrict__ cost_partial) {
+                                              double* __restrict__ g_J, double* __restrict__ cost_partial, const double* __restrict__ spec = nullptr) {
   __shared__ double sh[4];
+  if (spec && spec[0] == 0.0) return;   // (see PointPtrs::spec)
   const int cb = blockIdx.x * 256 + threadIdx.x;
   double cost = 0.0;
   if (cb < ncb) {
@@ -294,6 +296,9 @@ struct PointPtrs {
   const unsigned* fold_stream;
   double* fold_partial;
   double* fold_mc_partial;   // intrinsics x camera products of the same workgroups (one intrinsics block only; nullptr: gather path)
+  // A launch enqueued BEFORE the host has seen the step it follows (msfm_ba_run): spec[0] != 0 if the device-side decision
+  // (k_publish_scalars) accepted that step - else the launch ends at once - and spec[1] = the new trust-region radius.
+  const double* spec;
 };
 
 // (8-lane groups; after the first two steps the four lanes of a quad hold the same value, so adding lane 7 - i is adding lane i ^ 4)
@@ -376,7 +381,8 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
         d0 = dg[0]; d1 = dg[1]; d2 = dg[2];
       }
       // lm_diagonal = sqrt(diagonal / radius); the eliminator adds its square
-      const double q0 = sqrt(d0 / P.radius), q1 = sqrt(d1 / P.radius), q2 = sqrt(d2 / P.radius);
+      const double radius = P.spec ? P.spec[1] : P.radius;
+      const double q0 = sqrt(d0 / radius), q1 = sqrt(d1 / radius), q2 = sqrt(d2 / radius);
       V00 += q0 * q0; V11 += q1 * q1; V22 += q2 * q2;
       // 3x3 Cholesky (Eigen LLT on the e-block in Ceres' InvertPSDMatrix)
       bool ok = V00 > 0.0;
@@ -673,6 +679,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ double sh[4];
   __shared__ double park[24 * 256];
   __shared__ __attribute__((aligned(16))) unsigned ent_s[FOLD_WORDS];
+  if (P.spec && P.spec[0] == 0.0) return;   // enqueued ahead of a step that was not accepted
   k_point_body(P, gmax_partial, sh, park, ent_s);
 }
 
@@ -1013,11 +1020,23 @@ __device__ __forceinline__ void asm_cc(int b, int t2, const int* __restrict__ bl
       s0 += v.x; s1 += v.y;
     }
   if (blk_fold_range) {   // the products formed inside k_point: one partial per (workgroup, block), in workgroup order
-    // four running sums (slots sl, sl + 1, sl + 2, sl + 3 mod 4) keep four loads in flight; combined in a fixed order
+    // four running sums (slots sl, sl + 1, sl + 2, sl + 3 mod 4), combined in a fixed order.  SIXTEEN loads are in flight per
+    // round: the launch lasts as long as its longest block (a camera's diagonal block has a partial from every workgroup
+    // that sees the camera - 138 on average at config 3 - and four loads per round trip made that 35 dependent trips)
     double2 q0 = make_double2(0.0, 0.0), q1 = q0, q2 = q0, q3 = q0;
     const int f0 = blk_fold_range[2 * b], f1 = blk_fold_range[2 * b + 1];
     const double2* fp = reinterpret_cast<const double2*>(fold_partial + t);
     int sl = f0;
+    for (; sl + 15 < f1; sl += 16) {
+      double2 v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = fp[(size_t)(sl + j) * 18];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        q0.x += v[j].x; q0.y += v[j].y; q1.x += v[j + 1].x; q1.y += v[j + 1].y;
+        q2.x += v[j + 2].x; q2.y += v[j + 2].y; q3.x += v[j + 3].x; q3.y += v[j + 3].y;
+      }
+    }
     for (; sl + 3 < f1; sl += 4) {
       const double2 v0 = fp[(size_t)sl * 18], v1 = fp[(size_t)(sl + 1) * 18], v2 = fp[(size_t)(sl + 2) * 18], v3 = fp[(size_t)(sl + 3) * 18];
       q0.x += v0.x; q0.y += v0.y; q1.x += v1.x; q1.y += v1.y; q2.x += v2.x; q2.y += v2.y; q3.x += v3.x; q3.y += v3.y;
@@ -1053,6 +1072,13 @@ __device__ __forceinline__ void asm_mc(int b, const int* __restrict__ blk_row, c
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
     const int f0 = fold_range[2 * b], f1 = fold_range[2 * b + 1];
     int sl = f0;
+    for (; sl + 15 < f1; sl += 16) {   // sixteen loads per round trip (see asm_cc), the four sums as before
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) v[j] = fold_partial[(size_t)(sl + j) * 18 + t];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) { q0 += v[j]; q1 += v[j + 1]; q2 += v[j + 2]; q3 += v[j + 3]; }
+    }
     for (; sl + 3 < f1; sl += 4) {
       const double v0 = fold_partial[(size_t)sl * 18 + t], v1 = fold_partial[(size_t)(sl + 1) * 18 + t];
       const double v2 = fold_partial[(size_t)(sl + 2) * 18 + t], v3 = fold_partial[(size_t)(sl + 3) * 18 + t];
@@ -1334,12 +1360,56 @@ __global__ void k_zero_int(int* p) { *p = 0; }
 // The iteration's scalars go to the host through mapped pinned memory: sixteen doubles, then (after a system-scope fence) the
 // sequence number the host thread is spinning on - no copy engine, no event.  The failure bits were folded into
 // scal[S_FAIL] by the last k_reduce, so the flag word is cleared here for the next iteration (one launch less at its start).
-__global__ __launch_bounds__(64) void k_publish_scalars(const double* __restrict__ scal, double* h_scal, unsigned long long seq, int* fail) {
+// The trust-region decision of the step whose scalars are being handed over (Ceres TrustRegionMinimizer, the order of
+// msfm_ba_run's loop): taken HERE, on the device, so that the next linearisation (k_point and the rows of frozen points /
+// GPS) can be enqueued before the host has seen anything; the host mirrors the code and takes the radius from here.
+enum { LM_NONE = 0, LM_INVALID, LM_PARAM_TOL, LM_FUNC_TOL, LM_ACCEPT, LM_REJECT };
+enum { H_SEQ = 16, H_CODE = 17, H_RADIUS = 18 };   // slots of the pinned block behind the sixteen scalars
+struct LmDecide {
+  int on;           // a step was enqueued with this reduced system
+  int fresh;        // the system was built at a new linearisation point: the cost at x is scal[S_XCOST], else x_cost below
+  double x_cost, radius;
+  double min_relative_decrease, parameter_tolerance, function_tolerance, max_radius, min_radius;
+};
+// t^3 rounded once (the host's std::pow(t, 3) is correctly rounded in all but astronomically rare cases): the square and the
+// product as unevaluated sums, added at the end
+__device__ __forceinline__ double cube_rn(double t) {
+  const double h = t * t, l = fma(t, t, -h);
+  const double p = h * t, e = fma(h, t, -p);
+  return p + fma(l, t, e);
+}
+__global__ __launch_bounds__(64) void k_publish_scalars(const double* __restrict__ scal, double* h_scal, unsigned long long seq, int* fail, LmDecide D,
+                                                        double* __restrict__ spec) {
   const int lane = threadIdx.x;
   if (lane < 16) __hip_atomic_store(&h_scal[lane], scal[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (lane == 0) {
+    int code = LM_NONE;
+    double rnew = D.radius;
+    if (D.on) {
+      const double mcc = scal[S_MCC], cand = scal[S_COST], dx2 = scal[S_DX2], x2 = scal[S_X2];
+      const double xc = D.fresh ? scal[S_XCOST] : D.x_cost;
+      const bool solved = (int)scal[S_FAIL] == 0;
+      if (!(solved && mcc > 0.0)) code = LM_INVALID;
+      else if (sqrt(dx2) <= D.parameter_tolerance * (sqrt(x2) + D.parameter_tolerance)) code = LM_PARAM_TOL;
+      else if (fabs(xc - cand) <= D.function_tolerance * xc) code = LM_FUNC_TOL;
+      else {
+        const double rho = (xc - cand) / mcc;
+        if (rho > D.min_relative_decrease) {
+          code = LM_ACCEPT;
+          rnew = D.radius / fmax(1.0 / 3.0, 1.0 - cube_rn(2.0 * rho - 1.0));
+          rnew = fmin(D.max_radius, rnew);
+        } else code = LM_REJECT;
+      }
+    }
+    // what follows an accepted step unless the radius has run out (the gradient test needs the new linearisation itself)
+    spec[0] = (code == LM_ACCEPT && rnew > D.min_radius) ? 1.0 : 0.0;
+    spec[1] = rnew;
+    __hip_atomic_store(&h_scal[H_CODE], (double)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&h_scal[H_RADIUS], rnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __threadfence_system();
   if (lane == 0) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_scal + 16), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_scal + H_SEQ), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (fail) *fail = 0;
   }
 }
@@ -1439,7 +1509,9 @@ struct msfm_ba {
   DevBuf<double> partial, partial2, partial3, gmax_buf, scal, sloc;
   double* swrite = nullptr;  // where the kernels put scalars: scal (one rank) or sloc (partials, summed by reduce_scalars)
   DevBuf<int> fail;
-  double* h_scal = nullptr;  // pinned, mapped: [0, 16) scalars, [16] sequence number (k_publish_scalars)
+  double* h_scal = nullptr;  // pinned, mapped: [0, 16) scalars, [16] sequence number, [17] decision code, [18] radius (k_publish_scalars)
+  DevBuf<double> spec;       // {go, radius} of the device-side decision, read by the launches enqueued ahead of the host (PointPtrs::spec)
+  bool spec_on = true;       // MSFM_SPEC=0: the next linearisation is enqueued only after the host has seen the step
   double* h_scal_dev = nullptr;
   unsigned long long scal_seq = 0;
   int* h_fail = nullptr;
@@ -3424,7 +3496,8 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   const size_t npart = (size_t)ba->nblk_obs + ba->nblk_pt + cdiv(std::max(1, ncb), 256) + 64;
   AL(partial, npart); AL(partial2, npart); AL(partial3, npart);
   AL(gmax_buf, (size_t)ba->nblk_pt + 6 * (size_t)ncb + 3 * (size_t)nmb + 8);
-  AL(scal, S_N); AL(sloc, S_N);
+  AL(scal, S_N); AL(sloc, S_N); AL(spec, 8);
+  { const char* e = getenv("MSFM_SPEC"); ba->spec_on = !(e && atoi(e) == 0); }
   HIP_TRY(ctx, ba->fail.alloc(4));
 #undef AL
   // the first solve's solution buffer starts out "pending"; from then on every solve marks the other one (k_backsolve_chain)
@@ -3562,7 +3635,7 @@ static int allreduce(msfm_ba* ba, double* buf, size_t count, int op) {
 
 // cost (and, with jac, the stored linearisation) at x or at the candidate -> scal[slot]
 // (local partial; summed over ranks by the caller together with the other scalars)
-static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int slot, bool with_fail = false) {
+static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int slot, bool with_fail = false, const double* spec = nullptr) {
   msfm_ctx* ctx = ba->ctx;
   hipStream_t s = ctx->stream;
   const bool lead = ctx->rank == 0;
@@ -3576,8 +3649,8 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int
     // [nblk_pt, nblk_pt + ntail)) and the GPS rows.  The sum into `slot` follows k_point.
     KTimer t(ctx, "ba_linearize");
     const int ntail = cdiv(ba->A - ba->AE, 256);
-    if (ntail) hipLaunchKernelGGL(k_linearize<true>, dim3(ntail), dim3(256), 0, s, P, ba->AE, ba->partial.p + ba->nblk_pt);
-    if (ng) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + ba->nblk_pt + ntail);
+    if (ntail) hipLaunchKernelGGL(k_linearize<true>, dim3(ntail), dim3(256), 0, s, P, ba->AE, ba->partial.p + ba->nblk_pt, spec);
+    if (ng) hipLaunchKernelGGL(k_gps<true>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + ba->nblk_pt + ntail, spec);
     ba->lin_pending = true;
     ba->lin_huber = huber;
     (void)slot;   // S_XCOST
@@ -3585,8 +3658,8 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int
   }
   {
     KTimer t(ctx, "ba_cost");
-    hipLaunchKernelGGL(k_linearize<false>, dim3(nb), dim3(256), 0, s, P, 0, ba->partial.p);
-    if (ng) hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb);
+    hipLaunchKernelGGL(k_linearize<false>, dim3(nb), dim3(256), 0, s, P, 0, ba->partial.p, (const double*)nullptr);
+    if (ng) hipLaunchKernelGGL(k_gps<false>, dim3(ng), dim3(256), 0, s, ba->ncb, ba->cb_cam.p, P.cam, ba->gps.p, ba->gps_weight, huber, ba->scale_c.p, ba->g_r.p, ba->g_J.p, ba->partial.p + nb, (const double*)nullptr);
     ReduceJobs rj;
     rj.count = 1;
     rj.job[0] = {ba->partial.p, nb + (lead ? ng : 0), slot, 0};
@@ -3597,31 +3670,39 @@ static int run_evaluate(msfm_ba* ba, bool candidate, bool jac, double huber, int
   return MSFM_OK;
 }
 
-// point kernel + camera sums (+, for mode 0, the reduced system in M)
-static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, bool reuse_diag, int mode) {
+// The point kernel: linearises the rows of the eliminated points at x (or, `candidate`, at the candidate: the launch that
+// msfm_ba_run enqueues ahead of the host's view of a step, gated and given its radius by `spec`), eliminates the points.
+static void launch_point(msfm_ba* ba, const msfm_ba_options* opt, double radius, bool reuse_diag, int mode, bool store_rows, bool candidate,
+                         const double* spec) {
+  msfm_ctx* ctx = ba->ctx;
+  KTimer t(ctx, "ba_point");
+  PointPtrs Q;
+  Q.B = make_ptrs(ba, candidate, ba->lin_huber);
+  Q.npb = ba->npb; Q.NCR = std::max(1, ba->NCR); Q.pt_first = ba->pt_first.p;
+  Q.pm_first = ba->pm_first.p; Q.pm_mb = ba->pm_mb.p;
+  Q.diag_p = ba->diag_p.p; Q.ptL = ba->ptL.p; Q.ptg = ba->ptg.p;
+  Q.T = ba->T.p; Q.Tu = ba->Tu.p; Q.Tm = ba->Tm.p; Q.Tmu = ba->Tmu.p;
+  Q.radius = radius; Q.dmin = opt->min_lm_diagonal; Q.dmax = opt->max_lm_diagonal;
+  Q.reuse_diag = reuse_diag; Q.mode = mode; Q.fail = ba->fail.p;
+  Q.store_rows = store_rows ? 1 : 0; Q.cost_partial = ba->partial.p;
+  const FoldTables& F = ba->fold;
+  Q.fold_wg = F.on ? F.wg_fold.p : nullptr; Q.fold_ovf_off = F.ovf_off.p; Q.fold_wg_pass_first = F.wg_pass_first.p; Q.fold_slot_rank = F.slot_rank.p;
+  Q.fold_pass = F.pass.p; Q.fold_stream = F.stream.p; Q.fold_partial = F.partial.p;
+  Q.fold_mc_partial = (F.on && F.mc_on) ? F.mc_partial.p : nullptr;
+  Q.spec = spec;
+  hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, ctx->stream, Q, ba->gmax_buf.p);
+}
+
+// point kernel + camera sums (+, for mode 0, the reduced system in M).  point_enqueued: the point kernel of this
+// linearisation point is already in the stream (msfm_ba_run enqueued it ahead of the step's read-back).
+static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, bool reuse_diag, int mode, bool point_enqueued = false) {
   msfm_ctx* ctx = ba->ctx;
   hipStream_t s = ctx->stream;
-  const int ncb = ba->ncb, nmb = ba->nmb, npb = ba->npb;
+  const int ncb = ba->ncb, nmb = ba->nmb;
   const int lead = ctx->rank == 0 ? 1 : 0;
   const bool store_rows = ba->lin_pending;   // new linearisation point (else: the same rows again, new radius)
   ba->lin_pending = false;
-  {
-    KTimer t(ctx, "ba_point");
-    PointPtrs Q;
-    Q.B = make_ptrs(ba, false, ba->lin_huber);
-    Q.npb = npb; Q.NCR = std::max(1, ba->NCR); Q.pt_first = ba->pt_first.p;
-    Q.pm_first = ba->pm_first.p; Q.pm_mb = ba->pm_mb.p;
-    Q.diag_p = ba->diag_p.p; Q.ptL = ba->ptL.p; Q.ptg = ba->ptg.p;
-    Q.T = ba->T.p; Q.Tu = ba->Tu.p; Q.Tm = ba->Tm.p; Q.Tmu = ba->Tmu.p;
-    Q.radius = radius; Q.dmin = opt->min_lm_diagonal; Q.dmax = opt->max_lm_diagonal;
-    Q.reuse_diag = reuse_diag; Q.mode = mode; Q.fail = ba->fail.p;
-    Q.store_rows = store_rows ? 1 : 0; Q.cost_partial = ba->partial.p;
-    const FoldTables& F = ba->fold;
-    Q.fold_wg = F.on ? F.wg_fold.p : nullptr; Q.fold_ovf_off = F.ovf_off.p; Q.fold_wg_pass_first = F.wg_pass_first.p; Q.fold_slot_rank = F.slot_rank.p;
-    Q.fold_pass = F.pass.p; Q.fold_stream = F.stream.p; Q.fold_partial = F.partial.p;
-    Q.fold_mc_partial = (F.on && F.mc_on) ? F.mc_partial.p : nullptr;
-    hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, s, Q, ba->gmax_buf.p);
-  }
+  if (!point_enqueued) launch_point(ba, opt, radius, reuse_diag, mode, store_rows, false, nullptr);
   // The Schur pair products read only what k_point wrote (T, Tm, Tmu) and write their own partials; the per-camera sums
   // (k_ftf ... k_modelsum, with the multi-rank exchange of camftf) read T.u and the camera rows.  Outside profiling runs
   // the pair products therefore go to a second stream beside them and the two meet again at the assembly (with the
@@ -3810,15 +3891,19 @@ static int reduce_scalars(msfm_ba* ba) {
   return MSFM_OK;
 }
 
-static int read_scalars(msfm_ba* ba) {
+static void publish_scalars(msfm_ba* ba, const LmDecide& D) {
   msfm_ctx* ctx = ba->ctx;
   const unsigned long long seq = ++ba->scal_seq;
-  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, ctx->stream, ba->scal.p, ba->h_scal_dev, seq, ba->fail.p);
+  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, ctx->stream, ba->scal.p, ba->h_scal_dev, seq, ba->fail.p, D, ba->spec.p);
+}
+static int wait_scalars(msfm_ba* ba) {
+  msfm_ctx* ctx = ba->ctx;
+  const unsigned long long seq = ba->scal_seq;
   // spin on the sequence number: the wake-up of a blocking wait costs more than the whole hand-over.  Bounded: a wedged kernel,
   // or a peer rank that left the loop so that a collective never completes, must surface as an error code, not as a host thread
   // spinning forever; a launch or execution error surfaces through the stream query that accompanies the clock check.
   static const double limit_s = [] { const char* e = getenv("MSFM_SYNC_TIMEOUT_S"); const double v = e ? atof(e) : 120.0; return v > 0 ? v : 120.0; }();
-  const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ba->h_scal + 16);
+  const volatile unsigned long long* flag = reinterpret_cast<const volatile unsigned long long*>(ba->h_scal + H_SEQ);
   unsigned long long spins = 0;
   const auto t0 = std::chrono::steady_clock::now();   // taken once: the deadline never re-arms, whatever the poll count does
   while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
@@ -3963,15 +4048,37 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
   // The reduced system and the trust-region step computed from it are enqueued back to back and
   // their scalars read with ONE host synchronisation per LM iteration: the step is speculative
   // only in that a gradient-tolerance stop discards it (it writes the candidate buffers only).
-  auto assemble_and_step = [&]() -> int {
-    MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0));
-    if (iteration < opt->max_num_iterations && radius > opt->min_trust_region_radius) MSFM_TRY(run_solve(ba, opt));
+  // The step's verdict (valid / tolerances / accept + new radius / reject) is formed on the device by k_publish_scalars,
+  // and what follows an accepted step - the linearisation at the candidate, i.e. the rows of frozen points, the GPS rows and
+  // k_point - is enqueued BEHIND it before the host has seen anything (`spec`: those launches end at once unless the step was
+  // accepted and take the radius from the device).  The host mirrors the verdict, swaps its buffer names and carries on
+  // behind k_point, so no launch waits for the read-back (it was a 9-13 us hole in front of every k_point).
+  double x_cost = 0.0;
+  bool spec_inflight = false;
+  auto assemble_and_step = [&](bool point_enqueued) -> int {
+    LmDecide D;
+    D.fresh = ba->lin_pending ? 1 : 0;
+    MSFM_TRY(run_assemble(ba, opt, radius, reuse_diag, 0, point_enqueued));
+    D.on = (iteration < opt->max_num_iterations && radius > opt->min_trust_region_radius) ? 1 : 0;
+    if (D.on) MSFM_TRY(run_solve(ba, opt));
     MSFM_TRY(reduce_scalars(ba));
-    MSFM_TRY(read_scalars(ba));
+    D.x_cost = x_cost; D.radius = radius;
+    D.min_relative_decrease = opt->min_relative_decrease; D.parameter_tolerance = opt->parameter_tolerance;
+    D.function_tolerance = opt->function_tolerance; D.max_radius = opt->max_trust_region_radius; D.min_radius = opt->min_trust_region_radius;
+    publish_scalars(ba, D);
+    spec_inflight = false;
+    if (D.on && ba->spec_on) {
+      // x_{k+1} would be the present candidate buffers
+      MSFM_TRY(run_evaluate(ba, /*candidate=*/true, /*jac=*/true, opt->huber_delta, S_XCOST, false, ba->spec.p));
+      launch_point(ba, opt, radius, false, 0, true, /*candidate=*/true, ba->spec.p);
+      ba->lin_pending = false;   // becomes true again if the host finds the step accepted
+      spec_inflight = true;
+    }
+    MSFM_TRY(wait_scalars(ba));
     return MSFM_OK;
   };
-  MSFM_TRY(assemble_and_step());
-  double x_cost = ba->h_scal[S_XCOST];
+  MSFM_TRY(assemble_and_step(false));
+  x_cost = ba->h_scal[S_XCOST];
   msfm_ba_iteration it;
   memset(&it, 0, sizeof it);
   it.cost = x_cost; it.gradient_max_norm = ba->h_scal[S_GMAX]; it.trust_region_radius = radius;
@@ -3996,9 +4103,10 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     // Cholesky / finiteness failures, and any of them makes the step invalid)
     if ((long)ba->h_scal[S_FAIL] >= MSFM_FAIL_SYNC)
       return msfm_set_error(ctx, MSFM_E_DEVICE, "a bounded in-kernel wait of the back substitution ran out (MSFM_SYNC_TIMEOUT_S)");
-    const bool solved = (int)ba->h_scal[S_FAIL] == 0;
+    const int code = (int)ba->h_scal[H_CODE];   // the device's verdict on the step (k_publish_scalars); mirrored here
     const double mcc = ba->h_scal[S_MCC], cand_cost = ba->h_scal[S_COST], dx2 = ba->h_scal[S_DX2], x2 = ba->h_scal[S_X2];
-    it.step_is_valid = solved && (mcc > 0.0);
+    if (code < LM_INVALID || code > LM_REJECT) return msfm_set_error(ctx, MSFM_E_DEVICE, "no verdict for the step (code %d)", code);
+    it.step_is_valid = code != LM_INVALID;
     bool relinearise = false;
     if (!it.step_is_valid) {
       if (++num_invalid >= opt->max_num_consecutive_invalid_steps) { termination = MSFM_BA_FAILURE; break; }
@@ -4008,17 +4116,16 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     } else {
       num_invalid = 0;
       it.step_norm = std::sqrt(dx2);
-      const double x_norm = std::sqrt(x2);
-      if (it.step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance)) { termination = MSFM_BA_CONVERGENCE_PARAMETER; break; }
+      (void)x2;
+      if (code == LM_PARAM_TOL) { termination = MSFM_BA_CONVERGENCE_PARAMETER; break; }
       it.cost_change = x_cost - cand_cost;
-      if (std::fabs(it.cost_change) <= opt->function_tolerance * x_cost) { termination = MSFM_BA_CONVERGENCE_FUNCTION; break; }
+      if (code == LM_FUNC_TOL) { termination = MSFM_BA_CONVERGENCE_FUNCTION; break; }
       it.relative_decrease = (x_cost - cand_cost) / mcc;
-      if (it.relative_decrease > opt->min_relative_decrease) {
+      if (code == LM_ACCEPT) {
         ba->cam.swap(ba->cam_c); ba->model.swap(ba->model_c); ba->pt.swap(ba->pt_c); ba->rot.swap(ba->rot_c);
         relinearise = true;
         it.step_is_successful = 1;
-        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * it.relative_decrease - 1.0, 3));
-        radius = std::min(opt->max_trust_region_radius, radius);
+        radius = ba->h_scal[H_RADIUS];   // = min(max_radius, radius / max(1/3, 1 - (2 rho - 1)^3)), formed on the device
         decrease_factor = 2.0; reuse_diag = false;
       } else {
         it.step_is_successful = 0; it.cost = cand_cost; it.gradient_max_norm = prev_gmax;
@@ -4028,10 +4135,18 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     }
     // ---- next reduced system (new Jacobian after a successful step, else new radius only) ----
     // (the failure bits were cleared by k_publish_scalars when it handed the last iteration's scalars over)
+    bool point_enqueued = false;
     if (relinearise) {
-      MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
+      if (spec_inflight && radius > opt->min_trust_region_radius) {
+        // the launches enqueued ahead found the same verdict on the device and are running
+        ba->lin_pending = true;
+        ba->lin_huber = opt->huber_delta;
+        point_enqueued = true;
+      } else {
+        MSFM_TRY(run_evaluate(ba, false, true, opt->huber_delta, S_XCOST));
+      }
     }
-    MSFM_TRY(assemble_and_step());
+    MSFM_TRY(assemble_and_step(point_enqueued));
     if (relinearise) {
       x_cost = ba->h_scal[S_XCOST];
       it.cost = x_cost;
