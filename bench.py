@@ -598,7 +598,7 @@ def main():
         v_s = time.perf_counter() - t0
         vst = ctx.profile_get()
         ctx.profile(False)
-        kms = sum(vst[k]["total_ms"] for k in ("geo_fransac_score", "geo_fransac_select") if k in vst)
+        kms = sum(v["total_ms"] for k, v in vst.items() if k.startswith("geo_fransac"))
         out["geo_verification"] = dict(metric="pairs verified/sec", value=n_vp / v_s, unit="pairs/s", pairs=n_vp, matches_per_pair=n_vm,
                                        outlier_fraction=0.3, samples_per_pair="up to 2000 (128 scored first, the rest only for pairs whose adaptive budget is still open)", accepted=int(vok.sum()), mean_inliers=float(vnin.mean()),
                                        kernel_ms=kms, kernel_pairs_per_sec=(n_vp / (kms * 1e-3)) if kms else None, dtype="f64",

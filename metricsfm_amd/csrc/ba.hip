@@ -1001,10 +1001,13 @@ __global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int
   for (int e = threadIdx.x; e < 64 * 32; e += 256) base[(size_t)(e >> 5) * (ld / 2) + (e & 31)] = make_double2(0.0, 0.0);
 }
 
-// camera-camera blocks: three blocks per 64-thread workgroup, 18 threads per block, two neighbouring entries of a row each
-// (16-byte loads of the partials, one 16-byte store into M: the launch is bound by the number of waves and their dependent
-// loads, not by bytes - one block per wave with 36 single entries took 0.059 ms at config 3, this 0.055; skipping the zero chunk partials 0.052).
-__device__ __forceinline__ void asm_cc(int b, int t2, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+// camera-camera blocks: one block per 64-thread workgroup; 18 threads hold two neighbouring entries of a row each (16-byte
+// loads of the partials, one 16-byte store into M), and THREE such groups share the block's list of fold partials (group g
+// sums partials g, g + 3, ...; the three sums meet in group 0 at the end).  The launch is bound by the dependent load rounds
+// of its longest block, not by bytes: a camera's diagonal block has a partial from every workgroup of k_point that sees the
+// camera (138 on average at config 3).  History at config 3: one block per wave, four loads per round 0.055 ms (three blocks
+// per wave; 0.052 with the zero chunk partials skipped), sixteen loads per round 0.042, the list split over three groups 0.0xx.
+__device__ __forceinline__ void asm_cc(int b, int sub, int t2, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                        const int* __restrict__ blk_chunk_first, const uint8_t* __restrict__ blk_live, const double* __restrict__ partial,
                                        const int* __restrict__ blk_fold_range, const double* __restrict__ fold_partial,
                                        const double* __restrict__ camftf, const double* __restrict__ diag_c,
@@ -1014,37 +1017,41 @@ __device__ __forceinline__ void asm_cc(int b, int t2, const int* __restrict__ bl
   double s0 = 0.0, s1 = 0.0;
   // (blk_chunk_first nullptr: every entry was folded into k_point, the gather kernel did not run; blk_live: which blocks still
   //  have an entry on the gather path - the chunk partials of the others are zero and their two dependent loads are skipped)
-  if (blk_chunk_first && (!blk_live || blk_live[b]))
+  if (sub == 0 && blk_chunk_first && (!blk_live || blk_live[b]))
     for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) {
       const double2 v = *reinterpret_cast<const double2*>(partial + (size_t)ch * 36 + t);
       s0 += v.x; s1 += v.y;
     }
   if (blk_fold_range) {   // the products formed inside k_point: one partial per (workgroup, block), in workgroup order
-    // four running sums (slots sl, sl + 1, sl + 2, sl + 3 mod 4), combined in a fixed order.  SIXTEEN loads are in flight per
-    // round: the launch lasts as long as its longest block (a camera's diagonal block has a partial from every workgroup
-    // that sees the camera - 138 on average at config 3 - and four loads per round trip made that 35 dependent trips)
+    // four running sums per group (its partials 0, 1, 2, 3 mod 4), sixteen loads in flight per round, combined in a fixed order
     double2 q0 = make_double2(0.0, 0.0), q1 = q0, q2 = q0, q3 = q0;
-    const int f0 = blk_fold_range[2 * b], f1 = blk_fold_range[2 * b + 1];
+    const int f0 = blk_fold_range[2 * b], f1 = sub < 3 ? blk_fold_range[2 * b + 1] : 0;
     const double2* fp = reinterpret_cast<const double2*>(fold_partial + t);
-    int sl = f0;
-    for (; sl + 15 < f1; sl += 16) {
+    int sl = f0 + sub;
+    for (; sl + 45 < f1; sl += 48) {
       double2 v[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) v[j] = fp[(size_t)(sl + j) * 18];
+      for (int j = 0; j < 16; j++) v[j] = fp[(size_t)(sl + 3 * j) * 18];
 #pragma unroll
       for (int j = 0; j < 16; j += 4) {
         q0.x += v[j].x; q0.y += v[j].y; q1.x += v[j + 1].x; q1.y += v[j + 1].y;
         q2.x += v[j + 2].x; q2.y += v[j + 2].y; q3.x += v[j + 3].x; q3.y += v[j + 3].y;
       }
     }
-    for (; sl + 3 < f1; sl += 4) {
-      const double2 v0 = fp[(size_t)sl * 18], v1 = fp[(size_t)(sl + 1) * 18], v2 = fp[(size_t)(sl + 2) * 18], v3 = fp[(size_t)(sl + 3) * 18];
+    for (; sl + 9 < f1; sl += 12) {
+      const double2 v0 = fp[(size_t)sl * 18], v1 = fp[(size_t)(sl + 3) * 18], v2 = fp[(size_t)(sl + 6) * 18], v3 = fp[(size_t)(sl + 9) * 18];
       q0.x += v0.x; q0.y += v0.y; q1.x += v1.x; q1.y += v1.y; q2.x += v2.x; q2.y += v2.y; q3.x += v3.x; q3.y += v3.y;
     }
-    for (; sl < f1; sl++) { const double2 v = fp[(size_t)sl * 18]; q0.x += v.x; q0.y += v.y; }
-    s0 += (q0.x + q1.x) + (q2.x + q3.x);
-    s1 += (q0.y + q1.y) + (q2.y + q3.y);
+    for (; sl < f1; sl += 3) { const double2 v = fp[(size_t)sl * 18]; q0.x += v.x; q0.y += v.y; }
+    const double g0 = (q0.x + q1.x) + (q2.x + q3.x), g1 = (q0.y + q1.y) + (q2.y + q3.y);
+    // groups 1 and 2 hand their sums to group 0 (every lane of the wave takes part in the exchange)
+    const int lane = (int)threadIdx.x;
+    const double a0 = __shfl(g0, lane + 18), a1 = __shfl(g1, lane + 18);
+    const double b0 = __shfl(g0, lane + 36), b1 = __shfl(g1, lane + 36);
+    s0 += (g0 + a0) + b0;
+    s1 += (g1 + a1) + b1;
   }
+  if (sub != 0) return;
   double v0 = -s0, v1 = -s1;
   const int a = t / 6, c = t % 6;
   if (rb == cbk && lead) {
@@ -1056,37 +1063,40 @@ __device__ __forceinline__ void asm_cc(int b, int t2, const int* __restrict__ bl
   *reinterpret_cast<double2*>(&M[(size_t)(cb_off[rb] + a) * ld + cb_off[cbk] + c]) = make_double2(v0, v1);
 }
 
-// intrinsics-camera blocks (rows 6*ncb + 3*mb.., cols 6*cb..): 18 used threads.
+// intrinsics-camera blocks (rows 6*ncb + 3*mb.., cols 6*cb..): 18 entries; three groups of 18 threads share the list of
+// fold partials as in asm_cc.
 __device__ __forceinline__ void asm_mc(int b, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
                                        const int* __restrict__ blk_chunk_first, const double* __restrict__ partial,
                                        const int* __restrict__ fold_range, const double* __restrict__ fold_partial,
                                        const double* __restrict__ camftf, const int* __restrict__ cb_mb,
                                        const int* __restrict__ cb_off, int mo, double* __restrict__ M, int ld, int lead) {
-  const int t = threadIdx.x;
-  if (t >= 18) return;
+  const int lane = threadIdx.x, sub = lane / 18, t = lane - 18 * sub;
   const int mb = blk_row[b], cb = blk_col[b];
   double s = 0.0;
-  if (blk_chunk_first)
+  if (sub == 0 && blk_chunk_first)
     for (int ch = blk_chunk_first[b]; ch < blk_chunk_first[b + 1]; ch++) s += partial[(size_t)ch * 18 + t];
   if (fold_range) {   // the products formed inside k_point: one partial per (workgroup, camera), in workgroup order
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-    const int f0 = fold_range[2 * b], f1 = fold_range[2 * b + 1];
-    int sl = f0;
-    for (; sl + 15 < f1; sl += 16) {   // sixteen loads per round trip (see asm_cc), the four sums as before
+    const int f0 = fold_range[2 * b], f1 = sub < 3 ? fold_range[2 * b + 1] : 0;
+    int sl = f0 + sub;
+    for (; sl + 45 < f1; sl += 48) {
       double v[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) v[j] = fold_partial[(size_t)(sl + j) * 18 + t];
+      for (int j = 0; j < 16; j++) v[j] = fold_partial[(size_t)(sl + 3 * j) * 18 + t];
 #pragma unroll
       for (int j = 0; j < 16; j += 4) { q0 += v[j]; q1 += v[j + 1]; q2 += v[j + 2]; q3 += v[j + 3]; }
     }
-    for (; sl + 3 < f1; sl += 4) {
-      const double v0 = fold_partial[(size_t)sl * 18 + t], v1 = fold_partial[(size_t)(sl + 1) * 18 + t];
-      const double v2 = fold_partial[(size_t)(sl + 2) * 18 + t], v3 = fold_partial[(size_t)(sl + 3) * 18 + t];
+    for (; sl + 9 < f1; sl += 12) {
+      const double v0 = fold_partial[(size_t)sl * 18 + t], v1 = fold_partial[(size_t)(sl + 3) * 18 + t];
+      const double v2 = fold_partial[(size_t)(sl + 6) * 18 + t], v3 = fold_partial[(size_t)(sl + 9) * 18 + t];
       q0 += v0; q1 += v1; q2 += v2; q3 += v3;
     }
-    for (; sl < f1; sl++) q0 += fold_partial[(size_t)sl * 18 + t];
-    s += (q0 + q1) + (q2 + q3);
+    for (; sl < f1; sl += 3) q0 += fold_partial[(size_t)sl * 18 + t];
+    const double g = (q0 + q1) + (q2 + q3);
+    const double ga = __shfl(g, lane + 18), gb = __shfl(g, lane + 36);
+    s += (g + ga) + gb;
   }
+  if (sub != 0) return;
   double v = -s;
   if (lead && cb_mb[cb] == mb) v += camftf[(size_t)cb * PSTRIDE + F_JMJC + t];
   const int a = t / 6, c = t % 6;
@@ -1156,14 +1166,12 @@ struct AsmArgs {
 };
 __global__ __launch_bounds__(64) void k_asm_all(AsmArgs a) {
   int b = blockIdx.x;
-  const int n_cc3 = (a.n_cc + 2) / 3;
-  if (b < n_cc3) {
-    const int sub = (int)threadIdx.x / 18, blk = 3 * b + sub;
-    if (sub < 3 && blk < a.n_cc)
-      asm_cc(blk, (int)threadIdx.x - 18 * sub, a.cc_row, a.cc_col, a.cc_first, a.cc_live, a.cc_partial, a.cc_fold_first, a.cc_fold_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead);
+  if (b < a.n_cc) {
+    const int sub = (int)threadIdx.x / 18;
+    asm_cc(b, sub, (int)threadIdx.x - 18 * sub, a.cc_row, a.cc_col, a.cc_first, a.cc_live, a.cc_partial, a.cc_fold_first, a.cc_fold_partial, a.camftf, a.diag_c, a.radius, a.cb_off, a.M, a.ld, a.lead);
     return;
   }
-  b -= n_cc3;
+  b -= a.n_cc;
   if (b < a.n_mc) { asm_mc(b, a.mc_row, a.mc_col, a.mc_first, a.mc_partial, a.mc_fold_range, a.mc_fold_partial, a.camftf, a.cb_mb, a.cb_off, a.mo, a.M, a.ld, a.lead); return; }
   b -= a.n_mc;
   if (b < a.n_mm) { asm_mm(b, a.mm_row, a.mm_col, a.mm_first, a.mm_partial, a.modelsum, a.diag_m, a.radius, a.mo, a.n, a.M, a.ld, a.lead); return; }
@@ -3842,7 +3850,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     aa.diag_m = ba->diag_m.p; aa.radius = radius; aa.ncb = ncb; aa.mo = ba->mo; aa.n = ba->nsys; aa.ld = ba->npad; aa.lead = lead; aa.M = ba->M.p;
     aa.n_padcol = ctx->world <= 1 ? ba->n_padcol : 0;
     aa.padcol = ba->padcol.p;
-    const int nasm = cdiv(aa.n_cc, 3) + aa.n_mc + aa.n_mm + aa.n_rhs + cdiv(aa.n_padcol, 64);
+    const int nasm = aa.n_cc + aa.n_mc + aa.n_mm + aa.n_rhs + cdiv(aa.n_padcol, 64);
     if (nasm) hipLaunchKernelGGL(k_asm_all, dim3(nasm), dim3(64), 0, s, aa);
   }
   hipError_t e = hipGetLastError();

@@ -20,6 +20,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "common.h"
+#include <chrono>
 #include "../../include/msfm.h"
 
 namespace chn {
@@ -241,6 +242,11 @@ MSFM_API int msfm_chain_verify(msfm_chain* C, msfm_match_result* res, const msfm
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const int np = C->n_pairs;
+  static const bool laps = getenv("MSFM_CHAIN_LAPS") != nullptr;   // host-side wall clock of the stages, to stderr
+  const auto lap_t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (laps) fprintf(stderr, "msfm: chain verify %-24s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lap_t0).count());
+  };
   C->ok.assign(std::max(1, np), 0);
   C->F.assign(9 * (size_t)std::max(1, np), 0.0);
   std::vector<int> off_g(np + 1, 0), off_a(np + 1, 0);
@@ -270,9 +276,11 @@ MSFM_API int msfm_chain_verify(msfm_chain* C, msfm_match_result* res, const msfm
       hipLaunchKernelGGL(chn::k_gather_sets, dim3(np), dim3(256), 0, s, d_src.p, v.code, m_good.p, g1.p, g2.p, m_all.p, a1.p, a2.p, pair_of_all.p);
     }
     CH_TRY(hipGetLastError());
+    lap("buffers + gather enqueued");
     // GeoVerificationFundamental on the good sets (fine_matching_graph.cc:141), then the closed-form filter on the all sets of
     // the pairs that passed (:145-147)
     MSFM_TRY(geo_fransac_dev(ctx, np, off_g.data(), d_offg.p, g1.p, g2.p, opt, dF.p, in_g.p, d_nin.p, d_ok.p));
+    lap("fundamental matrices");
     CH_TRY(hipMemsetAsync(in_a.p, 0, std::max(1, ta), s));
     MSFM_TRY(geo_epipolar_batch_dev(ctx, ta, pair_of_all.p, a1.p, a2.p, dF.p, d_ok.p, th_filter, in_a.p));
     {
@@ -284,6 +292,7 @@ MSFM_API int msfm_chain_verify(msfm_chain* C, msfm_match_result* res, const msfm
     CH_TRY(hipMemcpyAsync(C->F.data(), dF.p, sizeof(double) * 9 * (size_t)np, hipMemcpyDeviceToHost, s));
     CH_TRY(hipStreamSynchronize(s));
     for (int p = 0; p < np; p++) C->off_fin[p + 1] = C->off_fin[p] + C->n_fin[p];
+    lap("filter + counts back");
   }
   const int M = C->off_fin[np];
   CH_TRY(C->d_moff.from(C->off_fin, s));
@@ -297,6 +306,7 @@ MSFM_API int msfm_chain_verify(msfm_chain* C, msfm_match_result* res, const msfm
   }
   CH_TRY(hipGetLastError());
   CH_TRY(hipStreamSynchronize(s));   // the scratch above goes back to the pool
+  lap("compacted");
   C->verified = true;
   return MSFM_OK;
 }

@@ -11,12 +11,18 @@
 // is statistical; parity with oracle/ (same counter-based sampler) is exact:
 // this file uses only + - * / sqrt on doubles, in a fixed order, with contraction off.
 //
-// One GPU thread = one sample (hypothesis).  All `max_iterations` samples of a pair are scored in
-// parallel; the adaptive stop is then replayed over the per-sample inlier counts in sample order,
-// which selects exactly the model the sequential loop would have kept.
+// Models: one GPU thread = one sample (k_fransac_models: the 7-point solver, work matrix in LDS).  Scoring: one LANE = one
+// MATCH and the model is uniform over the wave (k_fransac_count: its nine numbers arrive through the scalar cache as SGPR
+// operands, a count is the population count of the wave's inlier mask) - the first form of this file scored with one thread
+// per sample walking all matches, its three models in scratch memory and lanes idle wherever a sample had fewer models:
+// 5.2 ms for the first 128 samples of the 9 120 pairs of 96 images, of which the solver was 0.24.  All samples of a range are
+// scored in parallel; the adaptive stop is then replayed over the per-sample inlier counts in sample order, which selects
+// exactly the model the sequential loop would have kept.
 #include "common.h"
 
 #include <cfloat>
+#include <mutex>
+#include <unordered_map>
 #include <cmath>
 
 #pragma clang fp contract(off)
@@ -203,74 +209,112 @@ __device__ static inline bool geo_inlier(const double* F, double x1, double y1, 
   return err <= th2;  // false for NaN
 }
 
-// grid (ceil((h1 - h0) / 64), n_pairs): thread = sample h in [h0, h1) of pair blockIdx.y.  counts[pair][h][3].
-// need != nullptr: only pairs flagged by the first selection pass are scored.
-__global__ __launch_bounds__(GEO_WAVE) void k_fransac_score(int H, int h0, int h1, int pair0, const int* __restrict__ off,
-                                                             const float2* __restrict__ pt1, const float2* __restrict__ pt2, uint64_t seed,
-                                                             double th2, int min_points, const uint8_t* __restrict__ need,
-                                                             int* __restrict__ counts) {
+// The models of samples [h0, h1) of the pairs in `slot_pair`: grid (ceil((h1 - h0) / 64), n_slots), thread = sample.
+// models[slot][h - h0]: up to three fundamental matrices and their number.
+struct GeoModelRec { double F[3][9]; int n, pad; };
+__global__ __launch_bounds__(GEO_WAVE) void k_fransac_models(int h0, int h1, const int* __restrict__ slot_pair, const int* __restrict__ n_slots_dev,
+                                                              const int* __restrict__ off, const float2* __restrict__ pt1, const float2* __restrict__ pt2,
+                                                              uint64_t seed, GeoModelRec* __restrict__ models) {
   __shared__ double A[63 * GEO_WAVE];
-  __shared__ float4 pts[1024];
-  const int pair = pair0 + blockIdx.y, h = h0 + blockIdx.x * GEO_WAVE + threadIdx.x;
+  if (n_slots_dev && (int)blockIdx.y >= *n_slots_dev) return;
+  const int slot = blockIdx.y, pair = slot_pair[slot], h = h0 + blockIdx.x * GEO_WAVE + threadIdx.x;
   const int o = off[pair], N = off[pair + 1] - o;
-  if (N < min_points || N < 8) return;  // GeoVerificationFundamental: pt1.size() < 30 -> false (uniform per block)
-  if (need && !need[pair]) return;
-  const int Hstride = H;
-  H = h1;  // samples of this launch end here
+  if (h >= h1) return;
   GeoModels m;
   m.n = 0;
-  if (h < H) geo_solve7(seed, pair, h, N, pt1 + o, pt2 + o, A + threadIdx.x, GEO_WAVE, m);
-  int cnt[3] = {0, 0, 0};
+  geo_solve7(seed, pair, h, N, pt1 + o, pt2 + o, A + threadIdx.x, GEO_WAVE, m);
+  GeoModelRec* r = models + (size_t)slot * (h1 - h0) + (h - h0);
+  for (int q = 0; q < 3; q++)
+    for (int k = 0; k < 9; k++) r->F[q][k] = q < m.n ? m.F[q][k] : 0.0;
+  r->n = m.n;
+  r->pad = 0;
+}
+
+// Inlier counts of those models: grid (ceil((h1 - h0) / 128), n_slots), 256 threads; the pair's matches wait in LDS (1024
+// at a time), wave w takes samples [32 w, 32 w + 32) of the block's 128 one after the other, lane = match.
+// counts[slot][h - h0][3] (-1: no such model).
+#define GEO_CNT_SAMPLES 128
+__global__ __launch_bounds__(256) void k_fransac_count(int h0, int h1, const int* __restrict__ slot_pair, const int* __restrict__ n_slots_dev,
+                                                        const int* __restrict__ off, const float2* __restrict__ pt1, const float2* __restrict__ pt2,
+                                                        double th2, const GeoModelRec* __restrict__ models, int* __restrict__ counts) {
+  __shared__ float4 pts[1024];
+  __shared__ int cnt_s[GEO_CNT_SAMPLES * 3];
+  if (n_slots_dev && (int)blockIdx.y >= *n_slots_dev) return;
+  const int slot = blockIdx.y, pair = slot_pair[slot];
+  const int o = off[pair], N = off[pair + 1] - o;
+  const int HS = h1 - h0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int s_first = blockIdx.x * GEO_CNT_SAMPLES + 32 * wave;   // first sample (relative to h0) of this wave
+  for (int e = threadIdx.x; e < GEO_CNT_SAMPLES * 3; e += 256) cnt_s[e] = 0;
   for (int base = 0; base < N; base += 1024) {
     const int nb = min(1024, N - base);
     __syncthreads();
-    for (int e = threadIdx.x; e < nb; e += GEO_WAVE) {
+    for (int e = threadIdx.x; e < nb; e += 256) {
       const float2 a = pt1[o + base + e], b = pt2[o + base + e];
       pts[e] = make_float4(a.x, a.y, b.x, b.y);
     }
     __syncthreads();
-    for (int e = 0; e < nb; e++) {
-      const float4 p = pts[e];
-      for (int q = 0; q < 3; q++)
-        if (q < m.n && geo_inlier(m.F[q], p.x, p.y, p.z, p.w, th2)) cnt[q]++;
+    for (int j = 0; j < 32; j++) {
+      const int hs = s_first + j;
+      if (hs >= HS) break;
+      const GeoModelRec* r = models + (size_t)slot * HS + hs;
+      const int nm = r->n;
+      for (int q = 0; q < nm; q++) {
+        double F[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) F[k] = r->F[q][k];
+        int c = 0;
+        for (int e = lane; e < nb; e += 64) {
+          const float4 p = pts[e];
+          c += geo_inlier(F, p.x, p.y, p.z, p.w, th2) ? 1 : 0;
+        }
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+        if (lane == 0) cnt_s[(32 * wave + j) * 3 + q] += c;   // (only this wave touches these entries)
+      }
     }
   }
-  if (h < H) {
-    int* c = counts + ((size_t)pair * Hstride + h) * 3;
-    c[0] = m.n > 0 ? cnt[0] : -1;
-    c[1] = m.n > 1 ? cnt[1] : -1;
-    c[2] = m.n > 2 ? cnt[2] : -1;
+  __syncthreads();
+  for (int e = threadIdx.x; e < GEO_CNT_SAMPLES * 3; e += 256) {
+    const int hs = blockIdx.x * GEO_CNT_SAMPLES + e / 3, q = e % 3;
+    if (hs < HS) counts[((size_t)slot * HS + hs) * 3 + q] = q < models[(size_t)slot * HS + hs].n ? cnt_s[e] : -1;
   }
 }
 
 // One wave per pair: replay OpenCV's sequential loop over the counts (niters shrinks whenever a
-// better model appears: cvRANSACUpdateNumIters, tabulated on the host as R[g] per pair), recompute
+// better model appears: cvRANSACUpdateNumIters, tabulated on the host as R[g] per distinct N), recompute
 // the winning model, write F, the inlier mask and the verdict of GeoVerificationFundamental.
-// Two passes: pass 1 replays the first Hscan samples only; pairs whose budget is still larger than
-// Hscan are flagged in `need` (and finished by pass 2 over all H samples), the others are final.
-__global__ __launch_bounds__(GEO_WAVE) void k_fransac_select(int H, int Hscan, int pass, uint8_t* __restrict__ need,
-                                                              const int* __restrict__ off, const float2* __restrict__ pt1,
+// Two passes: pass 1 (grid = the pairs with enough matches, `slot_pair`) replays the first H1 samples only; pairs whose budget
+// is still larger than H1 are appended to `need_list` (and finished by pass 2 over all H samples: grid = that list, the
+// counts of samples [H1, H) in counts2[k]), the others are final.
+__global__ __launch_bounds__(GEO_WAVE) void k_fransac_select(int H, int H1, int pass, const int* __restrict__ slot_pair, int* __restrict__ need_list,
+                                                              int* __restrict__ need_count, const int* __restrict__ off, const float2* __restrict__ pt1,
                                                               const float2* __restrict__ pt2, uint64_t seed, double th2,
-                                                              int min_points, int min_inliers, const int* __restrict__ counts,
-                                                              const int* __restrict__ niters_tab, double* __restrict__ Fout,
+                                                              int min_inliers, const int* __restrict__ counts1, const int* __restrict__ counts2,
+                                                              const int* __restrict__ niters_tab, const int* __restrict__ tab_off, double* __restrict__ Fout,
                                                               uint8_t* __restrict__ inlier, int* __restrict__ n_inliers,
                                                               uint8_t* __restrict__ ok) {
   __shared__ double A[63];
   __shared__ double Fw[9];
   __shared__ int win[3];
   __shared__ int cl[3 * 1024];
-  const int pair = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
+  if (pass == 2 && (int)blockIdx.x >= *need_count) return;
+  const int slot = pass == 2 ? need_list[blockIdx.x] : (int)blockIdx.x;
+  const int pair = slot_pair[slot];
   const int o = off[pair], N = off[pair + 1] - o;
-  if (pass == 2 && !need[pair]) return;
+  const int Hscan = pass == 1 ? H1 : H;
   if (lane == 0) { win[0] = -1; win[1] = 0; win[2] = H; }
-  if (N >= min_points && N >= 8) {
-    const int* R = niters_tab + o + pair;  // N + 1 entries
+  {
+    const int* R = niters_tab + tab_off[pair];  // N + 1 entries (the table of this N)
     int best = 6;                          // a model must beat modelPoints - 1
     for (int h0 = 0; h0 < Hscan; h0 += 1024) {
       __syncthreads();
       if (h0 >= win[2]) break;  // uniform: win[2] is shared
       const int nh = min(1024, Hscan - h0);
-      for (int e = lane; e < 3 * nh; e += GEO_WAVE) cl[e] = counts[((size_t)pair * H + h0) * 3 + e];
+      for (int e = lane; e < 3 * nh; e += GEO_WAVE) {
+        const int h = h0 + e / 3, q = e % 3;
+        cl[e] = h < H1 ? counts1[((size_t)slot * H1 + h) * 3 + q] : counts2[((size_t)blockIdx.x * (H - H1) + (h - H1)) * 3 + q];
+      }
       __syncthreads();
       if (lane == 0) {
         int niters = win[2];
@@ -289,9 +333,11 @@ __global__ __launch_bounds__(GEO_WAVE) void k_fransac_select(int H, int Hscan, i
   }
   __syncthreads();
   if (pass == 1) {
-    const bool more = N >= min_points && N >= 8 && win[2] > Hscan && Hscan < H;  // the sequential loop would have gone on past Hscan
-    if (lane == 0) need[pair] = more ? 1 : 0;
-    if (more) return;
+    const bool more = win[2] > H1 && H1 < H;  // the sequential loop would have gone on past H1
+    if (more) {
+      if (lane == 0) need_list[atomicAdd(need_count, 1)] = slot;
+      return;
+    }
   }
   const int wh = win[0];
   if (wh < 0) {
@@ -345,6 +391,11 @@ __global__ __launch_bounds__(256) void k_epipolar_batch(int total, const int* __
   inlier[e] = fabs(dis) < th ? 1 : 0;
 }
 
+__global__ void k_gather_int(int n, const int* __restrict__ idx, const int* __restrict__ src, int* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
+}
+
 // cvRANSACUpdateNumIters(p, ep, model_points, max_iters) for ep = (N - g) / N, clamped to max_iters
 static int geo_update_num_iters(double p, double ep, int model_points, int max_iters) {
   p = std::max(p, 0.0); p = std::min(p, 1.0);
@@ -374,46 +425,112 @@ MSFM_API void msfm_fransac_default_options(msfm_fransac_options* o) {
 int geo_fransac_dev(msfm_ctx* ctx, int n_pairs, const int* offsets, const int* d_off, const float* d1, const float* d2,
                     const msfm_fransac_options* opt, double* dF, uint8_t* d_in, int* d_nin, uint8_t* d_ok) {
   hipStream_t s = ctx->stream;
-  const int total = offsets[n_pairs];
   const int H = opt->max_iterations;
-  // R[g] per pair (N + 1 entries each)
-  std::vector<int> tab((size_t)total + n_pairs);
-  par_ranges((size_t)n_pairs, host_threads(), [&](int, size_t p0, size_t p1) {   // (N + 1) log / pow evaluations per pair
-    for (size_t p = p0; p < p1; p++) {
-      const int o = offsets[p], N = offsets[p + 1] - o;
-      int* R = tab.data() + o + p;
-      for (int g = 0; g <= N; g++) R[g] = N > 0 ? geo_update_num_iters(opt->confidence, (double)(N - g) / N, 7, H) : H;
+  // R[g] = cvRANSACUpdateNumIters for g inliers of N: a pow and two logs per entry.  The table of a pair depends on its N
+  // alone, so one table per DISTINCT N is formed (and kept from call to call while confidence and sample limit stay the same:
+  // the matching loop verifies thousands of pairs with one set of options) - at 9 120 pairs of ~125 good matches each the
+  // per-pair tables were 1.1 M evaluations, 7 of the 15 ms of msfm_chain_verify on sixteen host threads.
+  std::vector<int> tab, tab_off(std::max(1, n_pairs), 0);
+  {
+    struct TabCache { std::mutex mu; double conf = -1.0; int H = -1; std::unordered_map<int, std::vector<int>> by_n; size_t entries = 0; };
+    static TabCache cache;
+    std::lock_guard<std::mutex> lock(cache.mu);
+    if (cache.conf != opt->confidence || cache.H != H || cache.entries > (size_t)32 << 20) {
+      cache.by_n.clear(); cache.entries = 0; cache.conf = opt->confidence; cache.H = H;
     }
-  }, 16);
-  DevBuf<int> d_tab, d_counts;
+    std::vector<int> missing;
+    for (int p = 0; p < n_pairs; p++) {
+      const int N = offsets[p + 1] - offsets[p];
+      if (N >= opt->min_points && N >= 8 && cache.by_n.find(N) == cache.by_n.end()) { cache.by_n[N]; missing.push_back(N); }
+    }
+    std::vector<std::vector<int>*> slot(missing.size());
+    for (size_t k = 0; k < missing.size(); k++) { slot[k] = &cache.by_n[missing[k]]; slot[k]->resize((size_t)missing[k] + 1); cache.entries += (size_t)missing[k] + 1; }
+    par_ranges(missing.size(), host_threads(), [&](int, size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; k++) {
+        const int N = missing[k];
+        int* R = slot[k]->data();
+        for (int g = 0; g <= N; g++) R[g] = geo_update_num_iters(opt->confidence, (double)(N - g) / N, 7, H);
+      }
+    }, 4);
+    std::unordered_map<int, int> at;   // N -> offset of its table in this call's upload
+    for (int p = 0; p < n_pairs; p++) {
+      const int N = offsets[p + 1] - offsets[p];
+      if (!(N >= opt->min_points && N >= 8)) continue;   // (the kernels do not look at the table of such a pair)
+      auto it = at.find(N);
+      if (it == at.end()) {
+        it = at.emplace(N, (int)tab.size()).first;
+        const std::vector<int>& R = cache.by_n[N];
+        tab.insert(tab.end(), R.begin(), R.end());
+      }
+      tab_off[p] = it->second;
+    }
+    if (tab.empty()) tab.push_back(H);
+  }
+  DevBuf<int> d_tab_off;
+  HIP_TRY(ctx, d_tab_off.from(tab_off, s));
+  DevBuf<int> d_tab;
   HIP_TRY(ctx, d_tab.from(tab, s));
-  HIP_TRY(ctx, d_counts.alloc((size_t)n_pairs * H * 3));
   const double th2 = opt->threshold * opt->threshold;
+  // pairs without enough matches (GeoVerificationFundamental: pt1.size() < 30 -> false) get their verdict here; the others
+  // form the slot list the kernels run over
+  std::vector<int> slot_pair;
+  for (int p = 0; p < n_pairs; p++) {
+    const int N = offsets[p + 1] - offsets[p];
+    if (N >= opt->min_points && N >= 8) slot_pair.push_back(p);
+  }
+  const int n_slots = (int)slot_pair.size();
+  HIP_TRY(ctx, hipMemsetAsync(dF, 0, sizeof(double) * 9 * (size_t)n_pairs, s));
+  HIP_TRY(ctx, hipMemsetAsync(d_in, 0, (size_t)std::max(1, offsets[n_pairs]), s));
+  HIP_TRY(ctx, hipMemsetAsync(d_nin, 0, sizeof(int) * (size_t)n_pairs, s));
+  HIP_TRY(ctx, hipMemsetAsync(d_ok, 0, (size_t)n_pairs, s));
+  if (n_slots == 0) { HIP_TRY(ctx, hipStreamSynchronize(s)); return MSFM_OK; }
   // Most pairs stop after a few dozen samples (cvRANSACUpdateNumIters): score the first H1 samples of every pair,
   // replay them, and run the remaining H - H1 samples only for the pairs whose budget is still open.
   const int H1 = std::min(H, 128);
-  DevBuf<uint8_t> d_need;
-  HIP_TRY(ctx, d_need.alloc(n_pairs));
-  auto score = [&](int h0, int h1, const uint8_t* need) {
-    KTimer t(ctx, "geo_fransac_score");
-    for (int p0 = 0; p0 < n_pairs; p0 += 32768) {  // grid.y limit
-      const int np = std::min(32768, n_pairs - p0);
-      hipLaunchKernelGGL(k_fransac_score, dim3(cdiv(h1 - h0, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, H, h0, h1, p0, d_off,
-                         reinterpret_cast<const float2*>(d1), reinterpret_cast<const float2*>(d2), opt->seed, th2,
-                         opt->min_points, need, d_counts.p);
+  DevBuf<int> d_slot_pair, d_need, d_counts1, d_counts2;
+  DevBuf<GeoModelRec> d_models1, d_models2;
+  HIP_TRY(ctx, d_slot_pair.from(slot_pair, s));
+  HIP_TRY(ctx, d_need.alloc((size_t)n_slots + 1));   // [0]: how many, [1..]: the slots
+  HIP_TRY(ctx, hipMemsetAsync(d_need.p, 0, sizeof(int), s));
+  HIP_TRY(ctx, d_counts1.alloc((size_t)n_slots * H1 * 3));
+  HIP_TRY(ctx, d_models1.alloc((size_t)n_slots * H1));
+  const float2* p1 = reinterpret_cast<const float2*>(d1);
+  const float2* p2 = reinterpret_cast<const float2*>(d2);
+  auto score = [&](int h0, int h1, int ns, const int* slots, const int* ns_dev, GeoModelRec* models, int* counts, const char* name) {
+    KTimer t(ctx, name);
+    for (int p0 = 0; p0 < ns; p0 += 32768) {  // grid.y limit
+      const int np = std::min(32768, ns - p0);
+      // (ns_dev counts from the start of the list: only a single slice may use it)
+      hipLaunchKernelGGL(k_fransac_models, dim3(cdiv(h1 - h0, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, h0, h1, slots + p0, ns > 32768 ? nullptr : ns_dev, d_off,
+                         p1, p2, opt->seed, models + (size_t)p0 * (h1 - h0));
+      hipLaunchKernelGGL(k_fransac_count, dim3(cdiv(h1 - h0, GEO_CNT_SAMPLES), np), dim3(256), 0, s, h0, h1, slots + p0, ns > 32768 ? nullptr : ns_dev, d_off,
+                         p1, p2, th2, models + (size_t)p0 * (h1 - h0), counts + (size_t)p0 * (h1 - h0) * 3);
     }
   };
-  auto select = [&](int hscan, int pass) {
+  auto select = [&](int pass, int grid) {
     KTimer t(ctx, "geo_fransac_select");
-    hipLaunchKernelGGL(k_fransac_select, dim3(n_pairs), dim3(GEO_WAVE), 0, s, H, hscan, pass, d_need.p, d_off,
-                       reinterpret_cast<const float2*>(d1), reinterpret_cast<const float2*>(d2), opt->seed, th2, opt->min_points,
-                       opt->min_inliers, d_counts.p, d_tab.p, dF, d_in, d_nin, d_ok);
+    hipLaunchKernelGGL(k_fransac_select, dim3(grid), dim3(GEO_WAVE), 0, s, H, H1, pass, d_slot_pair.p, d_need.p + 1, d_need.p, d_off, p1, p2, opt->seed, th2,
+                       opt->min_inliers, d_counts1.p, d_counts2.p, d_tab.p, d_tab_off.p, dF, d_in, d_nin, d_ok);
   };
-  score(0, H1, nullptr);
-  select(H1, 1);
+  score(0, H1, n_slots, d_slot_pair.p, nullptr, d_models1.p, d_counts1.p, "geo_fransac_score");
+  select(1, n_slots);
   if (H1 < H) {
-    score(H1, H, d_need.p);
-    select(H, 2);
+    int n_need = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_need, d_need.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (n_need > 0) {
+      HIP_TRY(ctx, d_counts2.alloc((size_t)n_need * (H - H1) * 3));
+      HIP_TRY(ctx, d_models2.alloc((size_t)n_need * (H - H1)));
+      // the list holds SLOTS; the kernels of the second range want pairs
+      DevBuf<int> d_need_pair;
+      HIP_TRY(ctx, d_need_pair.alloc(n_need));
+      hipLaunchKernelGGL(k_gather_int, dim3(cdiv(n_need, 256)), dim3(256), 0, s, n_need, d_need.p + 1, d_slot_pair.p, d_need_pair.p);
+      score(H1, H, n_need, d_need_pair.p, nullptr, d_models2.p, d_counts2.p, "geo_fransac_score_rest");
+      select(2, n_need);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(s));
+      return MSFM_OK;
+    }
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamSynchronize(s));   // the tables and counters above are released on return
