@@ -897,12 +897,26 @@ __global__ __launch_bounds__(64) void k_modelsum(const int* __restrict__ mcam_fi
   double acc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.0;
-  for (int q = mcam_first[mb] + lane; q < mcam_first[mb + 1]; q += 64) {
-    const double* f = camftf + (size_t)mcam[q] * PSTRIDE;
+  // (a lane's cameras q, q + 64, ... in that order; the records of FOUR of them are asked for before the first is added - the
+  //  launch is one wave whose time is its dependent load rounds: 8 rounds of 12 loads at config 3, 12.7 us, before)
+  const int q1 = mcam_first[mb + 1];
+  for (int q = mcam_first[mb] + lane; q < q1; q += 256) {
+    double v[4][12];
 #pragma unroll
-    for (int k = 0; k < 9; k++) acc[k] += f[F_JMJM + k];
+    for (int j = 0; j < 4; j++) {
+      const int qq = q + 64 * j;
+      const double* f = camftf + (size_t)mcam[min(qq, q1 - 1)] * PSTRIDE;
 #pragma unroll
-    for (int k = 0; k < 3; k++) acc[9 + k] += f[F_JMR + k];
+      for (int k = 0; k < 9; k++) v[j][k] = f[F_JMJM + k];
+#pragma unroll
+      for (int k = 0; k < 3; k++) v[j][9 + k] = f[F_JMR + k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (q + 64 * j < q1) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) acc[k] += v[j][k];
+      }
   }
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = wave_sum(acc[k]);

@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict_
   u32 aD0 = 0xffffffffu, aD1 = 0xffffffffu, bD0 = 0xffffffffu, bD1 = 0xffffffffu;
   int aI0 = 0x7fffffff, aI1 = 0x7fffffff, bI0 = 0x7fffffff, bI1 = 0x7fffffff;
   u32 ak0 = 0xffffffffu, ak1 = 0xffffffffu, bk0 = 0xffffffffu, bk1 = 0xffffffffu;
+  u32 aTl = 0x7fffffffu, bTl = 0x7fffffffu;
   const int n_tiles = (T.n_train + TT - 1) / TT;
   // staging: 64 rows x 8 chunks of 16 B = 512 chunks, 2 per thread; chunk' = chunk ^ ((row >> 1) & 7)
   uint4 stage[2];
@@ -443,7 +444,12 @@ __global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict_
 #ifndef MSFM_KNN_GROUP
 #define MSFM_KNN_GROUP 4
 #endif
+#ifndef MSFM_KNN_NOSHARE
+      // (aTl / bTl: the second smallest m over the lists of BOTH lanes that hold this query - see the flush below)
+      u32 thra = min(ak1 >> 9, aTl), thrb = min(bk1 >> 9, bTl);
+#else
       u32 thra = min(ak1 >> 9, aD1 >> 1), thrb = min(bk1 >> 9, bD1 >> 1);
+#endif
       // all the compares of a group of register slots first (their results are wave masks in scalar registers - no compare ->
       // branch latency per slot), then the selection for the slots whose mask is not empty.  The key formation is volatile
       // assembly so that it stays inside the conditional block (the compiler would otherwise hoist it in front of the tests).
@@ -535,6 +541,20 @@ __global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict_
       const int base = (tile & ~3) * TT;
       flush_window8(ak0, ak1, aD0, aI0, aD1, aI1, base);
       flush_window8(bk0, bk1, bD0, bI0, bD1, bI1, base);
+#ifndef MSFM_KNN_NOSHARE
+      // A query's train rows are split between lanes r and r + 32, each with its own list.  A candidate worse than the second
+      // best of the two lists TOGETHER cannot be among the query's two nearest, whichever lane it falls to: that bound (formed
+      // here, where the lists change - once per 256 rows) halves the candidates that pass the compare filter late in the sweep
+      // (a row enters a lane's own top two with probability 4 / rows seen, the query's with 2 / rows seen).
+      {
+        const auto a0 = __builtin_amdgcn_permlane32_swap(aD0 >> 1, aD0 >> 1, false, false);
+        const auto a1 = __builtin_amdgcn_permlane32_swap(aD1 >> 1, aD1 >> 1, false, false);
+        aTl = min(max((u32)a0[0], (u32)a0[1]), min((u32)a1[0], (u32)a1[1]));
+        const auto b0 = __builtin_amdgcn_permlane32_swap(bD0 >> 1, bD0 >> 1, false, false);
+        const auto b1 = __builtin_amdgcn_permlane32_swap(bD1 >> 1, bD1 >> 1, false, false);
+        bTl = min(max((u32)b0[0], (u32)b0[1]), min((u32)b1[0], (u32)b1[1]));
+      }
+#endif
     }
     if (tile + 1 < n_tiles) commit(cur ^ 1);
     __syncthreads();

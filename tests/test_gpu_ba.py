@@ -542,3 +542,57 @@ def test_ba_persistent_panel_chain_is_bit_identical_to_the_launch_chain(ctx, mon
     np.testing.assert_array_equal(res["launches"][1], res["chain"][1])
     for x, y in zip(res["launches"][2], res["chain"][2]):
         np.testing.assert_array_equal(x, y)
+
+
+def test_ba_device_side_verdict_and_launch_ahead_are_bit_identical_to_the_host_order(ctx, monkeypatch):
+    """Round 4: the step's verdict (valid / tolerances / accept + radius / reject) is formed on the device and the next
+    linearisation - rows of frozen points, GPS rows, k_point - is enqueued behind it before the host has seen the step,
+    gated and given its radius by the device.  MSFM_SPEC=0 enqueues it only after the read-back, as before.  Both orders
+    must give the same trajectory to the last bit: accepted and rejected steps (frozen cameras left at perturbed poses), the iteration cap,
+    convergence by tolerance, frozen cameras / points / intrinsics with GPS rows (the gated small kernels), and a resident
+    problem run twice (a launch enqueued ahead of the last step of the first run must leave nothing behind)."""
+    from metricsfm_amd import capi
+    rng = np.random.default_rng(5)
+    sc1 = scene.make_ring_scene(6, 300, seed=11)
+    sc2 = scene.make_aerial_scene(24, 3000, seed=5, gps_sigma=0.5, rot_sigma=0.02, trans_sigma=0.2, point_sigma=0.2)
+    cam_mut = (np.arange(sc2.n_cams) % 3 != 0).astype(np.uint8)
+    pt_mut = (rng.random(sc2.n_points) > 0.2).astype(np.uint8)
+    sc3 = scene.make_aerial_scene(14, 2000, seed=17)
+    cm3 = np.ones(sc3.n_cams, np.uint8); cm3[::4] = 0
+    pm3 = (np.arange(sc3.n_points) % 11 != 0).astype(np.uint8)
+    cases = [
+        (lambda: A.BaArrays.from_scene(sc3, cam_mutable=cm3, pt_mutable=pm3), dict(max_num_iterations=12)),   # rejected steps
+        (lambda: A.BaArrays.from_scene(sc1), dict(max_num_iterations=14, initial_trust_region_radius=1e7)),
+        (lambda: A.BaArrays.from_scene(sc1), dict(max_num_iterations=5, initial_trust_region_radius=1e-2)),   # the cap
+        (lambda: A.BaArrays.from_scene(sc1), dict(max_num_iterations=60)),                                    # a tolerance stops it
+        (lambda: A.BaArrays.from_scene(sc2, gps_xyz=sc2.gps_xyz, gps_weight=float(sc2.n_obs // sc2.n_cams), cam_mutable=cam_mut, pt_mutable=pt_mut),
+         dict(max_num_iterations=20)),
+    ]
+    for mk, kw in cases:
+        out = []
+        for spec in ("0", "1"):
+            monkeypatch.setenv("MSFM_SPEC", spec)
+            a = mk()
+            r = ctx.ba_solve(a, capi.default_options(**kw))
+            out.append((r, a))
+        (r0, a0), (r1, a1) = out
+        assert r0["termination"] == r1["termination"] and r0["num_iterations"] == r1["num_iterations"]
+        for key in ("cost", "gradient_max_norm", "step_norm", "step_is_successful", "step_is_valid", "trust_region_radius", "relative_decrease"):
+            np.testing.assert_array_equal(r0["iterations"][key], r1["iterations"][key])
+        for name in ("cam_pose", "cam_model", "point"):
+            np.testing.assert_array_equal(getattr(a0, name), getattr(a1, name))
+    r_rej = ctx.ba_solve(cases[0][0](), capi.default_options(**cases[0][1]))
+    ok_steps = r_rej["iterations"]["step_is_successful"][1:]
+    assert (ok_steps == 0).sum() >= 3 and (ok_steps == 1).sum() >= 3, "the first case is meant to mix rejected and accepted steps"
+    res = []
+    for spec in ("0", "1"):
+        monkeypatch.setenv("MSFM_SPEC", spec)
+        ba = ctx.ba(cases[4][0]())
+        ra = ba.run(capi.default_options(max_num_iterations=3))
+        rb = ba.run(capi.default_options(max_num_iterations=4))
+        res.append((ra["iterations"]["cost"], rb["iterations"]["cost"], ba.download()))
+        ba.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    for x, y in zip(res[0][2], res[1][2]):
+        np.testing.assert_array_equal(x, y)
