@@ -724,9 +724,9 @@ struct CamRows {
   const double *x, *y, *w;   // [NCR]
   const int4* chunk_cam;     // [chunks] camera, intrinsics, camera block, intrinsics block (-1: frozen) of the chunk's rows
 };
-__global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end, BaPtrs P, CamRows R,
-                                              const double* __restrict__ Tu, const int* __restrict__ cpos_pb, double* __restrict__ partial) {
-  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void ftf_body(int blk, int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end, const BaPtrs& P, const CamRows& R,
+                                         const double* __restrict__ Tu, const int* __restrict__ cpos_pb, double* __restrict__ partial) {
+  const int chunk = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (chunk >= nchunk) return;
   // Jc^T Jc and Jm^T Jm are symmetric: 21 + 6 of their 36 + 9 entries are accumulated (the mirrored ones are the same
   // products in the other order, so the stored 78 values are what the full loops gave).
@@ -828,6 +828,10 @@ __global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__
     out[o1] = v;
     if (o2 != o1) out[o2] = v;
   }
+}
+__global__ __launch_bounds__(256) void k_ftf(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end, BaPtrs P, CamRows R,
+                                              const double* __restrict__ Tu, const int* __restrict__ cpos_pb, double* __restrict__ partial) {
+  ftf_body(blockIdx.x, nchunk, ch_start, ch_end, P, R, Tu, cpos_pb, partial);
 }
 
 // Sum the FTF partials of each camera block (fixed order) -> camftf[cb][PSTRIDE]; the GPS rows
@@ -940,17 +944,21 @@ __global__ void k_make_scale(int n, const double* __restrict__ norm2, double* __
 // --------------------------------------------------------------------------------------
 // k_pairs: one wave per chunk of a block-pair list: sum_e A[pa[e]] (DA x 3) * B[pb[e]]^T (3 x DB).
 // --------------------------------------------------------------------------------------
-template <int DA, int DB, bool WITH_U>
-__global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
-                                                const int* __restrict__ pa, const int* __restrict__ pb,
-                                                const double* __restrict__ TA, const double* __restrict__ TB,
-                                                const double* __restrict__ UA, size_t plane, double* __restrict__ partial,
-                                                const int* __restrict__ live = nullptr) {
+// SPARSE: the list of a problem whose products were formed inside k_point (FoldTables) - only a few entries of a visited chunk
+// are still live (0.4 % at config 3).  All index words of the chunk are asked for at once and the sixty-four-entry steps
+// without a live entry are skipped as a wave, instead of sixteen dependent load -> test rounds (the three residue launches
+// were 20 us each for a few thousand products).
+template <int DA, int DB, bool WITH_U, bool SPARSE = false>
+__device__ __forceinline__ void pairs_body(int blk, int nblk, int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
+                                           const int* __restrict__ pa, const int* __restrict__ pb,
+                                           const double* __restrict__ TA, const double* __restrict__ TB,
+                                           const double* __restrict__ UA, size_t plane, double* __restrict__ partial,
+                                           const int* __restrict__ live) {
   constexpr int NOUT = DA * DB + (WITH_U ? DA : 0);
   // XCD-aware chunk order: workgroups b, b+8, ... share an XCD (and its L2), so hand each XCD a
   // contiguous range of chunks — chunks are sorted by (row camera, col camera), a contiguous range
   // keeps re-reading the same cameras' T segments (speed only; any mapping is correct)
-  const int nwg = gridDim.x, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int nwg = nblk, xcd = blk & 7, loc = blk >> 3;
   const int qn = nwg >> 3, rm = nwg & 7;
   const int swz = (xcd < rm ? xcd * (qn + 1) : rm * (qn + 1) + (xcd - rm) * qn) + loc;
   const int cidx = swz * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -959,9 +967,27 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
   double acc[NOUT];
 #pragma unroll
   for (int k = 0; k < NOUT; k++) acc[k] = 0.0;
-  for (int e = ch_start[chunk] + lane; e < ch_end[chunk]; e += 64) {
-    const int ia = pa[e], ib = pb[e];
+  const int e0 = ch_start[chunk] + lane, e1 = ch_end[chunk];
+  constexpr int NPRE = SPARSE ? CHUNK / 64 : 1;
+  int pre_a[NPRE];
+  if constexpr (SPARSE) {
+#pragma unroll
+    for (int k = 0; k < NPRE; k++) pre_a[k] = e0 + 64 * k < e1 ? pa[e0 + 64 * k] : -1;
+  }
+#pragma unroll 1
+  for (int e = e0, step = 0; e < e1 || (SPARSE && step < NPRE); e += 64, step++) {
+    int ia;
+    if constexpr (SPARSE) {
+      if (step >= NPRE) break;
+      ia = -1;
+#pragma unroll
+      for (int k = 0; k < NPRE; k++) if (k == step) ia = pre_a[k];
+      if (__builtin_amdgcn_ballot_w64(ia >= 0) == 0ull) continue;   // nothing live in these sixty-four entries
+    } else {
+      ia = pa[e];
+    }
     if (ia < 0) continue;   // formed inside k_point (FoldTables)
+    const int ib = pb[e];
     double ta[DA * 3], tb[DB * 3];
     // 6-row records (camera blocks) live component-major, T[k][position] with `plane` positions per component;
     // 3-row records (intrinsics entries) are small contiguous records
@@ -993,6 +1019,14 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
   }
   wave_reduce_store<NOUT>(acc, partial + (size_t)chunk * NOUT, lane);
 }
+template <int DA, int DB, bool WITH_U, bool SPARSE = false>
+__global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ ch_end,
+                                                const int* __restrict__ pa, const int* __restrict__ pb,
+                                                const double* __restrict__ TA, const double* __restrict__ TB,
+                                                const double* __restrict__ UA, size_t plane, double* __restrict__ partial,
+                                                const int* __restrict__ live = nullptr) {
+  pairs_body<DA, DB, WITH_U, SPARSE>(blockIdx.x, gridDim.x, nchunk, ch_start, ch_end, pa, pb, TA, TB, UA, plane, partial, live);
+}
 
 // --------------------------------------------------------------------------------------
 // Assembly of the padded dense system M (row-major npad x npad, lower triangle; row n = rhs).
@@ -1002,8 +1036,7 @@ __global__ __launch_bounds__(256) void k_pairs(int nchunk, const int* __restrict
 // and of the root chain (everything else is structurally zero and never touched: at config 3 one tile in five of the square).
 // lev[b] / lo[b] / hi[b]: level and leaf interval of the node that owns 64-block b (root: level 127, every leaf).
 struct ZeroMap { unsigned char lev[256]; short lo[256], hi[256]; int nb; };
-__global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int ld, ZeroMap Z) {
-  const int tile = blockIdx.x;
+__device__ __forceinline__ void zero_tile_body(int tile, double* __restrict__ M, int ld, const ZeroMap& Z) {
   int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
   while (I * (I + 1) / 2 > tile) I--;
   while ((I + 1) * (I + 2) / 2 <= tile) I++;
@@ -1013,6 +1046,39 @@ __global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int
   if (!same && !above) return;
   double2* base = reinterpret_cast<double2*>(M + (size_t)(64 * I) * ld + 64 * J);
   for (int e = threadIdx.x; e < 64 * 32; e += 256) base[(size_t)(e >> 5) * (ld / 2) + (e & 31)] = make_double2(0.0, 0.0);
+}
+__global__ __launch_bounds__(256) void k_zero_system(double* __restrict__ M, int ld, ZeroMap Z) { zero_tile_body(blockIdx.x, M, ld, Z); }
+
+// With the Schur products formed inside k_point (FoldTables) what is left between k_point and the assembly is the per-camera
+// sums (k_ftf's chunks), a residue of the three pair lists (a few thousand live entries; the intrinsics x intrinsics list in
+// full: one 3 x 3 product per point) and the zero fill of the reduced system - rounds 3-4 ran the residue and the fill as
+// four launches on a second stream beside k_ftf: two events on the main stream (13 + 6 us of idle time around them in the
+// kernel trace) and three 19 us launches for next to no work.  Here they are ONE launch on the main stream: the residue and
+// the zero tiles are its first workgroups and finish in the shadow of the camera chunks.  Same arithmetic per chunk, so the
+// partials - and the solve - are bit-identical to the separate launches (MSFM_FUSED_SUMS=0).
+struct SumsArgs {
+  int n_zero, n_mc_wg, n_mm_wg, n_cc_wg, n_ftf_wg;   // workgroups of each part, in this order
+  // zero fill
+  double* M; int ld; ZeroMap Z;
+  // pair lists: intrinsics x camera (live chunks), intrinsics x intrinsics (all), camera x camera (live chunks)
+  int mc_n; const int *mc_start, *mc_end, *mc_pa, *mc_pb, *mc_live; double* mc_partial;
+  int mm_n; const int *mm_start, *mm_end, *mm_pa, *mm_pb; double* mm_partial;
+  int cc_n; const int *cc_start, *cc_end, *cc_pa, *cc_pb, *cc_live; double* cc_partial;
+  const double *T, *Tm, *Tmu; size_t plane;
+  // per-camera sums
+  int f_n; const int *f_start, *f_end; BaPtrs P; CamRows R; const double* Tu; const int* cpos_pb; double* f_partial;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sums(SumsArgs a) {
+  int b = blockIdx.x;
+  if (b < a.n_zero) { zero_tile_body(b, a.M, a.ld, a.Z); return; }
+  b -= a.n_zero;
+  if (b < a.n_mc_wg) { pairs_body<3, 6, false, true>(b, a.n_mc_wg, a.mc_n, a.mc_start, a.mc_end, a.mc_pa, a.mc_pb, a.Tm, a.T, nullptr, a.plane, a.mc_partial, a.mc_live); return; }
+  b -= a.n_mc_wg;
+  if (b < a.n_mm_wg) { pairs_body<3, 3, true, false>(b, a.n_mm_wg, a.mm_n, a.mm_start, a.mm_end, a.mm_pa, a.mm_pb, a.Tm, a.Tm, a.Tmu, (size_t)0, a.mm_partial, nullptr); return; }
+  b -= a.n_mm_wg;
+  if (b < a.n_cc_wg) { pairs_body<6, 6, false, true>(b, a.n_cc_wg, a.cc_n, a.cc_start, a.cc_end, a.cc_pa, a.cc_pb, a.T, a.T, nullptr, a.plane, a.cc_partial, a.cc_live); return; }
+  b -= a.n_cc_wg;
+  ftf_body(b, a.f_n, a.f_start, a.f_end, a.P, a.R, a.Tu, a.cpos_pb, a.f_partial);
 }
 
 // camera-camera blocks: one block per 64-thread workgroup; 18 threads hold two neighbouring entries of a row each (16-byte
@@ -3735,7 +3801,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   auto launch_pairs = [&](hipStream_t sp) {
     if (ba->fold.on && ba->fold.mc_on) {
       if (ba->fold.mc_n_live)
-        hipLaunchKernelGGL((k_pairs<3, 6, false>), dim3(cdiv(ba->fold.mc_n_live, 4)), dim3(256), 0, sp, ba->fold.mc_n_live, ba->mc.ch_start.p,
+        hipLaunchKernelGGL((k_pairs<3, 6, false, true>), dim3(cdiv(ba->fold.mc_n_live, 4)), dim3(256), 0, sp, ba->fold.mc_n_live, ba->mc.ch_start.p,
                            ba->mc.ch_end.p, ba->mc.pa.p, ba->mc.pb.p, ba->Tm.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR),
                            ba->mc.partial.p, ba->fold.mc_live_chunk.p);
     } else if (ba->mc.n_chunks)
@@ -3746,7 +3812,7 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
                          ba->mm.ch_end.p, ba->mm.pa.p, ba->mm.pb.p, ba->Tm.p, ba->Tm.p, ba->Tmu.p, (size_t)0, ba->mm.partial.p);
     if (ba->fold.on) {
       if (ba->fold.n_live)
-        hipLaunchKernelGGL((k_pairs<6, 6, false>), dim3(cdiv(ba->fold.n_live, 4)), dim3(256), 0, sp, ba->fold.n_live, ba->cc.ch_start.p,
+        hipLaunchKernelGGL((k_pairs<6, 6, false, true>), dim3(cdiv(ba->fold.n_live, 4)), dim3(256), 0, sp, ba->fold.n_live, ba->cc.ch_start.p,
                            ba->cc.ch_end.p, ba->cc.pa.p, ba->cc.pb.p, ba->T.p, ba->T.p, (const double*)nullptr, (size_t)std::max(1, ba->NCR),
                            ba->cc.partial.p, ba->fold.live_chunk.p);
     } else if (ba->cc.n_chunks)
@@ -3758,7 +3824,11 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   // pays again (1.251 -> 1.229 ms per iteration at config 3).  So: forked when the fold tables are on, MSFM_OVERLAP=0 / 1 forces.
   static const char* overlap_env = getenv("MSFM_OVERLAP");
   const bool overlap = overlap_env ? atoi(overlap_env) != 0 : ba->fold.on;
-  const bool forked = mode == 0 && !ctx->profile && overlap;
+  // (round 4, later: with the fold tables and one intrinsics block everything between k_point and the assembly is ONE launch on
+  //  the main stream - k_sums - and nothing is forked)
+  static const char* fused_env = getenv("MSFM_FUSED_SUMS");
+  const bool fused = mode == 0 && ba->fold.on && ba->fold.mc_on && ba->n_fchunks > 0 && !(fused_env && atoi(fused_env) == 0);
+  const bool forked = mode == 0 && !ctx->profile && overlap && !fused;
   // zero fill of the reduced system in front of the assembly (reads nothing: with the fork it runs on the second stream too)
   auto zero_system = [&](hipStream_t sz) -> int {
     const int nb64 = ba->npad / 64;
@@ -3777,6 +3847,18 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
       hipLaunchKernelGGL(k_zero_system, dim3(nb64 * (nb64 + 1) / 2), dim3(256), 0, sz, ba->M.p, ba->npad, Z);
     }
     return MSFM_OK;
+  };
+  auto zero_map = [&](ZeroMap& Z) -> int {   // the tiles k_sums fills (0: the plain memset is needed instead)
+    const int nb64 = ba->npad / 64;
+    if (ctx->world > 1 || nb64 > 256) return 0;
+    Z.nb = nb64;
+    for (int b = 0; b < nb64; b++) { Z.lev[b] = 127; Z.lo[b] = 0; Z.hi[b] = 0x7fff; }
+    for (int lv = 0; lv < ba->plan.n_levels; lv++)
+      for (int k = 0; k < ba->plan.level[lv].K; k++) {
+        const msfm_chol_node& nd = ba->plan.level[lv].node[k];
+        for (int b = nd.begin / 64; b < nd.end / 64; b++) { Z.lev[b] = (unsigned char)lv; Z.lo[b] = (short)nd.leaf_lo; Z.hi[b] = (short)nd.leaf_hi; }
+      }
+    return nb64 * (nb64 + 1) / 2;
   };
   if (forked) {
     if (!ctx->stream2) {
@@ -3801,8 +3883,24 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   double* gmax_m = gmax_c + 6 * (size_t)ncb;
   {
     KTimer t(ctx, "ba_ftf");
-    if (ba->n_fchunks)
-    {
+    if (fused) {
+      const size_t ncr = (size_t)std::max(1, ba->NCR);
+      SumsArgs a;
+      a.n_zero = zero_map(a.Z);
+      if (a.n_zero == 0) MSFM_TRY(zero_system(s));
+      a.M = ba->M.p; a.ld = ba->npad;
+      a.mc_n = ba->fold.mc_n_live; a.mc_start = ba->mc.ch_start.p; a.mc_end = ba->mc.ch_end.p; a.mc_pa = ba->mc.pa.p; a.mc_pb = ba->mc.pb.p;
+      a.mc_live = ba->fold.mc_live_chunk.p; a.mc_partial = ba->mc.partial.p;
+      a.mm_n = ba->mm.n_chunks; a.mm_start = ba->mm.ch_start.p; a.mm_end = ba->mm.ch_end.p; a.mm_pa = ba->mm.pa.p; a.mm_pb = ba->mm.pb.p; a.mm_partial = ba->mm.partial.p;
+      a.cc_n = ba->fold.n_live; a.cc_start = ba->cc.ch_start.p; a.cc_end = ba->cc.ch_end.p; a.cc_pa = ba->cc.pa.p; a.cc_pb = ba->cc.pb.p;
+      a.cc_live = ba->fold.live_chunk.p; a.cc_partial = ba->cc.partial.p;
+      a.T = ba->T.p; a.Tm = ba->Tm.p; a.Tmu = ba->Tmu.p; a.plane = ncr;
+      a.f_n = ba->n_fchunks; a.f_start = ba->f_start.p; a.f_end = ba->f_end.p; a.P = make_ptrs(ba, false, ba->lin_huber);
+      a.R = CamRows{ba->cm_pt.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
+      a.Tu = ba->Tu.p; a.cpos_pb = ba->cpos_pb.p; a.f_partial = ba->f_partial.p;
+      a.n_mc_wg = cdiv(a.mc_n, 4); a.n_mm_wg = cdiv(a.mm_n, 4); a.n_cc_wg = cdiv(a.cc_n, 4); a.n_ftf_wg = cdiv(a.f_n, 4);
+      hipLaunchKernelGGL(k_sums, dim3(a.n_zero + a.n_mc_wg + a.n_mm_wg + a.n_cc_wg + a.n_ftf_wg), dim3(256), 0, s, a);
+    } else if (ba->n_fchunks) {
       const size_t ncr = (size_t)std::max(1, ba->NCR);
       const CamRows R{ba->cm_pt.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
       hipLaunchKernelGGL(k_ftf, dim3(cdiv(ba->n_fchunks, 4)), dim3(256), 0, s, ba->n_fchunks, ba->f_start.p, ba->f_end.p,
@@ -3842,13 +3940,13 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
     join.armed = false;
     const hipError_t je = hipStreamWaitEvent(s, ctx->ev_join, 0);
     if (je != hipSuccess) { (void)hipStreamSynchronize(ctx->stream2); HIP_TRY(ctx, je); }
-  } else {
+  } else if (!fused) {
     KTimer t(ctx, "ba_schur_pairs");
     launch_pairs(s);
   }
   {
     KTimer t(ctx, "ba_assemble");
-    if (!forked) MSFM_TRY(zero_system(s));   // (forked: done on the second stream beside the per-camera sums, joined above)
+    if (!forked && !fused) MSFM_TRY(zero_system(s));   // (forked: done on the second stream beside the per-camera sums, joined above)
     AsmArgs aa;
     aa.n_cc = ba->cc.n_blocks; aa.n_mc = ba->mc.n_blocks; aa.n_mm = ba->mm.n_blocks; aa.n_rhs = cdiv(6 * ncb, 64);
     aa.cc_row = ba->cc.blk_row.p; aa.cc_col = ba->cc.blk_col.p; aa.cc_first = (ba->fold.on && ba->fold.all) ? nullptr : ba->cc.blk_chunk_first.p; aa.cc_partial = ba->cc.partial.p;
