@@ -336,7 +336,9 @@ def main():
         add("ba_assemble", "hbm", fold_bytes + (cc_live + mc_live > 0) * 0 + lay["reduced_order"] ** 2 * 4,
             "slot partials in, lower triangle of the reduced system out")
         add("ba_backsub", "hbm", sc.n_obs * 52 + sc.n_points * 12 * 8, "row data, point and its 3x3 factor in, candidate point out")
-        add("ba_ftf", "hbm", sc.n_obs * (28 + 24 + 48 + 4), "camera-major statics (28 B), point (24 B), T.u (48 B) per row in; the rows are linearised again")
+        add("ba_ftf", "hbm", sc.n_obs * (28 + 24 + 48 + 4), "camera-major statics (28 B), point (24 B), T.u (48 B) per row in; the rows are linearised again.  "
+            "(round 4: the class times k_sums + k_camftf and k_modelsum as two scopes per iteration - k_sums also carries the residue of the pair lists and the "
+            "zero fill of the reduced system, which used to be the class ba_schur_pairs on a second stream)")
     dom = kernels[0]
     step_bw = alg_bytes / (ba_s / args.steps) / 1e9
     whole = dict(bound="hbm", achieved=step_bw, peak=HBM_PEAK_GBS, unit="GB/s", frac=step_bw / HBM_PEAK_GBS, traffic=None,
@@ -600,7 +602,7 @@ def main():
         ctx.profile(False)
         kms = sum(v["total_ms"] for k, v in vst.items() if k.startswith("geo_fransac"))
         out["geo_verification"] = dict(metric="pairs verified/sec", value=n_vp / v_s, unit="pairs/s", pairs=n_vp, matches_per_pair=n_vm,
-                                       outlier_fraction=0.3, samples_per_pair="up to 2000 (128 scored first, the rest only for pairs whose adaptive budget is still open)", accepted=int(vok.sum()), mean_inliers=float(vnin.mean()),
+                                       outlier_fraction=0.3, samples_per_pair="up to 2000 (128 scored first, the rest only for pairs whose adaptive budget is still open); scoring with lane = match, model uniform over the wave (round 4)", accepted=int(vok.sum()), mean_inliers=float(vnin.mean()),
                                        kernel_ms=kms, kernel_pairs_per_sec=(n_vp / (kms * 1e-3)) if kms else None, dtype="f64",
                                        note="host arrays in, host arrays out (PCIe inclusive); FM_RANSAC restatement, 7-point solver")
         if world == 1 and not args.no_cpu_baseline:

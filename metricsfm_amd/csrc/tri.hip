@@ -1,4 +1,10 @@
-// Batched triangulation / reprojection / epipolar filter: one thread per track (FP64).
+// Batched triangulation / reprojection / epipolar filter (FP64).
+// Round 4: the midpoint triangulation and the reprojection run in two kinds of phases inside one workgroup of 64 tracks - what
+// belongs to ONE observation (its ray, its reprojection error, its ray for the angle gate: all the loads, divisions and square
+// roots) is computed with lane = observation from coalesced reads and parked in LDS; what the reference SUMS over a track's
+// observations in their order is then done by one thread per track from LDS.  Every number is formed by the same operations
+// in the same order as in the thread-per-track form (which remains: DLT, and workgroups whose observations do not fit the
+// LDS area), so results are unchanged; the kernel no longer waits for a chain of dependent loads per observation.
 // Reference: Point3D::Trianglate2 SfM/src/structure.cc:211-265, Point3D::Trianglate (DLT)
 // :163-209, Point3D::Reprojection :267-300, Point3D::SufficientTriangulationAngle :325-355,
 // GeoVerification::GeoVerificationFundamental (closed form) SfM/src/utils/geo_verification.cc:60-79.
@@ -47,10 +53,8 @@ __device__ bool track_angle_ok(const TrackPtrs& T, int b, int e, const double* X
   return false;
 }
 
-__global__ __launch_bounds__(256) void k_tri_midpoint(TrackPtrs T, double th_error, double cos_min, double* __restrict__ Xo,
-                                                       double* __restrict__ mse, uint8_t* __restrict__ ok) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= T.n_tracks) return;
+__device__ __forceinline__ void tri_midpoint_track(const TrackPtrs& T, int t, double th_error, double cos_min, double* __restrict__ Xo,
+                                                   double* __restrict__ mse, uint8_t* __restrict__ ok) {
   const int b = T.off[t], e = T.off[t + 1];
   double A[16], bv[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -121,6 +125,227 @@ __global__ __launch_bounds__(256) void k_tri_midpoint(TrackPtrs T, double th_err
   const double m = track_mse(T, b, e, X);
   mse[t] = m;
   ok[t] = !(sqrt(m) > th_error || !track_angle_ok(T, b, e, X, cos_min));
+}
+__global__ __launch_bounds__(256) void k_tri_midpoint(TrackPtrs T, double th_error, double cos_min, double* __restrict__ Xo,
+                                                       double* __restrict__ mse, uint8_t* __restrict__ ok) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T.n_tracks) return;
+  tri_midpoint_track(T, t, th_error, cos_min, Xo, mse, ok);
+}
+
+// ---- the staged form: 64 tracks per workgroup, observations through LDS ----
+#define TRI_TPB 64      // tracks per workgroup
+#define TRI_CAP 768     // observations per workgroup that fit the LDS area (else: thread per track)
+#define TRI_REC 7       // doubles per observation: ray (3), centre (3), squared reprojection error
+__global__ __launch_bounds__(256) void k_tri_midpoint_staged(TrackPtrs T, double th_error, double cos_min, double* __restrict__ Xo,
+                                                              double* __restrict__ mse, uint8_t* __restrict__ ok) {
+  __shared__ double sd[TRI_CAP * TRI_REC];
+  __shared__ double Xs[TRI_TPB * 3];
+  __shared__ int offs[TRI_TPB + 1];
+  __shared__ short tk[TRI_CAP];
+  __shared__ unsigned char alive[TRI_TPB];
+  const int tid = threadIdx.x, t0 = blockIdx.x * TRI_TPB;
+  const int nt = min(TRI_TPB, T.n_tracks - t0);
+  if (tid <= nt) offs[tid] = T.off[t0 + tid];
+  __syncthreads();
+  const int ob = offs[0], nobs = offs[nt] - ob;
+  if (nobs > TRI_CAP) {   // (uniform) long tracks: the thread-per-track form for this workgroup
+    if (tid < nt) tri_midpoint_track(T, t0 + tid, th_error, cos_min, Xo, mse, ok);
+    return;
+  }
+  // -- per observation: the unit ray through the image point in world coordinates, the camera centre (structure.cc:224-236)
+  for (int j = tid; j < nobs; j += 256) {
+    const int i = ob + j;
+    const int c = T.cam[i];
+    const double* R = T.R + 9 * (size_t)c;
+    const double* o = T.c + 3 * (size_t)c;
+    const double f = T.fk[3 * (size_t)c];
+    const double d0 = T.xy[2 * (size_t)i], d1 = T.xy[2 * (size_t)i + 1];
+    double dw[3] = {R[0] * d0 + R[3] * d1 + R[6] * f, R[1] * d0 + R[4] * d1 + R[7] * f, R[2] * d0 + R[5] * d1 + R[8] * f};
+    const double n = sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
+    dw[0] /= n; dw[1] /= n; dw[2] /= n;
+    double* rec = sd + (size_t)j * TRI_REC;
+    rec[0] = dw[0]; rec[1] = dw[1]; rec[2] = dw[2]; rec[3] = o[0]; rec[4] = o[1]; rec[5] = o[2];
+  }
+  __syncthreads();
+  // -- per track: the sums over its observations in their order, the 4 x 4 LLT (structure.cc:237-258)
+  if (tid < nt) {
+    const int t = t0 + tid, b = offs[tid] - ob, e = offs[tid + 1] - ob;
+    double A[16], bv[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++) A[k] = 0.0;
+    for (int j = b; j < e; j++) {
+      const double* rec = sd + (size_t)j * TRI_REC;
+      tk[j] = (short)tid;
+      const double dh[4] = {rec[0], rec[1], rec[2], 0.0};
+      const double oh[4] = {rec[3], rec[4], rec[5], 1.0};
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const double at = (r == q ? 1.0 : 0.0) - dh[r] * dh[q];
+          A[r * 4 + q] += at;
+          acc += at * oh[q];
+        }
+        bv[r] += acc;
+      }
+    }
+    ok[t] = 0;
+    mse[t] = 0.0;
+    double L[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) L[k] = 0.0;
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double d = A[j * 4 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) d -= L[j * 4 + k] * L[j * 4 + k];
+      if (!(d > 0.0)) pd = false;
+      L[j * 4 + j] = sqrt(d);
+#pragma unroll
+      for (int i = j + 1; i < 4; i++) {
+        double sacc = A[i * 4 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) sacc -= L[i * 4 + k] * L[j * 4 + k];
+        L[i * 4 + j] = sacc / L[j * 4 + j];
+      }
+    }
+    alive[tid] = pd ? 1 : 0;
+    if (pd) {
+      double y[4], x[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        double sacc = bv[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) sacc -= L[i * 4 + k] * y[k];
+        y[i] = sacc / L[i * 4 + i];
+      }
+#pragma unroll
+      for (int i = 3; i >= 0; i--) {
+        double sacc = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 4; k++) sacc -= L[k * 4 + i] * x[k];
+        x[i] = sacc / L[i * 4 + i];
+      }
+      const double X0 = x[0] / x[3], X1 = x[1] / x[3], X2 = x[2] / x[3];
+      Xo[3 * (size_t)t] = X0; Xo[3 * (size_t)t + 1] = X1; Xo[3 * (size_t)t + 2] = X2;
+      Xs[3 * tid] = X0; Xs[3 * tid + 1] = X1; Xs[3 * tid + 2] = X2;
+    }
+  }
+  __syncthreads();
+  // -- per observation: squared reprojection error (structure.cc:267-300; negative depth is flagged) and the unit ray from the
+  //    camera centre to the point (:325-355)
+  for (int j = tid; j < nobs; j += 256) {
+    const int trk = tk[j];
+    if (!alive[trk]) continue;
+    const int i = ob + j;
+    const int c = T.cam[i];
+    const double X[3] = {Xs[3 * trk], Xs[3 * trk + 1], Xs[3 * trk + 2]};
+    const double* R = T.R + 9 * (size_t)c;
+    const double* tt = T.t + 3 * (size_t)c;
+    const double* fk = T.fk + 3 * (size_t)c;
+    double* rec = sd + (size_t)j * TRI_REC;
+    const double pc0 = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + tt[0];
+    const double pc1 = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + tt[1];
+    const double pc2 = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + tt[2];
+    double err = -1.0;   // pc2 < 0: the track's error is the constant 100000 (structure.cc:283)
+    if (!(pc2 < 0)) {
+      const double x = pc0 / pc2, y = pc1 / pc2;
+      const double r2 = x * x + y * y;
+      const double distortion = 1.0 + r2 * (fk[1] + fk[2] * r2);
+      const double u = fk[0] * distortion * x, v = fk[0] * distortion * y;
+      const double du = u - T.xy[2 * (size_t)i], dv = v - T.xy[2 * (size_t)i + 1];
+      err = du * du + dv * dv;
+    }
+    double a[3] = {X[0] - rec[3], X[1] - rec[4], X[2] - rec[5]};
+    const double na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    a[0] /= na; a[1] /= na; a[2] /= na;
+    rec[0] = a[0]; rec[1] = a[1]; rec[2] = a[2]; rec[6] = err;
+  }
+  __syncthreads();
+  // -- per track: the error sum in observation order, the angle gate over the pairs of rays
+  if (tid < nt && alive[tid]) {
+    const int t = t0 + tid, b = offs[tid] - ob, e = offs[tid + 1] - ob;
+    double m = 0.0;
+    int count = 0;
+    bool behind = false;
+    for (int j = b; j < e; j++) {
+      const double er = sd[(size_t)j * TRI_REC + 6];
+      if (er < 0.0) { behind = true; break; }
+      m += er;
+      count++;
+    }
+    m = behind ? 100000.0 : m / count;
+    mse[t] = m;
+    bool wide = false;
+    for (int i = b; i + 1 < e && !wide; i++) {
+      const double* ai = sd + (size_t)i * TRI_REC;
+      for (int j = i + 1; j < e; j++) {
+        const double* dj = sd + (size_t)j * TRI_REC;
+        if (ai[0] * dj[0] + ai[1] * dj[1] + ai[2] * dj[2] < cos_min) { wide = true; break; }
+      }
+    }
+    ok[t] = !(sqrt(m) > th_error || !wide);
+  }
+}
+
+// Reprojection only (RemovePointOutliers, sfm_incremental.cc:1831-1863): the errors with lane = observation, the sums per track.
+__global__ __launch_bounds__(256) void k_reproject_staged(TrackPtrs T, const double* __restrict__ X, double* __restrict__ mse) {
+  __shared__ double er_s[TRI_CAP];
+  __shared__ int offs[TRI_TPB + 1];
+  const int tid = threadIdx.x, t0 = blockIdx.x * TRI_TPB;
+  const int nt = min(TRI_TPB, T.n_tracks - t0);
+  if (tid <= nt) offs[tid] = T.off[t0 + tid];
+  __syncthreads();
+  const int ob = offs[0], nobs = offs[nt] - ob;
+  if (nobs > TRI_CAP) {
+    if (tid < nt) {
+      const int t = t0 + tid;
+      const double Xt[3] = {X[3 * (size_t)t], X[3 * (size_t)t + 1], X[3 * (size_t)t + 2]};
+      mse[t] = track_mse(T, T.off[t], T.off[t + 1], Xt);
+    }
+    return;
+  }
+  for (int j = tid; j < nobs; j += 256) {
+    const int i = ob + j;
+    int lo = 0, hi = nt - 1;   // the track of observation i: the last one whose first observation is <= i
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (offs[mid] <= i) lo = mid; else hi = mid - 1; }
+    const size_t t = (size_t)(t0 + lo);
+    const double Xt[3] = {X[3 * t], X[3 * t + 1], X[3 * t + 2]};
+    const int c = T.cam[i];
+    const double* R = T.R + 9 * (size_t)c;
+    const double* tt = T.t + 3 * (size_t)c;
+    const double* fk = T.fk + 3 * (size_t)c;
+    const double pc0 = R[0] * Xt[0] + R[1] * Xt[1] + R[2] * Xt[2] + tt[0];
+    const double pc1 = R[3] * Xt[0] + R[4] * Xt[1] + R[5] * Xt[2] + tt[1];
+    const double pc2 = R[6] * Xt[0] + R[7] * Xt[1] + R[8] * Xt[2] + tt[2];
+    double err = -1.0;
+    if (!(pc2 < 0)) {
+      const double x = pc0 / pc2, y = pc1 / pc2;
+      const double r2 = x * x + y * y;
+      const double distortion = 1.0 + r2 * (fk[1] + fk[2] * r2);
+      const double u = fk[0] * distortion * x, v = fk[0] * distortion * y;
+      const double du = u - T.xy[2 * (size_t)i], dv = v - T.xy[2 * (size_t)i + 1];
+      err = du * du + dv * dv;
+    }
+    er_s[j] = err;
+  }
+  __syncthreads();
+  if (tid < nt) {
+    const int b = offs[tid] - ob, e = offs[tid + 1] - ob;
+    double m = 0.0;
+    int count = 0;
+    bool behind = false;
+    for (int j = b; j < e; j++) {
+      const double er = er_s[j];
+      if (er < 0.0) { behind = true; break; }
+      m += er;
+      count++;
+    }
+    mse[t0 + tid] = behind ? 100000.0 : m / count;
+  }
 }
 
 // DLT: streaming Givens QR of the 2k x 4 design matrix, one-sided Jacobi SVD of the 4x4 factor.
@@ -232,6 +457,10 @@ __global__ __launch_bounds__(256) void k_epipolar(const float* __restrict__ pt1,
 }
 
 // ---- host ----
+static bool tri_staged() {   // MSFM_TRI_STAGED=0: the thread-per-track kernels (comparison)
+  static const bool on = [] { const char* e = getenv("MSFM_TRI_STAGED"); return !(e && atoi(e) == 0); }();
+  return on;
+}
 struct TrackDev {
   DevBuf<int> off, cam;
   DevBuf<double> xy, R, t, c, fk;
@@ -274,6 +503,7 @@ static int triangulate(msfm_ctx* ctx, const msfm_tracks* T, double th_error, dou
   {
     KTimer t(ctx, dlt ? "tri_dlt" : "tri_midpoint");
     if (dlt) hipLaunchKernelGGL(k_tri_dlt, dim3(cdiv(n, 256)), dim3(256), 0, s, D.ptrs, th_error, cos(th_angle), dX.p, dm.p, dok.p);
+    else if (tri_staged()) hipLaunchKernelGGL(k_tri_midpoint_staged, dim3(cdiv(n, TRI_TPB)), dim3(256), 0, s, D.ptrs, th_error, cos(th_angle), dX.p, dm.p, dok.p);
     else hipLaunchKernelGGL(k_tri_midpoint, dim3(cdiv(n, 256)), dim3(256), 0, s, D.ptrs, th_error, cos(th_angle), dX.p, dm.p, dok.p);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -289,7 +519,8 @@ static int triangulate(msfm_ctx* ctx, const msfm_tracks* T, double th_error, dou
 int tri_midpoint_dev(msfm_ctx* ctx, const TrackPtrs& T, double th_error, double th_angle, double* dX, double* dmse, uint8_t* dok) {
   if (T.n_tracks == 0) return MSFM_OK;
   KTimer t(ctx, "tri_midpoint");
-  hipLaunchKernelGGL(k_tri_midpoint, dim3(cdiv(T.n_tracks, 256)), dim3(256), 0, ctx->stream, T, th_error, cos(th_angle), dX, dmse, dok);
+  if (tri_staged()) hipLaunchKernelGGL(k_tri_midpoint_staged, dim3(cdiv(T.n_tracks, TRI_TPB)), dim3(256), 0, ctx->stream, T, th_error, cos(th_angle), dX, dmse, dok);
+  else hipLaunchKernelGGL(k_tri_midpoint, dim3(cdiv(T.n_tracks, 256)), dim3(256), 0, ctx->stream, T, th_error, cos(th_angle), dX, dmse, dok);
   HIP_TRY(ctx, hipGetLastError());
   return MSFM_OK;
 }
@@ -318,7 +549,8 @@ MSFM_API int msfm_reproject_mse_batch(msfm_ctx* ctx, const msfm_tracks* T, const
   HIP_TRY(ctx, dX.upload(X, 3 * (size_t)n, s));
   {
     KTimer t(ctx, "tri_reproject");
-    hipLaunchKernelGGL(k_reproject, dim3(cdiv(n, 256)), dim3(256), 0, s, D.ptrs, dX.p, dm.p);
+    if (tri_staged()) hipLaunchKernelGGL(k_reproject_staged, dim3(cdiv(n, TRI_TPB)), dim3(256), 0, s, D.ptrs, dX.p, dm.p);
+    else hipLaunchKernelGGL(k_reproject, dim3(cdiv(n, 256)), dim3(256), 0, s, D.ptrs, dX.p, dm.p);
   }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(mse, dm.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));

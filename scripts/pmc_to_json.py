@@ -19,7 +19,8 @@ CLASSES = {  # bench.py kernel class -> substrings of the kernel names it launch
     "ba_schur_pairs": ["k_pairs<"],          # (not devsetup::k_pairs_of_points, the list builders of msfm_ba_create)
     "ba_point": ["k_point("],                # (not devsetup::k_point_keys / k_point_lengths)
     "ba_backsub": ["k_backsub"],
-    "ba_ftf": ["k_ftf"],
+    "ba_ftf": ["k_ftf"],                     # (round 4: launched by itself only without the fold tables)
+    "ba_sums": ["k_sums"],                   # per-camera sums + pair-list residue + zero fill of the reduced system in one launch
 }
 
 

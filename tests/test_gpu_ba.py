@@ -308,13 +308,16 @@ def test_ba_folded_schur_products_match_the_oracle_and_the_gather_path(oracle):
             "run(sc, cam_mutable=cm, pt_mutable=pm, gps_xyz=sc.gps_xyz, gps_weight=50.0)\n"
             "print(repr(out))\n") % ROOT
     outs = {}
-    for name, env in (("fold", dict(MSFM_FOLD_MIN="0")), ("gather", dict(MSFM_NO_FOLD="1"))):
+    for name, env in (("fold", dict(MSFM_FOLD_MIN="0")), ("gather", dict(MSFM_NO_FOLD="1")), ("fold_separate_launches", dict(MSFM_FOLD_MIN="0", MSFM_FUSED_SUMS="0"))):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[name] = eval(r.stdout.strip().splitlines()[-1])
     for a, b in zip(outs["fold"], outs["gather"]):
         np.testing.assert_allclose(a, b, rtol=1e-8)   # (the two paths sum in different orders: equal only to rounding; both
                                                       #  already matched the oracle to 1e-9 above, rejected trial steps included)
+    # round 4: per-camera sums, pair-list residue and zero fill as ONE launch (k_sums) against the separate launches on two streams:
+    # the same arithmetic per chunk, so every cost of every trajectory is the same number
+    assert outs["fold"] == outs["fold_separate_launches"]
 
 
 def test_ba_domains_with_window_masks(ctx, oracle, monkeypatch):
