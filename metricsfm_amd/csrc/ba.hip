@@ -155,10 +155,8 @@ __device__ __forceinline__ double obs_linearize(const BaPtrs& P, int i, double& 
 // eliminated points are linearised inside k_point.
 // --------------------------------------------------------------------------------------
 template <bool WRITE_JAC>
-__global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __restrict__ cost_partial, const double* __restrict__ spec = nullptr) {
-  __shared__ double sh[4];
-  if (spec && spec[0] == 0.0) return;   // (see PointPtrs::spec)
-  const int i = i0 + blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void linearize_block(const BaPtrs& P, int i0, int blk, double* __restrict__ cost_partial, double* sh) {
+  const int i = i0 + blk * 256 + threadIdx.x;
   double cost = 0.0;
   if (i < P.A) {
     if (WRITE_JAC) {
@@ -189,7 +187,13 @@ __global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __r
     }
   }
   const double t = block_sum256(cost, sh);
-  if (threadIdx.x == 0) cost_partial[blockIdx.x] = t;
+  if (threadIdx.x == 0) cost_partial[blk] = t;
+}
+template <bool WRITE_JAC>
+__global__ __launch_bounds__(256) void k_linearize(BaPtrs P, int i0, double* __restrict__ cost_partial, const double* __restrict__ spec = nullptr) {
+  __shared__ double sh[4];
+  if (spec && spec[0] == 0.0) return;   // (see PointPtrs::spec)
+  linearize_block<WRITE_JAC>(P, i0, blockIdx.x, cost_partial, sh);
 }
 
 // rot[c] = msfm_rot_prepare(cam[c]) for all cameras (run start; the candidates' are formed inside k_backsub)
@@ -201,13 +205,11 @@ __global__ __launch_bounds__(256) void k_rot_cache(int Nc, const double* __restr
 // GPS residual per camera block (gps_error_pose_absolute.h:31-44; d|x|/dx = x<0 ? -1 : 1).
 // Writes corrected, column-scaled r and J (diagonal) and the cost into cost_partial[slot].
 template <bool WRITE_JAC>
-__global__ __launch_bounds__(256) void k_gps(int ncb, const int* __restrict__ cb_cam, const double* __restrict__ cam,
-                                              const double* __restrict__ gps, double w, double huber,
-                                              const double* __restrict__ scale_c, double* __restrict__ g_r,
-                                              double* __restrict__ g_J, double* __restrict__ cost_partial, const double* __restrict__ spec = nullptr) {
-  __shared__ double sh[4];
-  if (spec && spec[0] == 0.0) return;   // (see PointPtrs::spec)
-  const int cb = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void gps_block(int blk, int ncb, const int* __restrict__ cb_cam, const double* __restrict__ cam,
+                                          const double* __restrict__ gps, double w, double huber,
+                                          const double* __restrict__ scale_c, double* __restrict__ g_r,
+                                          double* __restrict__ g_J, double* __restrict__ cost_partial, double* sh) {
+  const int cb = blk * 256 + threadIdx.x;
   double cost = 0.0;
   if (cb < ncb) {
     const int c = cb_cam[cb];
@@ -233,7 +235,16 @@ __global__ __launch_bounds__(256) void k_gps(int ncb, const int* __restrict__ cb
     }
   }
   const double t = block_sum256(cost, sh);
-  if (threadIdx.x == 0) cost_partial[blockIdx.x] = t;
+  if (threadIdx.x == 0) cost_partial[blk] = t;
+}
+template <bool WRITE_JAC>
+__global__ __launch_bounds__(256) void k_gps(int ncb, const int* __restrict__ cb_cam, const double* __restrict__ cam,
+                                              const double* __restrict__ gps, double w, double huber,
+                                              const double* __restrict__ scale_c, double* __restrict__ g_r,
+                                              double* __restrict__ g_J, double* __restrict__ cost_partial, const double* __restrict__ spec = nullptr) {
+  __shared__ double sh[4];
+  if (spec && spec[0] == 0.0) return;   // (see PointPtrs::spec)
+  gps_block<WRITE_JAC>(blockIdx.x, ncb, cb_cam, cam, gps, w, huber, scale_c, g_r, g_J, cost_partial, sh);
 }
 
 // Sum (or max) `n` partials in a fixed order into scal[slot]: one workgroup of 1024 threads, each
@@ -1072,11 +1083,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int b = blockIdx.x;
   if (b < a.n_zero) { zero_tile_body(b, a.M, a.ld, a.Z); return; }
   b -= a.n_zero;
-  if (b < a.n_mc_wg) { pairs_body<3, 6, false, true>(b, a.n_mc_wg, a.mc_n, a.mc_start, a.mc_end, a.mc_pa, a.mc_pb, a.Tm, a.T, nullptr, a.plane, a.mc_partial, a.mc_live); return; }
+  if (b < a.n_mc_wg) {   // (a list without live chunks is a full one: small problems, several intrinsics blocks)
+    if (a.mc_live) pairs_body<3, 6, false, true>(b, a.n_mc_wg, a.mc_n, a.mc_start, a.mc_end, a.mc_pa, a.mc_pb, a.Tm, a.T, nullptr, a.plane, a.mc_partial, a.mc_live);
+    else pairs_body<3, 6, false, false>(b, a.n_mc_wg, a.mc_n, a.mc_start, a.mc_end, a.mc_pa, a.mc_pb, a.Tm, a.T, nullptr, a.plane, a.mc_partial, nullptr);
+    return;
+  }
   b -= a.n_mc_wg;
   if (b < a.n_mm_wg) { pairs_body<3, 3, true, false>(b, a.n_mm_wg, a.mm_n, a.mm_start, a.mm_end, a.mm_pa, a.mm_pb, a.Tm, a.Tm, a.Tmu, (size_t)0, a.mm_partial, nullptr); return; }
   b -= a.n_mm_wg;
-  if (b < a.n_cc_wg) { pairs_body<6, 6, false, true>(b, a.n_cc_wg, a.cc_n, a.cc_start, a.cc_end, a.cc_pa, a.cc_pb, a.T, a.T, nullptr, a.plane, a.cc_partial, a.cc_live); return; }
+  if (b < a.n_cc_wg) {
+    if (a.cc_live) pairs_body<6, 6, false, true>(b, a.n_cc_wg, a.cc_n, a.cc_start, a.cc_end, a.cc_pa, a.cc_pb, a.T, a.T, nullptr, a.plane, a.cc_partial, a.cc_live);
+    else pairs_body<6, 6, false, false>(b, a.n_cc_wg, a.cc_n, a.cc_start, a.cc_end, a.cc_pa, a.cc_pb, a.T, a.T, nullptr, a.plane, a.cc_partial, nullptr);
+    return;
+  }
   b -= a.n_cc_wg;
   ftf_body(b, a.f_n, a.f_start, a.f_end, a.P, a.R, a.Tu, a.cpos_pb, a.f_partial);
 }
@@ -1414,13 +1433,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // model cost change of rows without an eliminated point (obs [AE, A)) and of the GPS rows.
-__global__ __launch_bounds__(256) void k_mcc_rest(int A, int AE, int ncb, const int* __restrict__ o_cb, const int* __restrict__ o_mb,
-                                                   const double* __restrict__ lin_r, const double* __restrict__ lin_Jc,
-                                                   const double* __restrict__ lin_Jm, const double* __restrict__ z, int has_gps,
-                                                   const double* __restrict__ g_r, const double* __restrict__ g_J,
-                                                   double* __restrict__ mcc_partial) {
-  __shared__ double sh[4];
-  const int t = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void mcc_rest_block(int blk, int A, int AE, int ncb, const int* __restrict__ o_cb, const int* __restrict__ o_mb,
+                                               const double* __restrict__ lin_r, const double* __restrict__ lin_Jc,
+                                               const double* __restrict__ lin_Jm, const double* __restrict__ z, int has_gps,
+                                               const double* __restrict__ g_r, const double* __restrict__ g_J,
+                                               double* __restrict__ mcc_partial, double* sh) {
+  const int t = blk * 256 + threadIdx.x;
   const int nrest = A - AE;
   double mcc = 0.0;
   if (t < nrest) {
@@ -1441,7 +1459,37 @@ __global__ __launch_bounds__(256) void k_mcc_rest(int A, int AE, int ncb, const 
     }
   }
   const double s = block_sum256(mcc, sh);
-  if (threadIdx.x == 0) mcc_partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) mcc_partial[blk] = s;
+}
+__global__ __launch_bounds__(256) void k_mcc_rest(int A, int AE, int ncb, const int* __restrict__ o_cb, const int* __restrict__ o_mb,
+                                                   const double* __restrict__ lin_r, const double* __restrict__ lin_Jc,
+                                                   const double* __restrict__ lin_Jm, const double* __restrict__ z, int has_gps,
+                                                   const double* __restrict__ g_r, const double* __restrict__ g_J,
+                                                   double* __restrict__ mcc_partial) {
+  __shared__ double sh[4];
+  mcc_rest_block(blockIdx.x, A, AE, ncb, o_cb, o_mb, lin_r, lin_Jc, lin_Jm, z, has_gps, g_r, g_J, mcc_partial, sh);
+}
+
+// What follows the back substitution in ONE launch: the model cost change of the rows without an eliminated point and of the GPS
+// rows (k_mcc_rest), the cost at the candidate (k_linearize<false> over all rows) and of its GPS rows (k_gps<false>) - three
+// launches of ~5 us each for the window of a new camera, whose sums then share one k_reduce.  The same workgroups with the same
+// partial slots as the separate launches (the cost partials in a buffer of their own: both sets are alive at once now).
+struct TailArgs {
+  int n_mcc, n_cost, n_gps;   // workgroups
+  // model cost change of the remaining rows
+  int A, AE, ncb; const int *o_cb, *o_mb; const double *lin_r, *lin_Jc, *lin_Jm, *z; int has_gps; const double *g_r, *g_J; double* mcc_partial;
+  // cost at the candidate
+  BaPtrs P; double* cost_partial;
+  const int* cb_cam; const double *cam_c, *gps; double gps_weight, huber; const double* scale_c; double *g_r_w, *g_J_w;
+};
+__global__ __launch_bounds__(256) void k_tail(TailArgs a) {
+  __shared__ double sh[4];
+  int b = blockIdx.x;
+  if (b < a.n_mcc) { mcc_rest_block(b, a.A, a.AE, a.ncb, a.o_cb, a.o_mb, a.lin_r, a.lin_Jc, a.lin_Jm, a.z, a.has_gps, a.g_r, a.g_J, a.mcc_partial, sh); return; }
+  b -= a.n_mcc;
+  if (b < a.n_cost) { linearize_block<false>(a.P, 0, b, a.cost_partial, sh); return; }
+  b -= a.n_cost;
+  gps_block<false>(b, a.ncb, a.cb_cam, a.cam_c, a.gps, a.gps_weight, a.huber, a.scale_c, a.g_r_w, a.g_J_w, a.cost_partial + a.n_cost, sh);
 }
 
 __global__ void k_zero_int(int* p) { *p = 0; }
@@ -1594,7 +1642,7 @@ struct msfm_ba {
   FoldTables fold;
   DevBuf<double> M, Linv, w, z;
   DevBuf<double> gps, g_r, g_J;
-  DevBuf<double> partial, partial2, partial3, gmax_buf, scal, sloc;
+  DevBuf<double> partial, partial2, partial3, partial4, gmax_buf, scal, sloc;
   double* swrite = nullptr;  // where the kernels put scalars: scal (one rank) or sloc (partials, summed by reduce_scalars)
   DevBuf<int> fail;
   double* h_scal = nullptr;  // pinned, mapped: [0, 16) scalars, [16] sequence number, [17] decision code, [18] radius (k_publish_scalars)
@@ -3582,7 +3630,7 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   ba->nblk_obs = cdiv(As, 256);
   ba->nblk_pt = cdiv(std::max(1, npb), 32);  // 8 lanes per point
   const size_t npart = (size_t)ba->nblk_obs + ba->nblk_pt + cdiv(std::max(1, ncb), 256) + 64;
-  AL(partial, npart); AL(partial2, npart); AL(partial3, npart);
+  AL(partial, npart); AL(partial2, npart); AL(partial3, npart); AL(partial4, npart);
   AL(gmax_buf, (size_t)ba->nblk_pt + 6 * (size_t)ncb + 3 * (size_t)nmb + 8);
   AL(scal, S_N); AL(sloc, S_N); AL(spec, 8);
   { const char* e = getenv("MSFM_SPEC"); ba->spec_on = !(e && atoi(e) == 0); }
@@ -3827,7 +3875,10 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
   // (round 4, later: with the fold tables and one intrinsics block everything between k_point and the assembly is ONE launch on
   //  the main stream - k_sums - and nothing is forked)
   static const char* fused_env = getenv("MSFM_FUSED_SUMS");
-  const bool fused = mode == 0 && ba->fold.on && ba->fold.mc_on && ba->n_fchunks > 0 && !(fused_env && atoi(fused_env) == 0);
+  // (also for the problems too small for the fold tables - the window of a new camera: their full pair lists are three
+  //  latency-bound launches of 13-25 us one after the other; a LARGE problem without fold tables keeps the separate launches,
+  //  whose pair kernels want more waves per SIMD than this launch has)
+  const bool fused = mode == 0 && ba->n_fchunks > 0 && (ba->fold.on || ba->cc.n_pairs < 262144) && !(fused_env && atoi(fused_env) == 0);
   const bool forked = mode == 0 && !ctx->profile && overlap && !fused;
   // zero fill of the reduced system in front of the assembly (reads nothing: with the fork it runs on the second stream too)
   auto zero_system = [&](hipStream_t sz) -> int {
@@ -3889,11 +3940,12 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
       a.n_zero = zero_map(a.Z);
       if (a.n_zero == 0) MSFM_TRY(zero_system(s));
       a.M = ba->M.p; a.ld = ba->npad;
-      a.mc_n = ba->fold.mc_n_live; a.mc_start = ba->mc.ch_start.p; a.mc_end = ba->mc.ch_end.p; a.mc_pa = ba->mc.pa.p; a.mc_pb = ba->mc.pb.p;
-      a.mc_live = ba->fold.mc_live_chunk.p; a.mc_partial = ba->mc.partial.p;
+      const bool mc_sparse = ba->fold.on && ba->fold.mc_on;
+      a.mc_n = mc_sparse ? ba->fold.mc_n_live : ba->mc.n_chunks; a.mc_start = ba->mc.ch_start.p; a.mc_end = ba->mc.ch_end.p; a.mc_pa = ba->mc.pa.p; a.mc_pb = ba->mc.pb.p;
+      a.mc_live = mc_sparse ? ba->fold.mc_live_chunk.p : nullptr; a.mc_partial = ba->mc.partial.p;
       a.mm_n = ba->mm.n_chunks; a.mm_start = ba->mm.ch_start.p; a.mm_end = ba->mm.ch_end.p; a.mm_pa = ba->mm.pa.p; a.mm_pb = ba->mm.pb.p; a.mm_partial = ba->mm.partial.p;
-      a.cc_n = ba->fold.n_live; a.cc_start = ba->cc.ch_start.p; a.cc_end = ba->cc.ch_end.p; a.cc_pa = ba->cc.pa.p; a.cc_pb = ba->cc.pb.p;
-      a.cc_live = ba->fold.live_chunk.p; a.cc_partial = ba->cc.partial.p;
+      a.cc_n = ba->fold.on ? ba->fold.n_live : ba->cc.n_chunks; a.cc_start = ba->cc.ch_start.p; a.cc_end = ba->cc.ch_end.p; a.cc_pa = ba->cc.pa.p; a.cc_pb = ba->cc.pb.p;
+      a.cc_live = ba->fold.on ? ba->fold.live_chunk.p : nullptr; a.cc_partial = ba->cc.partial.p;
       a.T = ba->T.p; a.Tm = ba->Tm.p; a.Tmu = ba->Tmu.p; a.plane = ncr;
       a.f_n = ba->n_fchunks; a.f_start = ba->f_start.p; a.f_end = ba->f_end.p; a.P = make_ptrs(ba, false, ba->lin_huber);
       a.R = CamRows{ba->cm_pt.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
@@ -4086,6 +4138,37 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
     }
     const int ngps = (ba->has_gps && lead) ? ncb : 0;
     const int nrest = (ba->A - ba->AE) + ngps;
+    const char* tail_env = getenv("MSFM_FUSED_TAIL");   // (read per call: the tests switch it inside one process)
+    if (!(tail_env && atoi(tail_env) == 0)) {
+      // model cost change of the remaining rows + cost at the candidate (all rows, GPS rows) in one launch, one reduction for
+      // the four sums (the failure bits of the factorisation / finiteness checks are final here)
+      TailArgs a;
+      a.n_mcc = nrest ? cdiv(nrest, 256) : 0;
+      a.A = ba->A; a.AE = ba->AE; a.ncb = ncb; a.o_cb = ba->o_cb.p; a.o_mb = ba->o_mb.p; a.lin_r = ba->lin_r.p; a.lin_Jc = ba->lin_Jc.p; a.lin_Jm = ba->lin_Jm.p;
+      a.z = ba->z.p; a.has_gps = ngps ? 1 : 0; a.g_r = ba->g_r.p; a.g_J = ba->g_J.p; a.mcc_partial = ba->partial.p + moff;
+      moff += a.n_mcc;
+      a.P = make_ptrs(ba, /*candidate=*/true, opt->huber_delta);
+      a.n_cost = ba->nblk_obs; a.cost_partial = ba->partial4.p;
+      a.n_gps = ba->has_gps ? cdiv(ncb, 256) : 0;
+      a.cb_cam = ba->cb_cam.p; a.cam_c = a.P.cam; a.gps = ba->gps.p; a.gps_weight = ba->gps_weight; a.huber = opt->huber_delta; a.scale_c = ba->scale_c.p;
+      a.g_r_w = ba->g_r.p; a.g_J_w = ba->g_J.p;   // (not written: WRITE_JAC is false)
+      {
+        KTimer t2(ctx, "ba_cost");
+        hipLaunchKernelGGL(k_tail, dim3(a.n_mcc + a.n_cost + a.n_gps), dim3(256), 0, s, a);
+      }
+      ReduceJobs rj;
+      rj.count = 4;
+      rj.job[0] = {ba->partial.p, moff, S_MCC, 0};
+      rj.job[1] = {ba->partial2.p, off, S_DX2, 0};
+      rj.job[2] = {ba->partial3.p, off, S_X2, 0};
+      rj.job[3] = {ba->partial4.p, a.n_cost + (lead ? a.n_gps : 0), S_COST, 0};
+      rj.fail = ba->fail.p;
+      rj.fail_slot = S_FAIL;
+      hipLaunchKernelGGL(k_reduce, dim3(4), dim3(1024), 0, s, rj, ba->swrite);
+      hipError_t e2 = hipGetLastError();
+      if (e2 != hipSuccess) return msfm_set_error(ctx, MSFM_E_DEVICE, "solve launch: %s", hipGetErrorString(e2));
+      return MSFM_OK;
+    }
     if (nrest) {
       hipLaunchKernelGGL(k_mcc_rest, dim3(cdiv(nrest, 256)), dim3(256), 0, s, ba->A, ba->AE, ncb, ba->o_cb.p, ba->o_mb.p, ba->lin_r.p,
                          ba->lin_Jc.p, ba->lin_Jm.p, ba->z.p, ngps ? 1 : 0, ba->g_r.p, ba->g_J.p, ba->partial.p + moff);

@@ -573,17 +573,22 @@ def test_ba_device_side_verdict_and_launch_ahead_are_bit_identical_to_the_host_o
     ]
     for mk, kw in cases:
         out = []
-        for spec in ("0", "1"):
+        # (third variant: the launches behind the back substitution - model cost change of the remaining rows, cost at the
+        #  candidate, its GPS rows - separately instead of as k_tail with one reduction for the four sums)
+        for spec, tail in (("0", "1"), ("1", "1"), ("1", "0")):
             monkeypatch.setenv("MSFM_SPEC", spec)
+            monkeypatch.setenv("MSFM_FUSED_TAIL", tail)
             a = mk()
             r = ctx.ba_solve(a, capi.default_options(**kw))
             out.append((r, a))
-        (r0, a0), (r1, a1) = out
-        assert r0["termination"] == r1["termination"] and r0["num_iterations"] == r1["num_iterations"]
-        for key in ("cost", "gradient_max_norm", "step_norm", "step_is_successful", "step_is_valid", "trust_region_radius", "relative_decrease"):
-            np.testing.assert_array_equal(r0["iterations"][key], r1["iterations"][key])
-        for name in ("cam_pose", "cam_model", "point"):
-            np.testing.assert_array_equal(getattr(a0, name), getattr(a1, name))
+        monkeypatch.delenv("MSFM_FUSED_TAIL")
+        (r0, a0) = out[0]
+        for (r1, a1) in out[1:]:
+            assert r0["termination"] == r1["termination"] and r0["num_iterations"] == r1["num_iterations"]
+            for key in ("cost", "gradient_max_norm", "step_norm", "step_is_successful", "step_is_valid", "trust_region_radius", "relative_decrease"):
+                np.testing.assert_array_equal(r0["iterations"][key], r1["iterations"][key])
+            for name in ("cam_pose", "cam_model", "point"):
+                np.testing.assert_array_equal(getattr(a0, name), getattr(a1, name))
     r_rej = ctx.ba_solve(cases[0][0](), capi.default_options(**cases[0][1]))
     ok_steps = r_rej["iterations"]["step_is_successful"][1:]
     assert (ok_steps == 0).sum() >= 3 and (ok_steps == 1).sum() >= 3, "the first case is meant to mix rejected and accepted steps"
