@@ -4142,6 +4142,7 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
     if (!(tail_env && atoi(tail_env) == 0)) {
       // model cost change of the remaining rows + cost at the candidate (all rows, GPS rows) in one launch, one reduction for
       // the four sums (the failure bits of the factorisation / finiteness checks are final here)
+      t.stop();   // (the class ba_backsub ends here: what follows is timed as ba_cost)
       TailArgs a;
       a.n_mcc = nrest ? cdiv(nrest, 256) : 0;
       a.A = ba->A; a.AE = ba->AE; a.ncb = ncb; a.o_cb = ba->o_cb.p; a.o_mb = ba->o_mb.p; a.lin_r = ba->lin_r.p; a.lin_Jc = ba->lin_Jc.p; a.lin_Jm = ba->lin_Jm.p;
@@ -4152,10 +4153,8 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
       a.n_gps = ba->has_gps ? cdiv(ncb, 256) : 0;
       a.cb_cam = ba->cb_cam.p; a.cam_c = a.P.cam; a.gps = ba->gps.p; a.gps_weight = ba->gps_weight; a.huber = opt->huber_delta; a.scale_c = ba->scale_c.p;
       a.g_r_w = ba->g_r.p; a.g_J_w = ba->g_J.p;   // (not written: WRITE_JAC is false)
-      {
-        KTimer t2(ctx, "ba_cost");
-        hipLaunchKernelGGL(k_tail, dim3(a.n_mcc + a.n_cost + a.n_gps), dim3(256), 0, s, a);
-      }
+      KTimer t2(ctx, "ba_cost");
+      hipLaunchKernelGGL(k_tail, dim3(a.n_mcc + a.n_cost + a.n_gps), dim3(256), 0, s, a);
       ReduceJobs rj;
       rj.count = 4;
       rj.job[0] = {ba->partial.p, moff, S_MCC, 0};

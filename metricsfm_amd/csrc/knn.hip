@@ -825,7 +825,23 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
   // rows outside the two lists: v >= the 4th key of their half
   const double b_mine = gi[3] < T.n_train ? (double)__uint_as_float(gv[3]) : inf;
   const double b_other = oi[3] < T.n_train ? (double)__uint_as_float(ov[3]) : inf;
+#ifdef MSFM_KNN_F16_FILTER
+  // with the compare filter a lane drops rows above the fourth key of the two lists TOGETHER, so that key bounds the unlisted rows
+  double b_union = inf;
+  {
+    double mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double x = gi[i] < T.n_train ? (double)__uint_as_float(gv[i]) : inf;
+      const double y = oi[3 - i] < T.n_train ? (double)__uint_as_float(ov[3 - i]) : inf;
+      mx[i] = fmax(x, y);
+    }
+    b_union = fmin(fmin(mx[0], mx[1]), fmin(mx[2], mx[3]));
+  }
+  const double bound = fmin(fmin(b_mine, b_other), b_union) - G - E;
+#else
   const double bound = fmin(b_mine, b_other) - G - E;
+#endif
   const size_t o = (size_t)T.out_off + q;
   if (!(bound > d1 * (double)T.s2 * (1.0 + 1e-12))) {   // cannot certify: exact brute force later, filed under the train image's group
     flagged[T.group_off + atomicAdd(&nf_group[T.group], 1)] = (int)o;
@@ -897,6 +913,9 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
   };
   u32 keymask;
   asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keymask));
+#ifdef MSFM_KNN_F16_FILTER
+  u32 aU = 0xffffffffu, bU = 0xffffffffu;
+#endif
   fetch(0);
   commit(0);
   __syncthreads();
@@ -924,13 +943,14 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
       }
       const int wbase = ((tile & 3) * 2 + st) * 32;
 #ifdef MSFM_KNN_F16_FILTER   // measured SLOWER here (670 against 694 Mmatches/s on 4 032 pairs: four keys per lane double the hit rate,
-                             // half of the slots still run their ten operations, and the masks cost 8 registers at two waves per SIMD)
+                             // half of the slots still run their ten operations, and the masks cost 8 registers at two waves per SIMD;
+                             // with the bound shared by the two lanes of a query as in k_knn2_i8 - aU / bU below - 680 against 715)
       // Round 4: one compare per candidate (see k_knn2_i8).  A value above the lane's fourth smallest - of the window (a3) and
       // of the list over all rows so far (gva[3]) - cannot enter either list: its key is not formed.  The accumulator bits are
       // compared raw against the threshold key with its index byte filled (conservative); the thresholds are taken once per
       // 32-row step.  The lists, hence the certification bound "every unlisted row is >= the list's fourth key", are what the
       // unconditional form gives.
-      const u32 ta = min(a3, gva[3]) | 255u, tb = min(b3, gvb[3]) | 255u;
+      const u32 ta = min(a3, aU) | 255u, tb = min(b3, bU) | 255u;   // (aU / bU: the fourth smallest key over the lists of BOTH lanes of the query, see the merge below)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         unsigned long long hm[4];
@@ -969,6 +989,28 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
       merge_window4(gvb, gib, b0, b1, b2, b3, base);
       a0 = a1 = a2 = a3 = 0xffffffffu;
       b0 = b1 = b2 = b3 = 0xffffffffu;
+#ifdef MSFM_KNN_F16_FILTER
+      // the fourth smallest key of the two sorted lists of a query together: min over i + j = 3 of max(x_i, y_j).  A row above it
+      // is neither among the query's two nearest nor needed by the certificate, whose bound for unlisted rows becomes this key
+      // (finish_query_f16) instead of the smaller of the two lists' fourth keys.
+      {
+        u32 m[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(gva[3 - i], gva[3 - i], false, false);
+          const u32 other = h ? (u32)sw[0] : (u32)sw[1];
+          m[i] = max(gva[i], other);
+        }
+        aU = min(min(m[0], m[1]), min(m[2], m[3]));
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(gvb[3 - i], gvb[3 - i], false, false);
+          const u32 other = h ? (u32)sw[0] : (u32)sw[1];
+          m[i] = max(gvb[i], other);
+        }
+        bU = min(min(m[0], m[1]), min(m[2], m[3]));
+      }
+#endif
     }
     if (tile + 1 < n_tiles) commit(cur ^ 1);
     __syncthreads();
