@@ -704,6 +704,15 @@ __global__ __launch_bounds__(256) void k_cam_rows(int A, const int* __restrict__
   if (cp < 0) return;
   cm_pt[cp] = o_pt[i]; cm_x[cp] = o_x[i]; cm_y[cp] = o_y[i]; cm_w[cp] = o_w[i]; cm_row[cp] = i;
 }
+// cm_X / cm_Xc at the start of a run: the coordinates of every camera-major row's point (the rows of frozen points keep them)
+__global__ __launch_bounds__(256) void k_cam_points(int ncr, const int* __restrict__ cm_pt, const double* __restrict__ pt, double* __restrict__ X0,
+                                                     double* __restrict__ X1) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= ncr) return;
+  const size_t p = (size_t)cm_pt[e];
+#pragma unroll
+  for (int j = 0; j < 3; j++) { const double v = pt[3 * p + j]; X0[3 * (size_t)e + j] = v; X1[3 * (size_t)e + j] = v; }
+}
 __global__ __launch_bounds__(256) void k_chunk_cam(int nchunk, const int* __restrict__ ch_start, const int* __restrict__ cm_row, const int* __restrict__ o_cam,
                                                     const int* __restrict__ o_model, const int* __restrict__ o_cb, const int* __restrict__ o_mb,
                                                     int4* __restrict__ chunk_cam) {
@@ -732,6 +741,9 @@ __device__ __forceinline__ void wave_reduce_store(double (&acc)[N], double* out,
 // as before: the per-camera sums are what the stored rows gave.
 struct CamRows {
   const int* pt;             // [NCR] point of the row at camera-major position e
+  const double* X;           // [NCR][3] the point's coordinates at the linearisation point, in camera-major order (cm_X: written by
+                             // k_backsub for the candidate, swapped with the parameters; the 24-byte gather through `pt` moved
+                             // 100 MB of cache lines for 29 MB of coordinates at config 3)
   const double *x, *y, *w;   // [NCR]
   const int4* chunk_cam;     // [chunks] camera, intrinsics, camera block, intrinsics block (-1: frozen) of the chunk's rows
 };
@@ -760,14 +772,12 @@ __device__ __forceinline__ void ftf_body(int blk, int nchunk, const int* __restr
   for (int j = 0; j < 3; j++) { cm[j] = P.model[3 * (size_t)m + j]; sm[j] = mb >= 0 ? P.scale_m[3 * mb + j] : 0.0; }
   const int e1 = ch_end[chunk];
   int e = ch_start[chunk] + lane;
-  // two rows ahead: the statics of row e + 128 and, with its point index known, the point of row e + 64
-  int pn = 0, pnn = 0;
-  double xn = 0, yn = 0, wn = 0, xnn = 0, ynn = 0, wnn = 0, Xn[3] = {0, 0, 0};
-  if (e < e1) { pn = R.pt[e]; xn = R.x[e]; yn = R.y[e]; wn = R.w[e]; }
-  if (e + 64 < e1) { pnn = R.pt[e + 64]; xnn = R.x[e + 64]; ynn = R.y[e + 64]; wnn = R.w[e + 64]; }
+  // one row ahead: statics and point (camera-major copies, all coalesced) of row e + 64
+  double xn = 0, yn = 0, wn = 0, Xn[3] = {0, 0, 0};
   if (e < e1) {
+    xn = R.x[e]; yn = R.y[e]; wn = R.w[e];
 #pragma unroll
-    for (int j = 0; j < 3; j++) Xn[j] = P.pt[3 * (size_t)pn + j];
+    for (int j = 0; j < 3; j++) Xn[j] = R.X[3 * (size_t)e + j];
   }
   for (; e < e1; e += 64) {
     const double X[3] = {Xn[0], Xn[1], Xn[2]};
@@ -779,13 +789,11 @@ __device__ __forceinline__ void ftf_body(int blk, int nchunk, const int* __restr
 #pragma unroll
       for (int a = 0; a < 3; a++) tu2[a] = tp[a];
     }
-    // shift the pipeline: row e + 64 becomes "next" (its point is fetched now), row e + 128's statics are asked for
-    pn = pnn; xn = xnn; yn = ynn; wn = wnn;
     if (e + 64 < e1) {
+      xn = R.x[e + 64]; yn = R.y[e + 64]; wn = R.w[e + 64];
 #pragma unroll
-      for (int j = 0; j < 3; j++) Xn[j] = P.pt[3 * (size_t)pn + j];
+      for (int j = 0; j < 3; j++) Xn[j] = R.X[3 * (size_t)(e + 64) + j];
     }
-    if (e + 128 < e1) { pnn = R.pt[e + 128]; xnn = R.x[e + 128]; ynn = R.y[e + 128]; wnn = R.w[e + 128]; }
     double r0, r1, jcr[12], jmr[6], jpr[6];
     linearize_core(pose, rc, cm, X, ox, oy, ow, sc, sm, sp, P.huber, r0, r1, jcr, jmr, jpr);
     const double* jc = jcr;
@@ -1355,6 +1363,7 @@ struct BackPtrs {
   const int *pt_first, *pb_pt;
   const double *ptL, *z;
   double* pt_c;
+  double* cm_Xc;   // the candidate's coordinates again, at the camera-major positions of the point's rows (CamRows::X)
   int Nc;                  // the first Nc threads of the launch also prepare the candidate cameras' rotations
   const double* cam_c;     // (final before this launch: k_update_params)
   double* rot_c;
@@ -1404,7 +1413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   GROUP_SUM(V00) GROUP_SUM(V10) GROUP_SUM(V11) GROUP_SUM(V20) GROUP_SUM(V21) GROUP_SUM(V22)
   GROUP_SUM(g0) GROUP_SUM(g1) GROUP_SUM(g2) GROUP_SUM(h0) GROUP_SUM(h1) GROUP_SUM(h2) GROUP_SUM(qr) GROUP_SUM(qq)
-  double mcc = 0.0, dx2 = 0.0, x2 = 0.0;
+  double mcc = 0.0, dx2 = 0.0, x2 = 0.0, cand0 = 0.0, cand1 = 0.0, cand2 = 0.0;
   if (act && sub == 0) {
     const double* L = P.ptL + 6 * (size_t)pb;
     const double l00 = L[0], l10 = L[1], l11 = L[2], l20 = L[3], l21 = L[4], l22 = L[5];
@@ -1421,10 +1430,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const double x0 = P.B.pt[3 * p], x1 = P.B.pt[3 * p + 1], x2v = P.B.pt[3 * p + 2];
     const double c0 = x0 + s0 * sc[0], c1 = x1 + s1 * sc[1], c2 = x2v + s2 * sc[2];
     P.pt_c[3 * p] = c0; P.pt_c[3 * p + 1] = c1; P.pt_c[3 * p + 2] = c2;
+    cand0 = c0; cand1 = c1; cand2 = c2;
     dx2 = (c0 - x0) * (c0 - x0) + (c1 - x1) * (c1 - x1) + (c2 - x2v) * (c2 - x2v);
     x2 = x0 * x0 + x1 * x1 + x2v * x2v;
     const double sVs = s0 * (V00 * s0 + 2.0 * (V10 * s1 + V20 * s2)) + s1 * (V11 * s1 + 2.0 * V21 * s2) + s2 * V22 * s2;
     mcc = -((s0 * g0 + s1 * g1 + s2 * g2) + qr + 0.5 * sVs + (s0 * h0 + s1 * h1 + s2 * h2) + 0.5 * qq);
+  }
+  // the candidate to every row of the point in camera-major order (what k_ftf reads if the step is accepted): lane = row again
+  // (measured: trading the records between the lanes first, as k_point does for its T stores, made this SLOWER - 104 against 98 us)
+  cand0 = __shfl(cand0, 0, 8); cand1 = __shfl(cand1, 0, 8); cand2 = __shfl(cand2, 0, 8);
+  for (int base = f; base < l; base += 8) {
+    const int i = base + sub;
+    if (i < l) {
+      const int cp = P.B.o_cpos[i];
+      if (cp >= 0) { double* xr = P.cm_Xc + 3 * (size_t)cp; xr[0] = cand0; xr[1] = cand1; xr[2] = cand2; }
+    }
   }
   const double t0 = block_sum256(mcc, sh);
   const double t1 = block_sum256(dx2, sh);
@@ -1628,6 +1648,7 @@ struct msfm_ba {
   DevBuf<double> lin_r, lin_Jc, lin_Jm, T, Tu, Tm, Tmu, rot, rot_c;
   DevBuf<int> cm_pt;            // camera-major statics of the rows (k_ftf linearises them again)
   DevBuf<double> cm_xyw;        // [3][NCR]
+  DevBuf<double> cm_X, cm_Xc;   // [NCR][3] point coordinates in camera-major order at x / at the candidate (CamRows::X)
   DevBuf<int4> chunk_cam;
   DevBuf<int> cpos_pb;
   DevBuf<double> scale_c, scale_m, scale_p, diag_c, diag_m, diag_p;
@@ -3619,7 +3640,7 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   const size_t Atail = (size_t)std::max(1, A - ba->AE);   // rows of frozen points: the only ones whose linearisation is stored
   AL(lin_r, 2 * Atail); AL(lin_Jc, 12 * Atail); AL(lin_Jm, 6 * Atail);
   AL(T, 18 * (size_t)NCR); AL(Tu, 6 * (size_t)NCR);
-  AL(cm_pt, (size_t)NCR); AL(cm_xyw, 3 * (size_t)NCR); AL(chunk_cam, (size_t)ba->n_fchunks);
+  AL(cm_pt, (size_t)NCR); AL(cm_xyw, 3 * (size_t)NCR); AL(cm_X, 3 * (size_t)NCR); AL(cm_Xc, 3 * (size_t)NCR); AL(chunk_cam, (size_t)ba->n_fchunks);
   AL(Tm, 9 * (size_t)NPM); AL(Tmu, 3 * (size_t)NPM);
   AL(scale_c, 6 * (size_t)ncb); AL(scale_m, 3 * (size_t)nmb); AL(scale_p, 3 * (size_t)npb);
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
@@ -3948,13 +3969,13 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
       a.cc_live = ba->fold.on ? ba->fold.live_chunk.p : nullptr; a.cc_partial = ba->cc.partial.p;
       a.T = ba->T.p; a.Tm = ba->Tm.p; a.Tmu = ba->Tmu.p; a.plane = ncr;
       a.f_n = ba->n_fchunks; a.f_start = ba->f_start.p; a.f_end = ba->f_end.p; a.P = make_ptrs(ba, false, ba->lin_huber);
-      a.R = CamRows{ba->cm_pt.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
+      a.R = CamRows{ba->cm_pt.p, ba->cm_X.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
       a.Tu = ba->Tu.p; a.cpos_pb = ba->cpos_pb.p; a.f_partial = ba->f_partial.p;
       a.n_mc_wg = cdiv(a.mc_n, 4); a.n_mm_wg = cdiv(a.mm_n, 4); a.n_cc_wg = cdiv(a.cc_n, 4); a.n_ftf_wg = cdiv(a.f_n, 4);
       hipLaunchKernelGGL(k_sums, dim3(a.n_zero + a.n_mc_wg + a.n_mm_wg + a.n_cc_wg + a.n_ftf_wg), dim3(256), 0, s, a);
     } else if (ba->n_fchunks) {
       const size_t ncr = (size_t)std::max(1, ba->NCR);
-      const CamRows R{ba->cm_pt.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
+      const CamRows R{ba->cm_pt.p, ba->cm_X.p, ba->cm_xyw.p, ba->cm_xyw.p + ncr, ba->cm_xyw.p + 2 * ncr, ba->chunk_cam.p};
       hipLaunchKernelGGL(k_ftf, dim3(cdiv(ba->n_fchunks, 4)), dim3(256), 0, s, ba->n_fchunks, ba->f_start.p, ba->f_end.p,
                          make_ptrs(ba, false, ba->lin_huber), R, ba->Tu.p, ba->cpos_pb.p, ba->f_partial.p);
     }
@@ -4129,7 +4150,7 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
       BackPtrs Q;
       Q.B = make_ptrs(ba, false, ba->lin_huber);
       Q.npb = npb; Q.ncb = ncb; Q.pt_first = ba->pt_first.p; Q.pb_pt = ba->pb_pt.p;
-      Q.ptL = ba->ptL.p; Q.z = ba->z.p; Q.pt_c = ba->pt_c.p;
+      Q.ptL = ba->ptL.p; Q.z = ba->z.p; Q.pt_c = ba->pt_c.p; Q.cm_Xc = ba->cm_Xc.p;
       Q.Nc = ba->Nc; Q.cam_c = ba->cam_c.p; Q.rot_c = ba->rot_c.p;
       hipLaunchKernelGGL(k_backsub, dim3(nbp), dim3(256), 0, s, Q, ba->partial.p, ba->partial2.p + off, ba->partial3.p + off);
       off += nbp; moff += nbp;
@@ -4230,6 +4251,8 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
     hipLaunchKernelGGL(k_copy3, dim3(cdiv((long)std::max(n0, std::max(n1, n2)), 256)), dim3(256), 0, s, n0, ba->cam.p, ba->cam_c.p, n1,
                        ba->model.p, ba->model_c.p, n2, ba->pt.p, ba->pt_c.p);
   }
+  if (ba->NCR > 0)
+    hipLaunchKernelGGL(k_cam_points, dim3(cdiv(ba->NCR, 256)), dim3(256), 0, s, ba->NCR, ba->cm_pt.p, ba->pt.p, ba->cm_X.p, ba->cm_Xc.p);
   lap("scales reset");
   hipLaunchKernelGGL(k_zero_int, dim3(1), dim3(1), 0, s, ba->fail.p);
   double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
@@ -4324,7 +4347,7 @@ MSFM_API int msfm_ba_run(msfm_ba* ba, const msfm_ba_options* opt, msfm_ba_summar
       if (code == LM_FUNC_TOL) { termination = MSFM_BA_CONVERGENCE_FUNCTION; break; }
       it.relative_decrease = (x_cost - cand_cost) / mcc;
       if (code == LM_ACCEPT) {
-        ba->cam.swap(ba->cam_c); ba->model.swap(ba->model_c); ba->pt.swap(ba->pt_c); ba->rot.swap(ba->rot_c);
+        ba->cam.swap(ba->cam_c); ba->model.swap(ba->model_c); ba->pt.swap(ba->pt_c); ba->rot.swap(ba->rot_c); ba->cm_X.swap(ba->cm_Xc);
         relinearise = true;
         it.step_is_successful = 1;
         radius = ba->h_scal[H_RADIUS];   // = min(max_radius, radius / max(1/3, 1 - (2 rho - 1)^3)), formed on the device
