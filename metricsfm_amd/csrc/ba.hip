@@ -310,6 +310,7 @@ struct PointPtrs {
   // A launch enqueued BEFORE the host has seen the step it follows (msfm_ba_run): spec[0] != 0 if the device-side decision
   // (k_publish_scalars) accepted that step - else the launch ends at once - and spec[1] = the new trust-region radius.
   const double* spec;
+  int keep_T;   // MSFM_KEEP_T=1: store every T record as rounds 1-3 did (comparison)
 };
 
 // (8-lane groups; after the first two steps the four lanes of a quad hold the same value, so adding lane 7 - i is adding lane i ^ 4)
@@ -433,6 +434,7 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
     // Round 3 (FoldTables): in a folding workgroup every record also stays in LDS (record-major, where the parked rows were,
     // once every lane is done with those) and the camera x camera products are formed from there below.
     const int wl = tid & 63, tsrc = ((wl & 7) << 3) | (wl >> 3);
+    const bool need_T = !fold || P.fold_mc_partial == nullptr || P.keep_T;   // (uniform over the workgroup)
     auto round = [&](int rd, double (&Tk)[18], int& cpk) {
       const int i = f + rd + sub;
       int cp = -1;
@@ -467,8 +469,14 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
 #pragma unroll
       for (int k = 0; k < 18; k++) Tk[k] = T[k];
       const int cpt = __shfl(cp, tsrc, 64);
+      // The T records in memory are read by the pair kernels only - by the entries that did NOT fold.  A workgroup folds all
+      // of its entries or none (both records of an entry belong to one point), so a folding workgroup whose intrinsics x camera
+      // products fold too has no reader for its records: it keeps them in LDS for its own products and does not store them
+      // (173 MB per iteration at config 3, and the 36 lane exchanges per round that line the stores up).
+      if (need_T) {
 #pragma unroll
-      for (int k = 0; k < 18; k++) T[k] = __shfl(T[k], tsrc, 64);
+        for (int k = 0; k < 18; k++) T[k] = __shfl(T[k], tsrc, 64);
+      }
 #pragma unroll
       for (int k = 0; k < 6; k++) tu[k] = __shfl(tu[k], tsrc, 64);
       if (cpt >= 0) {
@@ -478,8 +486,10 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
         // component-major (T[k][position], positions camera-major): records of consecutive points of a camera are
         // neighbours in every component plane, so these stores and the pair kernel's loads coalesce over the runs of
         // points that share their cameras
+        if (need_T) {
 #pragma unroll
-        for (int k = 0; k < 18; k++) P.T[(size_t)k * P.NCR + cpt] = T[k];
+          for (int k = 0; k < 18; k++) P.T[(size_t)k * P.NCR + cpt] = T[k];
+        }
       }
     };
     // records in LDS: two halves (rows 0..2 and 3..5 of the 6 x 3 record) of 10 doubles each, record-major, so that a slot
@@ -3847,6 +3857,7 @@ static void launch_point(msfm_ba* ba, const msfm_ba_options* opt, double radius,
   Q.fold_pass = F.pass.p; Q.fold_stream = F.stream.p; Q.fold_partial = F.partial.p;
   Q.fold_mc_partial = (F.on && F.mc_on) ? F.mc_partial.p : nullptr;
   Q.spec = spec;
+  { static const bool keep = getenv("MSFM_KEEP_T") != nullptr && atoi(getenv("MSFM_KEEP_T")) != 0; Q.keep_T = keep ? 1 : 0; }
   hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, ctx->stream, Q, ba->gmax_buf.p);
 }
 
