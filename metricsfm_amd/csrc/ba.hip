@@ -415,8 +415,7 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
         if (!ok) atomicOr(P.fail, 2);
         double* L = P.ptL + 6 * (size_t)pb;
         L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
-        double* gp = P.ptg + 3 * (size_t)pb;
-        gp[0] = g0; gp[1] = g1; gp[2] = g2;
+        // (g itself is not stored: the back substitution forms it again from the rows)
         const double* sp = P.B.scale_p + 3 * (size_t)pb;
         gmax = fmax(fabs(g0 / sp[0]), fmax(fabs(g1 / sp[1]), fabs(g2 / sp[2])));
       }
