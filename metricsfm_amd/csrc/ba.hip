@@ -311,6 +311,7 @@ struct PointPtrs {
   // (k_publish_scalars) accepted that step - else the launch ends at once - and spec[1] = the new trust-region radius.
   const double* spec;
   int keep_T;   // MSFM_KEEP_T=1: store every T record as rounds 1-3 did (comparison)
+  int tu_direct;   // (MSFM_TU_DIRECT=0: T.u through the lane exchange as well)
 };
 
 // (8-lane groups; after the first two steps the four lanes of a quad hold the same value, so adding lane 7 - i is adding lane i ^ 4)
@@ -467,6 +468,15 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
       cpk = cp;
 #pragma unroll
       for (int k = 0; k < 18; k++) Tk[k] = T[k];
+      if (!need_T && P.tu_direct) {
+        // (only T.u leaves the workgroup: 48 contiguous bytes per row, stored from the lane that formed them - no exchange)
+        if (cp >= 0) {
+          double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cp);
+#pragma unroll
+          for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
+        }
+        return;
+      }
       const int cpt = __shfl(cp, tsrc, 64);
       // The T records in memory are read by the pair kernels only - by the entries that did NOT fold.  A workgroup folds all
       // of its entries or none (both records of an entry belong to one point), so a folding workgroup whose intrinsics x camera
@@ -3857,6 +3867,7 @@ static void launch_point(msfm_ba* ba, const msfm_ba_options* opt, double radius,
   Q.fold_mc_partial = (F.on && F.mc_on) ? F.mc_partial.p : nullptr;
   Q.spec = spec;
   { static const bool keep = getenv("MSFM_KEEP_T") != nullptr && atoi(getenv("MSFM_KEEP_T")) != 0; Q.keep_T = keep ? 1 : 0; }
+  { static const bool d = !(getenv("MSFM_TU_DIRECT") != nullptr && atoi(getenv("MSFM_TU_DIRECT")) == 0); Q.tu_direct = d ? 1 : 0; }
   hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, ctx->stream, Q, ba->gmax_buf.p);
 }
 
