@@ -1970,8 +1970,12 @@ static bool choose_dissection(const CamGraph& G, int tail_cols, int force_depth,
   bool found = false;
   CutCache cache;
   cache.reserve(16);
+  long leaf_steps = dense;   // longest leaf chain of the depth before
   for (int depth = 1; depth <= 3; depth++) {
     if (force_depth >= 0 && depth != force_depth) continue;
+    // one more cut replaces a leaf chain of p steps by ~p / 2 + its separator's + the 3 of the level: below a dozen steps that
+    // cannot pay, and the cuts need not be evaluated (a third of the ordering's host time at config 3)
+    if (force_depth < 0 && depth > 1 && leaf_steps < 12) break;
     NdTree T;
     std::vector<char> all(n, 1);
     nd_split(G, all, depth, 0, tail_cols, cache, T);
@@ -1987,6 +1991,7 @@ static bool choose_dissection(const CamGraph& G, int tail_cols, int force_depth,
     if (!ok) continue;
     long chain = 0, maxp = 0;
     for (auto& l : T.leaves) maxp = std::max<long>(maxp, cdiv(6 * (long)l.cams.size(), 64));
+    leaf_steps = maxp;
     chain += maxp + 3;
     for (size_t d = T.seps.size() - 1; d >= 1; d--) {
       long mp = 0;
