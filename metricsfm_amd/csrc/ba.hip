@@ -2493,75 +2493,98 @@ __global__ __launch_bounds__(256) void k_block_lists(long nkey, long ncol, const
 }  // namespace devsetup
 
 #define DTRY(expr) HIP_TRY(ctx, (expr))
+// One block-pair list in three phases, so that the three lists of a problem share their host synchronisations (each phase ends
+// in a read-back: the number of entries, then the numbers of blocks and chunks): the lists of a small problem - the window of a
+// new camera - are a few dozen short launches each, and nine stream synchronisations were a third of its set-up.
 template <int KIND>
-static int build_pairs_device(msfm_ctx* ctx, msfm_ba* ba, PairJobs& J, int nout, const int* d_pt_first, const int* d_pm_first, const int* d_pm_mb,
-                              DevBuf<char>& tmp, bool want_host_blocks) {
-  using namespace devsetup;
-  hipStream_t s = ctx->stream;
-  const int npb = ba->npb, ncb = ba->ncb, nmb = ba->nmb;
-  const long nrow = KIND == 0 ? ncb : nmb, ncol = KIND == 2 ? nmb : ncb;
-  const long nkey = nrow * ncol;
-  J.n_pairs = J.n_chunks = J.n_blocks = 0;
-  J.h_row.clear(); J.h_col.clear();
-  if (nkey == 0) {
-    DTRY(J.pa.alloc(1)); DTRY(J.pb.alloc(1)); DTRY(J.ch_start.alloc(1)); DTRY(J.ch_end.alloc(1)); DTRY(J.blk_row.alloc(1)); DTRY(J.blk_col.alloc(1));
-    DTRY(J.blk_chunk_first.alloc(1)); DTRY(hipMemsetAsync(J.blk_chunk_first.p, 0, sizeof(int), s)); DTRY(J.partial.alloc(nout));
+struct PairBuild {
+  msfm_ctx* ctx; msfm_ba* ba; PairJobs& J; int nout; const int *d_pt_first, *d_pm_first, *d_pm_mb; DevBuf<char>& tmp; bool want_host_blocks;
+  long nrow = 0, ncol = 0, nkey = 0;
+  DevBuf<int> count, offset, key, pa, pbv, key_hist, key_sorted, perm, perm_sorted, key_first, flag, nchunk, blk_of_key, chunk_first;
+  int total = 0, nbc[2] = {0, 0}, chunk = 0;
+  bool empty = false;
+  PairBuild(msfm_ctx* c, msfm_ba* b, PairJobs& j, int no, const int* pf, const int* pmf, const int* pmm, DevBuf<char>& t, bool w)
+      : ctx(c), ba(b), J(j), nout(no), d_pt_first(pf), d_pm_first(pmf), d_pm_mb(pmm), tmp(t), want_host_blocks(w) {}
+  // entries per point, their offsets; asks for the total
+  int phase1() {
+    using namespace devsetup;
+    hipStream_t s = ctx->stream;
+    const int npb = ba->npb, ncb = ba->ncb, nmb = ba->nmb;
+    nrow = KIND == 0 ? ncb : nmb; ncol = KIND == 2 ? nmb : ncb;
+    nkey = nrow * ncol;
+    J.n_pairs = J.n_chunks = J.n_blocks = 0;
+    J.h_row.clear(); J.h_col.clear();
+    if (nkey == 0) {
+      empty = true;
+      DTRY(J.pa.alloc(1)); DTRY(J.pb.alloc(1)); DTRY(J.ch_start.alloc(1)); DTRY(J.ch_end.alloc(1)); DTRY(J.blk_row.alloc(1)); DTRY(J.blk_col.alloc(1));
+      DTRY(J.blk_chunk_first.alloc(1)); DTRY(hipMemsetAsync(J.blk_chunk_first.p, 0, sizeof(int), s)); DTRY(J.partial.alloc(nout));
+      return MSFM_OK;
+    }
+    if (nkey > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_NOMEM, "block key space too large");
+    const int nb_p = cdiv(std::max(1, npb), 256);
+    DTRY(count.alloc((size_t)npb + 1)); DTRY(offset.alloc((size_t)npb + 1));
+    DTRY(hipMemsetAsync(count.p, 0, sizeof(int) * ((size_t)npb + 1), s));
+    if (npb) hipLaunchKernelGGL((k_pairs_of_points<KIND, false>), dim3(nb_p), dim3(256), 0, s, npb, d_pt_first, ba->o_cb.p, ba->o_cpos.p, d_pm_first, d_pm_mb,
+                                ncol, count.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+    DTRY(excl_scan(count.p, offset.p, (size_t)npb + 1, s, tmp));
+    DTRY(hipMemcpyAsync(&total, offset.p + npb, sizeof(int), hipMemcpyDeviceToHost, s));
     return MSFM_OK;
   }
-  if (nkey > 0x7fffffffL) return msfm_set_error(ctx, MSFM_E_NOMEM, "block key space too large");
-  DevBuf<int> count, offset, key, pa, pbv, key_hist, key_sorted, perm, perm_sorted, key_first, flag, nchunk, blk_of_key, chunk_first;
-  const int nb_p = cdiv(std::max(1, npb), 256);
-  DTRY(count.alloc((size_t)npb + 1)); DTRY(offset.alloc((size_t)npb + 1));
-  DTRY(hipMemsetAsync(count.p, 0, sizeof(int) * ((size_t)npb + 1), s));
-  if (npb) hipLaunchKernelGGL((k_pairs_of_points<KIND, false>), dim3(nb_p), dim3(256), 0, s, npb, d_pt_first, ba->o_cb.p, ba->o_cpos.p, d_pm_first, d_pm_mb,
-                              ncol, count.p, (const int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
-  DTRY(excl_scan(count.p, offset.p, (size_t)npb + 1, s, tmp));
-  int total = 0;
-  DTRY(hipMemcpyAsync(&total, offset.p + npb, sizeof(int), hipMemcpyDeviceToHost, s));
-  DTRY(hipStreamSynchronize(s));
-  if (total < 0) return msfm_set_error(ctx, MSFM_E_NOMEM, "pair list too long");
-  const size_t nt = (size_t)std::max(1, total);
-  DTRY(key.alloc(nt)); DTRY(pa.alloc(nt)); DTRY(pbv.alloc(nt)); DTRY(key_hist.alloc((size_t)nkey + 1)); DTRY(key_first.alloc((size_t)nkey + 1));
-  if (npb && total) hipLaunchKernelGGL((k_pairs_of_points<KIND, true>), dim3(nb_p), dim3(256), 0, s, npb, d_pt_first, ba->o_cb.p, ba->o_cpos.p, d_pm_first,
-                                       d_pm_mb, ncol, (int*)nullptr, offset.p, key.p, pa.p, pbv.p);
-  // entries sorted by block key, point order kept inside a block (stable)
-  DTRY(J.pa.alloc(nt)); DTRY(J.pb.alloc(nt)); DTRY(key_sorted.alloc(nt));
-  if (total) {
-    DTRY(perm.alloc(nt)); DTRY(perm_sorted.alloc(nt));
-    hipLaunchKernelGGL(k_iota, dim3(cdiv(total, 256)), dim3(256), 0, s, total, perm.p);
-    DTRY(sort_pairs(key.p, key_sorted.p, perm.p, perm_sorted.p, (size_t)total, bits_for(nkey), s, tmp));
-    hipLaunchKernelGGL(k_gather2, dim3(cdiv(total, 256)), dim3(256), 0, s, total, perm_sorted.p, pa.p, pbv.p, J.pa.p, J.pb.p);
+  // (after a synchronisation) entries emitted, sorted by block key, blocks and chunks counted; asks for the two counts
+  int phase2() {
+    using namespace devsetup;
+    if (empty) return MSFM_OK;
+    hipStream_t s = ctx->stream;
+    const int npb = ba->npb;
+    const int nb_p = cdiv(std::max(1, npb), 256);
+    if (total < 0) return msfm_set_error(ctx, MSFM_E_NOMEM, "pair list too long");
+    const size_t nt = (size_t)std::max(1, total);
+    DTRY(key.alloc(nt)); DTRY(pa.alloc(nt)); DTRY(pbv.alloc(nt)); DTRY(key_hist.alloc((size_t)nkey + 1)); DTRY(key_first.alloc((size_t)nkey + 1));
+    if (npb && total) hipLaunchKernelGGL((k_pairs_of_points<KIND, true>), dim3(nb_p), dim3(256), 0, s, npb, d_pt_first, ba->o_cb.p, ba->o_cpos.p, d_pm_first,
+                                         d_pm_mb, ncol, (int*)nullptr, offset.p, key.p, pa.p, pbv.p);
+    // entries sorted by block key, point order kept inside a block (stable)
+    DTRY(J.pa.alloc(nt)); DTRY(J.pb.alloc(nt)); DTRY(key_sorted.alloc(nt));
+    if (total) {
+      DTRY(perm.alloc(nt)); DTRY(perm_sorted.alloc(nt));
+      hipLaunchKernelGGL(k_iota, dim3(cdiv(total, 256)), dim3(256), 0, s, total, perm.p);
+      DTRY(sort_pairs(key.p, key_sorted.p, perm.p, perm_sorted.p, (size_t)total, bits_for(nkey), s, tmp));
+      hipLaunchKernelGGL(k_gather2, dim3(cdiv(total, 256)), dim3(256), 0, s, total, perm_sorted.p, pa.p, pbv.p, J.pa.p, J.pb.p);
+    }
+    hipLaunchKernelGGL(k_key_first, dim3(cdiv(nkey + 1, 256)), dim3(256), 0, s, nkey, total, key_sorted.p, key_first.p);
+    hipLaunchKernelGGL(k_key_hist, dim3(cdiv(nkey + 1, 256)), dim3(256), 0, s, nkey, key_first.p, key_hist.p);
+    // blocks and chunks
+    DTRY(flag.alloc((size_t)nkey + 1)); DTRY(nchunk.alloc((size_t)nkey + 1)); DTRY(blk_of_key.alloc((size_t)nkey + 1)); DTRY(chunk_first.alloc((size_t)nkey + 1));
+    DTRY(hipMemsetAsync(flag.p + nkey, 0, sizeof(int), s)); DTRY(hipMemsetAsync(nchunk.p + nkey, 0, sizeof(int), s));
+    chunk = chunk_for((long)total, CHUNK);   // (the host build, finish_jobs, takes the same length)
+    hipLaunchKernelGGL(k_block_flags, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, KIND, chunk, key_hist.p, ba->cb_mb.p, flag.p, nchunk.p);
+    DTRY(excl_scan(flag.p, blk_of_key.p, (size_t)nkey + 1, s, tmp));
+    DTRY(excl_scan(nchunk.p, chunk_first.p, (size_t)nkey + 1, s, tmp));
+    DTRY(hipMemcpyAsync(&nbc[0], blk_of_key.p + nkey, sizeof(int), hipMemcpyDeviceToHost, s));
+    DTRY(hipMemcpyAsync(&nbc[1], chunk_first.p + nkey, sizeof(int), hipMemcpyDeviceToHost, s));
+    return MSFM_OK;
   }
-  hipLaunchKernelGGL(k_key_first, dim3(cdiv(nkey + 1, 256)), dim3(256), 0, s, nkey, total, key_sorted.p, key_first.p);
-  hipLaunchKernelGGL(k_key_hist, dim3(cdiv(nkey + 1, 256)), dim3(256), 0, s, nkey, key_first.p, key_hist.p);
-  // blocks and chunks
-  DTRY(flag.alloc((size_t)nkey + 1)); DTRY(nchunk.alloc((size_t)nkey + 1)); DTRY(blk_of_key.alloc((size_t)nkey + 1)); DTRY(chunk_first.alloc((size_t)nkey + 1));
-  DTRY(hipMemsetAsync(flag.p + nkey, 0, sizeof(int), s)); DTRY(hipMemsetAsync(nchunk.p + nkey, 0, sizeof(int), s));
-  const int chunk = chunk_for((long)total, CHUNK);   // (the host build, finish_jobs, takes the same length)
-  hipLaunchKernelGGL(k_block_flags, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, KIND, chunk, key_hist.p, ba->cb_mb.p, flag.p, nchunk.p);
-  DTRY(excl_scan(flag.p, blk_of_key.p, (size_t)nkey + 1, s, tmp));
-  DTRY(excl_scan(nchunk.p, chunk_first.p, (size_t)nkey + 1, s, tmp));
-  int nbc[2] = {0, 0};
-  DTRY(hipMemcpyAsync(&nbc[0], blk_of_key.p + nkey, sizeof(int), hipMemcpyDeviceToHost, s));
-  DTRY(hipMemcpyAsync(&nbc[1], chunk_first.p + nkey, sizeof(int), hipMemcpyDeviceToHost, s));
-  DTRY(hipStreamSynchronize(s));
-  J.n_pairs = total; J.n_blocks = nbc[0]; J.n_chunks = nbc[1];
-  DTRY(J.blk_row.alloc((size_t)std::max(1, J.n_blocks))); DTRY(J.blk_col.alloc((size_t)std::max(1, J.n_blocks)));
-  DTRY(J.blk_chunk_first.alloc((size_t)J.n_blocks + 1));
-  DTRY(J.ch_start.alloc((size_t)std::max(1, J.n_chunks))); DTRY(J.ch_end.alloc((size_t)std::max(1, J.n_chunks)));
-  hipLaunchKernelGGL(k_block_lists, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, flag.p, blk_of_key.p, key_first.p, key_hist.p, chunk_first.p,
-                     chunk, J.blk_row.p, J.blk_col.p, J.blk_chunk_first.p, J.ch_start.p, J.ch_end.p);
-  DTRY(hipMemcpyAsync(J.blk_chunk_first.p + J.n_blocks, &J.n_chunks, sizeof(int), hipMemcpyHostToDevice, s));
-  DTRY(J.partial.alloc((size_t)std::max(1, J.n_chunks) * nout));
-  if (want_host_blocks && J.n_blocks) {
-    J.h_row.resize(J.n_blocks); J.h_col.resize(J.n_blocks);
-    DTRY(hipMemcpyAsync(J.h_row.data(), J.blk_row.p, sizeof(int) * J.n_blocks, hipMemcpyDeviceToHost, s));
-    DTRY(hipMemcpyAsync(J.h_col.data(), J.blk_col.p, sizeof(int) * J.n_blocks, hipMemcpyDeviceToHost, s));
+  // (after a synchronisation) the block and chunk lists; the caller synchronises once more before the temporaries go
+  int phase3() {
+    using namespace devsetup;
+    if (empty) return MSFM_OK;
+    hipStream_t s = ctx->stream;
+    J.n_pairs = total; J.n_blocks = nbc[0]; J.n_chunks = nbc[1];
+    DTRY(J.blk_row.alloc((size_t)std::max(1, J.n_blocks))); DTRY(J.blk_col.alloc((size_t)std::max(1, J.n_blocks)));
+    DTRY(J.blk_chunk_first.alloc((size_t)J.n_blocks + 1));
+    DTRY(J.ch_start.alloc((size_t)std::max(1, J.n_chunks))); DTRY(J.ch_end.alloc((size_t)std::max(1, J.n_chunks)));
+    hipLaunchKernelGGL(k_block_lists, dim3(cdiv(nkey, 256)), dim3(256), 0, s, nkey, ncol, flag.p, blk_of_key.p, key_first.p, key_hist.p, chunk_first.p,
+                       chunk, J.blk_row.p, J.blk_col.p, J.blk_chunk_first.p, J.ch_start.p, J.ch_end.p);
+    DTRY(hipMemcpyAsync(J.blk_chunk_first.p + J.n_blocks, &J.n_chunks, sizeof(int), hipMemcpyHostToDevice, s));
+    DTRY(J.partial.alloc((size_t)std::max(1, J.n_chunks) * nout));
+    if (want_host_blocks && J.n_blocks) {
+      J.h_row.resize(J.n_blocks); J.h_col.resize(J.n_blocks);
+      DTRY(hipMemcpyAsync(J.h_row.data(), J.blk_row.p, sizeof(int) * J.n_blocks, hipMemcpyDeviceToHost, s));
+      DTRY(hipMemcpyAsync(J.h_col.data(), J.blk_col.p, sizeof(int) * J.n_blocks, hipMemcpyDeviceToHost, s));
+    }
+    DTRY(hipGetLastError());
+    return MSFM_OK;
   }
-  DTRY(hipGetLastError());
-  DTRY(hipStreamSynchronize(s));   // the host copy of n_chunks and the temporaries go out of scope
-  return MSFM_OK;
-}
+};
 
 // ---- fold tables (FoldTables above), built from the resident index structures whichever way those were made ----
 namespace devsetup {
@@ -3206,10 +3229,18 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
   lap("entries + chunks");
   // ---- block-pair lists ----
   const bool want_blocks = ctx->world > 1;
-  MSFM_TRY((build_pairs_device<0>(ctx, ba, ba->cc, 36, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, want_blocks)));
+  {
+    PairBuild<0> b0(ctx, ba, ba->cc, 36, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, want_blocks);
+    PairBuild<1> b1(ctx, ba, ba->mc, 18, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, false);
+    PairBuild<2> b2(ctx, ba, ba->mm, 12, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, false);
+    MSFM_TRY(b0.phase1()); MSFM_TRY(b1.phase1()); MSFM_TRY(b2.phase1());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    MSFM_TRY(b0.phase2()); MSFM_TRY(b1.phase2()); MSFM_TRY(b2.phase2());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    MSFM_TRY(b0.phase3()); MSFM_TRY(b1.phase3()); MSFM_TRY(b2.phase3());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the host copies of the counts and the temporaries go out of scope
+  }
   lap("pairs cc");
-  MSFM_TRY((build_pairs_device<1>(ctx, ba, ba->mc, 18, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, false)));
-  MSFM_TRY((build_pairs_device<2>(ctx, ba, ba->mm, 12, ba->pt_first.p, ba->pm_first.p, ba->pm_mb.p, tmp, false)));
   lap("pairs mc mm");
   return MSFM_OK;
 }
