@@ -295,6 +295,16 @@ typedef struct msfm_ba_layout {
 } msfm_ba_layout;
 int msfm_ba_get_layout(const msfm_ba* ba, msfm_ba_layout* out);
 
+/* The elimination order of msfm_ba_create as a host-only function (no device, no context: a diagnostic for tests and for
+ * sizing): the nested dissection of a camera graph given as an n x n 0/1 adjacency matrix (cameras that see a common
+ * eliminated point; the reduced camera matrix of optimizer.cc:133's Schur complement has a block exactly there).
+ * tail_cols = columns that follow the last camera (3 per intrinsics block + 1), force_depth = -1 (choose) or 1..3.
+ * label[c] = leaf domain of camera c (0 .. n_leaves - 1), or -(d + 1) for a camera of a separator cut at depth d (-1 = the
+ * root separator).  *chain_steps = 64-column panel steps on the critical path (longest leaf + longest separator of every
+ * depth + root).  *n_leaves = 0 (and every label 0): the dense order is kept. */
+int msfm_camera_graph_dissection(int n_cams, const uint8_t* adjacency, int tail_cols, int force_depth, int32_t* label,
+                                 int* n_leaves, int* chain_steps);
+
 /* Multi-GPU: points (with all their observations) are sharded over ranks, cameras and
  * intrinsics are replicated; a few times per LM iteration `count` doubles at `buf_dev` (the per-camera J^T J sums, the
  * partial reduced system [S | rhs], a handful of scalars) must be reduced over ranks in place

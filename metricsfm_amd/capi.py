@@ -24,7 +24,7 @@ SYMBOLS = [
     "msfm_chain_fetch_tracks", "msfm_chain_triangulate", "msfm_chain_fetch_points", "msfm_chain_ba_create", "msfm_chain_fetch_point_tracks",
     "msfm_chain_destroy",
     "msfm_ba_options_default", "msfm_ba_solve", "msfm_ba_create", "msfm_ba_run",
-    "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ba_get_layout", "msfm_ctx_set_allreduce",
+    "msfm_ba_upload_params", "msfm_ba_download_params", "msfm_ba_destroy", "msfm_ba_get_layout", "msfm_camera_graph_dissection", "msfm_ctx_set_allreduce",
     "msfm_triangulate_midpoint_batch", "msfm_triangulate_dlt_batch", "msfm_reproject_mse_batch",
     "msfm_epipolar_filter", "msfm_fransac_default_options", "msfm_fundamental_ransac_batch",
     "msfm_epipolar_filter_batch", "msfm_tracks_build", "msfm_tracks_build_device", "msfm_track_set_size", "msfm_track_set_fetch", "msfm_track_set_destroy",
@@ -93,6 +93,7 @@ def lib():
     L.msfm_reproject_mse_batch.argtypes = [vp, C.POINTER(A.Tracks), A.c_double_p, A.c_double_p]
     L.msfm_epipolar_filter.argtypes = [vp, A.c_float_p, A.c_float_p, i, A.c_double_p, d, A.c_u8_p]
     L.msfm_ba_get_layout.argtypes = [vp, C.POINTER(A.BaLayout)]
+    L.msfm_camera_graph_dissection.argtypes = [i, vp, i, i, vp, C.POINTER(i), C.POINTER(i)]
     L.msfm_fransac_default_options.argtypes = [C.POINTER(A.FransacOptions)]
     L.msfm_fransac_default_options.restype = None
     L.msfm_fundamental_ransac_batch.argtypes = [vp, i, A.c_int_p, A.c_float_p, A.c_float_p, C.POINTER(A.FransacOptions),
@@ -715,3 +716,18 @@ class MultiContext:
             self.close()
         except Exception:
             pass
+
+
+def camera_graph_dissection(adjacency, tail_cols=4, force_depth=-1):
+    """msfm_camera_graph_dissection (host only: works without a GPU): labels per camera (leaf id, or -(d + 1) for a separator cut
+    at depth d), number of leaves (0: dense order kept) and the critical path in 64-column panel steps."""
+    import numpy as np
+    adj = np.ascontiguousarray(adjacency, dtype=np.uint8)
+    n = adj.shape[0]
+    assert adj.shape == (n, n)
+    label = np.zeros(n, np.int32)
+    nl, steps = C.c_int(0), C.c_int(0)
+    rc = lib().msfm_camera_graph_dissection(n, adj.ctypes.data, int(tail_cols), int(force_depth), label.ctypes.data, C.byref(nl), C.byref(steps))
+    if rc != 0:
+        raise MsfmError(rc, "msfm_camera_graph_dissection")
+    return label, nl.value, steps.value

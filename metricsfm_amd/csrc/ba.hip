@@ -2008,6 +2008,38 @@ static bool choose_dissection(const CamGraph& G, int tail_cols, int force_depth,
   return found;
 }
 
+MSFM_API int msfm_camera_graph_dissection(int n_cams, const uint8_t* adjacency, int tail_cols, int force_depth, int32_t* label,
+                                          int* n_leaves, int* chain_steps) {
+  if (n_cams < 1 || !adjacency || !label || !n_leaves || !chain_steps || force_depth > 3) return MSFM_E_INVAL;
+  CamGraph G;
+  G.n = n_cams;
+  G.adj.resize(n_cams);
+  for (int a = 0; a < n_cams; a++)
+    for (int b = 0; b < n_cams; b++) if (a != b && adjacency[(size_t)a * n_cams + b]) G.adj[a].push_back(b);
+  for (int c = 0; c < n_cams; c++) label[c] = 0;
+  *n_leaves = 0;
+  *chain_steps = (int)cdiv(6L * n_cams + tail_cols, 64);
+  NdTree T;
+  if (!choose_dissection(G, tail_cols, force_depth, T)) return MSFM_OK;
+  *n_leaves = (int)T.leaves.size();
+  long chain = 0, mx = 0;
+  for (size_t i = 0; i < T.leaves.size(); i++) {
+    for (int c : T.leaves[i].cams) label[c] = (int)i;
+    mx = std::max<long>(mx, cdiv(6 * (long)T.leaves[i].cams.size(), 64));
+  }
+  chain += mx;
+  for (size_t d = 0; d < T.seps.size(); d++) {
+    mx = 0;
+    for (auto& q : T.seps[d]) {
+      for (int c : q.cams) label[c] = -(int)(d + 1);
+      mx = std::max<long>(mx, cdiv(6 * (long)q.cams.size() + (d == 0 ? tail_cols : 0), 64));
+    }
+    chain += mx;
+  }
+  *chain_steps = (int)chain;
+  return MSFM_OK;
+}
+
 static bool is_mut(const uint8_t* m, int i) { return m == nullptr || m[i] != 0; }
 
 // Numbers the camera blocks in elimination order and lays the reduced system out: leaves, then the separators from the
