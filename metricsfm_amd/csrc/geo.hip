@@ -234,9 +234,10 @@ __global__ __launch_bounds__(GEO_WAVE) void k_fransac_models(int h0, int h1, con
 // at a time), wave w takes samples [32 w, 32 w + 32) of the block's 128 one after the other, lane = match.
 // counts[slot][h - h0][3] (-1: no such model).
 #define GEO_CNT_SAMPLES 128
+// counts[slot][cs samples][3]: this launch's samples start at sample `co` of a slot's row (a range taken in several pieces shares one array).
 __global__ __launch_bounds__(256) void k_fransac_count(int h0, int h1, const int* __restrict__ slot_pair, const int* __restrict__ n_slots_dev,
                                                         const int* __restrict__ off, const float2* __restrict__ pt1, const float2* __restrict__ pt2,
-                                                        double th2, const GeoModelRec* __restrict__ models, int* __restrict__ counts) {
+                                                        double th2, const GeoModelRec* __restrict__ models, int* __restrict__ counts, int cs, int co) {
   __shared__ float4 pts[1024];
   __shared__ int cnt_s[GEO_CNT_SAMPLES * 3];
   if (n_slots_dev && (int)blockIdx.y >= *n_slots_dev) return;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void k_fransac_count(int h0, int h1, const int
   __syncthreads();
   for (int e = threadIdx.x; e < GEO_CNT_SAMPLES * 3; e += 256) {
     const int hs = blockIdx.x * GEO_CNT_SAMPLES + e / 3, q = e % 3;
-    if (hs < HS) counts[((size_t)slot * HS + hs) * 3 + q] = q < models[(size_t)slot * HS + hs].n ? cnt_s[e] : -1;
+    if (hs < HS) counts[((size_t)slot * cs + co + hs) * 3 + q] = q < models[(size_t)slot * HS + hs].n ? cnt_s[e] : -1;
   }
 }
 
@@ -496,15 +497,19 @@ int geo_fransac_dev(msfm_ctx* ctx, int n_pairs, const int* offsets, const int* d
   HIP_TRY(ctx, d_models1.alloc((size_t)n_slots * H1));
   const float2* p1 = reinterpret_cast<const float2*>(d1);
   const float2* p2 = reinterpret_cast<const float2*>(d2);
-  auto score = [&](int h0, int h1, int ns, const int* slots, const int* ns_dev, GeoModelRec* models, int* counts, const char* name) {
+  // the models of a sample range live in memory only between the two kernels: a long range is taken in pieces of `piece`
+  // samples that reuse one model buffer (224 bytes per sample and pair: 1 872 samples at once would be 420 KB per pair)
+  auto score = [&](int h0, int h1, int piece, int ns, const int* slots, GeoModelRec* models, int* counts, const char* name) {
     KTimer t(ctx, name);
-    for (int p0 = 0; p0 < ns; p0 += 32768) {  // grid.y limit
-      const int np = std::min(32768, ns - p0);
-      // (ns_dev counts from the start of the list: only a single slice may use it)
-      hipLaunchKernelGGL(k_fransac_models, dim3(cdiv(h1 - h0, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, h0, h1, slots + p0, ns > 32768 ? nullptr : ns_dev, d_off,
-                         p1, p2, opt->seed, models + (size_t)p0 * (h1 - h0));
-      hipLaunchKernelGGL(k_fransac_count, dim3(cdiv(h1 - h0, GEO_CNT_SAMPLES), np), dim3(256), 0, s, h0, h1, slots + p0, ns > 32768 ? nullptr : ns_dev, d_off,
-                         p1, p2, th2, models + (size_t)p0 * (h1 - h0), counts + (size_t)p0 * (h1 - h0) * 3);
+    for (int a = h0; a < h1; a += piece) {
+      const int b = std::min(h1, a + piece);
+      for (int p0 = 0; p0 < ns; p0 += 32768) {  // grid.y limit
+        const int np = std::min(32768, ns - p0);
+        hipLaunchKernelGGL(k_fransac_models, dim3(cdiv(b - a, GEO_WAVE), np), dim3(GEO_WAVE), 0, s, a, b, slots + p0, (const int*)nullptr, d_off,
+                           p1, p2, opt->seed, models + (size_t)p0 * piece);
+        hipLaunchKernelGGL(k_fransac_count, dim3(cdiv(b - a, GEO_CNT_SAMPLES), np), dim3(256), 0, s, a, b, slots + p0, (const int*)nullptr, d_off,
+                           p1, p2, th2, models + (size_t)p0 * piece, counts + (size_t)p0 * (h1 - h0) * 3, h1 - h0, a - h0);
+      }
     }
   };
   auto select = [&](int pass, int grid) {
@@ -512,20 +517,21 @@ int geo_fransac_dev(msfm_ctx* ctx, int n_pairs, const int* offsets, const int* d
     hipLaunchKernelGGL(k_fransac_select, dim3(grid), dim3(GEO_WAVE), 0, s, H, H1, pass, d_slot_pair.p, d_need.p + 1, d_need.p, d_off, p1, p2, opt->seed, th2,
                        opt->min_inliers, d_counts1.p, d_counts2.p, d_tab.p, d_tab_off.p, dF, d_in, d_nin, d_ok);
   };
-  score(0, H1, n_slots, d_slot_pair.p, nullptr, d_models1.p, d_counts1.p, "geo_fransac_score");
+  score(0, H1, H1, n_slots, d_slot_pair.p, d_models1.p, d_counts1.p, "geo_fransac_score");
   select(1, n_slots);
   if (H1 < H) {
     int n_need = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n_need, d_need.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (n_need > 0) {
+      const int piece = std::min(H - H1, 256);
       HIP_TRY(ctx, d_counts2.alloc((size_t)n_need * (H - H1) * 3));
-      HIP_TRY(ctx, d_models2.alloc((size_t)n_need * (H - H1)));
+      HIP_TRY(ctx, d_models2.alloc((size_t)n_need * piece));
       // the list holds SLOTS; the kernels of the second range want pairs
       DevBuf<int> d_need_pair;
       HIP_TRY(ctx, d_need_pair.alloc(n_need));
       hipLaunchKernelGGL(k_gather_int, dim3(cdiv(n_need, 256)), dim3(256), 0, s, n_need, d_need.p + 1, d_slot_pair.p, d_need_pair.p);
-      score(H1, H, n_need, d_need_pair.p, nullptr, d_models2.p, d_counts2.p, "geo_fransac_score_rest");
+      score(H1, H, piece, n_need, d_need_pair.p, d_models2.p, d_counts2.p, "geo_fransac_score_rest");
       select(2, n_need);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(s));
