@@ -308,7 +308,8 @@ def test_ba_folded_schur_products_match_the_oracle_and_the_gather_path(oracle):
             "run(sc, cam_mutable=cm, pt_mutable=pm, gps_xyz=sc.gps_xyz, gps_weight=50.0)\n"
             "print(repr(out))\n") % ROOT
     outs = {}
-    for name, env in (("fold", dict(MSFM_FOLD_MIN="0")), ("gather", dict(MSFM_NO_FOLD="1")), ("fold_separate_launches", dict(MSFM_FOLD_MIN="0", MSFM_FUSED_SUMS="0"))):
+    for name, env in (("fold", dict(MSFM_FOLD_MIN="0")), ("gather", dict(MSFM_NO_FOLD="1")), ("fold_separate_launches", dict(MSFM_FOLD_MIN="0", MSFM_FUSED_SUMS="0")),
+                      ("fold_all_T_stored", dict(MSFM_FOLD_MIN="0", MSFM_KEEP_T="1", MSFM_TU_DIRECT="0"))):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         outs[name] = eval(r.stdout.strip().splitlines()[-1])
@@ -318,6 +319,10 @@ def test_ba_folded_schur_products_match_the_oracle_and_the_gather_path(oracle):
     # round 4: per-camera sums, pair-list residue and zero fill as ONE launch (k_sums) against the separate launches on two streams:
     # the same arithmetic per chunk, so every cost of every trajectory is the same number
     assert outs["fold"] == outs["fold_separate_launches"]
+    # round 4: a folding workgroup does not store its T records (their only readers are pair-list entries that did not fold, and a
+    # workgroup folds all of its entries or none) and sends T.u out without the lane exchange: storing everything as before
+    # must give the same numbers - a reader of an unstored record would show here
+    assert outs["fold"] == outs["fold_all_T_stored"]
 
 
 def test_ba_domains_with_window_masks(ctx, oracle, monkeypatch):
