@@ -654,6 +654,9 @@ __global__ __launch_bounds__(64) void k_knn2_exact(const PairTaskF* __restrict__
 // (k_exact_flagged), so the result is exact for every finite input; how many took that road is reported in the
 // result object (msfm_match_result_stats).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifndef MSFM_KNN_F16_PROBE
+#define MSFM_KNN_F16_PROBE 0
+#endif
 
 __global__ __launch_bounds__(256) void k_desc_prep_f16(const float* __restrict__ d, int count, float scale, unsigned short* __restrict__ th,
                                                         unsigned short* __restrict__ qh, float* __restrict__ n2s, float* __restrict__ rerr,
@@ -777,6 +780,17 @@ __device__ __forceinline__ void merge_window4(u32 (&g)[4], int (&gb)[4], u32 w0,
 }
 
 // Epilogue of one query (two lanes: r, r + 32, each with the list of its half of the train rows).
+//
+// Round 5: what the reference's loop consumes of a query is the index of its nearest row and the outcome of `ratio < th`
+// (fine_matching_graph.cc:116-130; slam_gps.cc:469-477) - the distances themselves only when the caller keeps the 2-NN arrays.
+// Every listed row's exact scaled distance lies in [val - G - E, val (1 + 2^-15) - G + E] and every other row's above
+// `unl - G - E` (unl: the smaller fourth key of the two lists and the bound of the rows the compare filter dropped).  When
+// the interval of the smallest value lies strictly below everybody else's lower bound, the nearest row is known; the second
+// nearest DISTANCE then lies between the smallest lower bound and the smallest upper bound of the others, the float ratio is
+// monotone in both distances (float conversion and float division are monotone), and if `ratio < th` comes out the same at
+// both ends of its interval it is the exact answer: the code is written without a single exact evaluation (97 % of the
+// queries on 512-norm SIFT-like data).  Otherwise - and whenever the 2-NN arrays are kept - the candidates are evaluated by
+// the oracle's definition as before: 32 scattered 16-byte loads per lane and candidate, which was a fifth of the kernel's time.
 __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, int q, bool qvalid, int h, const u32 (&gk)[4], const int (&gbase)[4],
                                                  float ratio_good, float ratio_all, int32_t* __restrict__ code, int* __restrict__ ids,
                                                  float* __restrict__ sqd, int* __restrict__ n_all, int* __restrict__ n_good,
@@ -794,7 +808,61 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
   const double b2 = (double)T.qn2s[qvalid ? q : 0], shift = (double)T.shift;
   const double E = f16_error_bound((double)T.a2max_s, (double)T.remax_a, b2, (double)T.qre[qvalid ? q : 0], shift);
   const double G = shift - b2;
+  // rows outside the two lists: v >= the 4th key of their half ...
+  const double b_mine = gi[3] < T.n_train ? (double)__uint_as_float(gv[3]) : inf;
+  const double b_other = oi[3] < T.n_train ? (double)__uint_as_float(ov[3]) : inf;
+  double unl = fmin(b_mine, b_other);
+#ifndef MSFM_KNN_F16_NOFILTER
+  // ... and the rows the compare filter of the main loop dropped were above a threshold that was never smaller than
+  // T = (second smallest key of the two final lists, low byte filled) (1 + 2^-15) + 2.01 E  (the loop adds 2.05 E, rounded up; a
+  // window's or an earlier flush's second smallest is never below the final one, and the two smallest rows of a query are
+  // never dropped nor pushed out of a four-key list), so T bounds them from below as the fourth keys bound the evicted rows.
+  {
+    u32 k1 = 0xffffffffu, k2 = 0xffffffffu;   // two smallest keys over both lists
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u32 kk = (j < 4 ? gv[j] : ov[j - 4]) | 255u;   // (gv / ov: the keys with their low byte cleared; an empty slot is all ones)
+      const u32 n1 = min(k1, kk);
+      k2 = min(max(k1, kk), k2);
+      k1 = n1;
+    }
+    if (k2 < 0x7f800000u) unl = fmin(unl, (double)__uint_as_float(k2) * (1.0 + 3.0517578125e-5) + 2.01 * E);
+  }
+#endif
   // scaled-distance interval of a listed row: [val - G - E, val (1 + 2^-15) - G + E]  (val = key with its low byte cleared)
+  // the two smallest values over both lists (both lanes of a query see the same eight entries: every decision below that
+  // both take is taken alike)
+  u32 v1 = 0xffffffffu, v2 = 0xffffffffu;
+  int id1 = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u32 kv = j < 4 ? gv[j] : ov[j - 4];
+    const int ki = j < 4 ? gi[j] : oi[j - 4];
+    if (ki < T.n_train) {
+      if (kv < v1 || (kv == v1 && ki < id1)) { v2 = v1; v1 = kv; id1 = ki; }
+      else if (kv < v2) v2 = kv;
+    }
+  }
+  bool certain = false;
+  float fa = 0.f, fb = 1.f;
+#ifndef MSFM_KNN_F16_NOFASTCODE
+  if (!ids && v2 < 0x7f800000u) {
+    const double inv_s2 = 1.0 / (double)T.s2;   // a power of two: exact
+    const double x1 = (double)__uint_as_float(v1), x2 = (double)__uint_as_float(v2);
+    // (the 1e-12: the oracle's 128 binary64 fused steps stay within 1.5e-14 of the real-number distance that E bounds)
+    const double lo0 = (x1 - G - E) * inv_s2 * (1.0 - 1e-12), hi0 = (x1 * (1.0 + 3.0517578125e-5) - G + E) * inv_s2 * (1.0 + 1e-12);
+    const double lo1 = (fmin(x2, unl) - G - E) * inv_s2 * (1.0 - 1e-12), hi1 = (x2 * (1.0 + 3.0517578125e-5) - G + E) * inv_s2 * (1.0 + 1e-12);
+    // the float distances the exact path would form lie in [(float)lo, (float)hi] (rounding is monotone); the 1e-30 guard keeps
+    // zeros, subnormal ratios and 0 / 0 on the exact path
+    const float f_lo0 = (float)lo0, f_hi0 = (float)hi0, f_lo1 = (float)lo1, f_hi1 = (float)hi1;
+    if (lo0 > 1e-30 && hi0 < lo1 && f_hi1 < 3.0e38f) {
+      const float r_lo = f_lo0 / f_hi1, r_hi = f_hi0 / f_lo1;   // the float ratio of the exact path lies in [r_lo, r_hi]
+      if (ratio_good < 0.f) certain = (r_lo > ratio_all) == (r_hi > ratio_all);
+      else certain = ((r_lo < ratio_good) == (r_hi < ratio_good)) && ((r_lo < ratio_all) == (r_hi < ratio_all));
+      fa = f_hi0; fb = f_lo1;   // any point of the interval gives the certain outcome
+    }
+  }
+#endif
   double h1 = inf, h2 = inf;  // the two smallest upper bounds over both lists
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -810,7 +878,7 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
   int i0 = 0x7fffffff, i1 = 0x7fffffff;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const bool eval = qvalid && gi[j] < T.n_train && ((double)__uint_as_float(gv[j]) - G - E) <= h2;
+    const bool eval = qvalid && !certain && gi[j] < T.n_train && ((double)__uint_as_float(gv[j]) - G - E) <= h2;
     if (eval) {
       const double s = exact_sqdist(T.tf32 + (size_t)gi[j] * DIM, qv);
       merge_top2(d0, i0, d1, i1, s, gi[j], inf, 0x7fffffff);
@@ -822,27 +890,12 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
     merge_top2(d0, i0, d1, i1, e0, j0, e1, j1);
   }
   if (h != 0 || !qvalid) return;
-  // rows outside the two lists: v >= the 4th key of their half
-  const double b_mine = gi[3] < T.n_train ? (double)__uint_as_float(gv[3]) : inf;
-  const double b_other = oi[3] < T.n_train ? (double)__uint_as_float(ov[3]) : inf;
-#ifdef MSFM_KNN_F16_FILTER
-  // with the compare filter a lane drops rows above the fourth key of the two lists TOGETHER, so that key bounds the unlisted rows
-  double b_union = inf;
-  {
-    double mx[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const double x = gi[i] < T.n_train ? (double)__uint_as_float(gv[i]) : inf;
-      const double y = oi[3 - i] < T.n_train ? (double)__uint_as_float(ov[3 - i]) : inf;
-      mx[i] = fmax(x, y);
-    }
-    b_union = fmin(fmin(mx[0], mx[1]), fmin(mx[2], mx[3]));
-  }
-  const double bound = fmin(fmin(b_mine, b_other), b_union) - G - E;
-#else
-  const double bound = fmin(b_mine, b_other) - G - E;
-#endif
   const size_t o = (size_t)T.out_off + q;
+  if (certain) {
+    code[o] = ratio_code(fa, fb, id1, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
+    return;
+  }
+  const double bound = unl - G - E;
   if (!(bound > d1 * (double)T.s2 * (1.0 + 1e-12))) {   // cannot certify: exact brute force later, filed under the train image's group
     flagged[T.group_off + atomicAdd(&nf_group[T.group], 1)] = (int)o;
     atomicAdd(n_flagged, 1);
@@ -913,8 +966,19 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
   };
   u32 keymask;
   asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keymask));
-#ifdef MSFM_KNN_F16_FILTER
+#ifndef MSFM_KNN_F16_NOFILTER
+  // Round 5: one compare per candidate, against the query's SECOND smallest value so far plus twice the error bound (below).
+  // aU / bU: threshold bits from the lists of both lanes of a query (formed at the window flush), mA / mB: 2.05 E of the lane's
+  // two queries, rounded up.
   u32 aU = 0xffffffffu, bU = 0xffffffffu;
+  float mA, mB;
+  {
+    const double sh = (double)T.shift;
+    const double Ea = f16_error_bound((double)T.a2max_s, (double)T.remax_a, (double)T.qn2s[va ? qa : 0], (double)T.qre[va ? qa : 0], sh);
+    const double Eb = f16_error_bound((double)T.a2max_s, (double)T.remax_a, (double)T.qn2s[vb ? qb : 0], (double)T.qre[vb ? qb : 0], sh);
+    mA = __uint_as_float(__float_as_uint((float)(2.05 * Ea)) + 1u);
+    mB = __uint_as_float(__float_as_uint((float)(2.05 * Eb)) + 1u);
+  }
 #endif
   fetch(0);
   commit(0);
@@ -942,15 +1006,24 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
         accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqb[ks], accb, 0, 0, 0);
       }
       const int wbase = ((tile & 3) * 2 + st) * 32;
-#ifdef MSFM_KNN_F16_FILTER   // measured SLOWER here (670 against 694 Mmatches/s on 4 032 pairs: four keys per lane double the hit rate,
-                             // half of the slots still run their ten operations, and the masks cost 8 registers at two waves per SIMD;
-                             // with the bound shared by the two lanes of a query as in k_knn2_i8 - aU / bU below - 680 against 715)
-      // Round 4: one compare per candidate (see k_knn2_i8).  A value above the lane's fourth smallest - of the window (a3) and
-      // of the list over all rows so far (gva[3]) - cannot enter either list: its key is not formed.  The accumulator bits are
-      // compared raw against the threshold key with its index byte filled (conservative); the thresholds are taken once per
-      // 32-row step.  The lists, hence the certification bound "every unlisted row is >= the list's fourth key", are what the
-      // unconditional form gives.
-      const u32 ta = min(a3, aU) | 255u, tb = min(b3, bU) | 255u;   // (aU / bU: the fourth smallest key over the lists of BOTH lanes of the query, see the merge below)
+#ifndef MSFM_KNN_F16_NOFILTER
+      // Round 5: one compare per candidate.  With v2 the second smallest accumulator value a query has met - in this lane's
+      // current window (a1) or in the lists of both its lanes at the last flush (aU) - a row whose value exceeds
+      // v2 (1 + 2^-15) + 2 E has an exact distance above that of two other rows (every value is within E of the exact scaled
+      // distance, the key truncation costs 2^-15): it is not among the two nearest and no certificate needs it, so its key is
+      // not formed.  (Round 4 compared with the FOURTH smallest, the bound of the lists themselves: twice to four times the
+      // hit rate, measured slower than the unconditional chain.)  An empty window key is a NaN pattern: above every finite
+      // value as an unsigned integer, so everything passes.  All compares of a group of four register slots first (wave masks
+      // in scalar registers), then the ten selection operations for the slots with a hit in either query set.
+#if MSFM_KNN_F16_PROBE == 1     // (timing probes, wrong results: no candidate ever passes)
+      const u32 ta = 0u, tb = 0u;
+#else
+      const u32 ta = min(__float_as_uint(__builtin_fmaf(__uint_as_float(a1 | 255u), 1.0000306f, mA)), aU);
+      const u32 tb = min(__float_as_uint(__builtin_fmaf(__uint_as_float(b1 | 255u), 1.0000306f, mB)), bU);
+#endif
+#if MSFM_KNN_F16_PROBE == 2     // (no selection at all: the accumulators are consumed by two operations per step)
+      a0 = min(a0, __float_as_uint(acca[0]) ^ __float_as_uint(acca[15])); b0 = min(b0, __float_as_uint(accb[0]) ^ __float_as_uint(accb[15]));
+#else
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         unsigned long long hm[4];
@@ -970,6 +1043,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
           b3 = umed3(b2, b3, kb); b2 = umed3(b1, b2, kb); b1 = umed3(b0, b1, kb); b0 = min(b0, kb);
         }
       }
+#endif
 #else
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
@@ -989,26 +1063,17 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
       merge_window4(gvb, gib, b0, b1, b2, b3, base);
       a0 = a1 = a2 = a3 = 0xffffffffu;
       b0 = b1 = b2 = b3 = 0xffffffffu;
-#ifdef MSFM_KNN_F16_FILTER
-      // the fourth smallest key of the two sorted lists of a query together: min over i + j = 3 of max(x_i, y_j).  A row above it
-      // is neither among the query's two nearest nor needed by the certificate, whose bound for unlisted rows becomes this key
-      // (finish_query_f16) instead of the smaller of the two lists' fourth keys.
+#ifndef MSFM_KNN_F16_NOFILTER
+      // the second smallest key over the sorted lists of BOTH lanes of a query: min(max(x0, y0), min(x1, y1))
       {
-        u32 m[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(gva[3 - i], gva[3 - i], false, false);
-          const u32 other = h ? (u32)sw[0] : (u32)sw[1];
-          m[i] = max(gva[i], other);
-        }
-        aU = min(min(m[0], m[1]), min(m[2], m[3]));
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(gvb[3 - i], gvb[3 - i], false, false);
-          const u32 other = h ? (u32)sw[0] : (u32)sw[1];
-          m[i] = max(gvb[i], other);
-        }
-        bU = min(min(m[0], m[1]), min(m[2], m[3]));
+        const auto s0 = __builtin_amdgcn_permlane32_swap(gva[0], gva[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(gva[1], gva[1], false, false);
+        const u32 v2 = min(max((u32)s0[0], (u32)s0[1]), min((u32)s1[0], (u32)s1[1])) | 255u;
+        aU = __float_as_uint(__builtin_fmaf(__uint_as_float(v2), 1.0000306f, mA));
+        const auto t0 = __builtin_amdgcn_permlane32_swap(gvb[0], gvb[0], false, false);
+        const auto t1 = __builtin_amdgcn_permlane32_swap(gvb[1], gvb[1], false, false);
+        const u32 w2 = min(max((u32)t0[0], (u32)t0[1]), min((u32)t1[0], (u32)t1[1])) | 255u;
+        bU = __float_as_uint(__builtin_fmaf(__uint_as_float(w2), 1.0000306f, mB));
       }
 #endif
     }

@@ -307,6 +307,14 @@ def _check_pairs_against_oracle(ctx, oracle, descs, pairs, fast=True):
             assert np.array_equal(ids, ids_r) and np.array_equal(d, d_r) and np.array_equal(code, code_r), (p, i, j)
             assert (na[p], ng[p]) == (na_r, ng_r), (p, i, j)
             n_good += ng_r
+        # the codes-only form (what the reference's loop consumes; the float kernel then decides most codes from certified
+        # distance intervals without an exact evaluation): same codes, same counts
+        res0 = ds.match_pairs(pairs, 0.6, 0.85, keep_knn=False)
+        na0, ng0 = res0.counts()
+        assert np.array_equal(na0, na) and np.array_equal(ng0, ng)
+        for p in range(len(pairs)):
+            assert np.array_equal(res0.fetch(p)[0], res.fetch(p)[0]), p
+        res0.close()
         res.close()
         ds.close()
     finally:
@@ -358,6 +366,56 @@ def test_config3_float_pair_sample_matches_the_oracle(ctx, oracle):
     assert stats["queries"] == 24 * 4096
     assert 0 < stats["slow_path"] < 0.02 * stats["queries"]     # the slow path ran at this size, and stayed the exception
     assert n_good > 100
+
+
+def test_float_codes_without_knn_arrays_are_the_oracles(ctx, oracle):
+    """Codes-only matching of float descriptors (round 5: nearest index and both ratio outcomes from certified intervals, exact
+    evaluation only where an interval straddles a threshold): queries planted ON the two thresholds - second-nearest rows
+    constructed so that d0 / d1 lands within a few float ulps of 0.6 and 0.85 on either side -, exact duplicates (0 / d and
+    0 / 0), near ties for the nearest row, clustered rows, three magnitudes, thresholds in the other order, and the SLAM form
+    (`ratio > th` rejects, equality and NaN pass; slam_gps.cc:469-477)."""
+    rng = np.random.default_rng(77)
+    tr = (512.0 * (lambda x: x / np.linalg.norm(x, axis=1, keepdims=True))(rng.gamma(0.6, 1.0, (900, 128)))).astype(np.float32)
+    qs = []
+    for k, th in enumerate([0.6, 0.85] * 12):
+        # query = train row k displaced by u (nearest: row k at |u|^2); plant row 400 + k at distance^2 = |u|^2 / th (1 + eps)
+        u = rng.standard_normal(128); u *= 20.0 / np.linalg.norm(u)
+        w = rng.standard_normal(128); w -= w.dot(u) / u.dot(u) * u; w /= np.linalg.norm(w)
+        q = tr[k].astype(np.float64) + u
+        eps = (k // 2 - 6) * 3e-8
+        tr[400 + k] = (q + np.sqrt(400.0 / th * (1 + eps)) * w).astype(np.float32)
+        qs.append(q.astype(np.float32))
+    qu = np.concatenate([np.array(qs), tr[[5, 6]], (512.0 * (lambda x: x / np.linalg.norm(x, axis=1, keepdims=True))(rng.gamma(0.6, 1.0, (300, 128)))).astype(np.float32)])
+    tr[700] = tr[5]                                  # 0 / 0
+    tr[701] = tr[30] * np.float32(1 + 3e-7)          # near tie for the nearest row of a later query
+    qu[40] = tr[30]
+    cl = (tr[50] + rng.normal(0, 0.01, (40, 128))).astype(np.float32)   # a tight cluster: nothing certifies there
+    tr[800:840] = cl
+    qu[41:45] = cl[:4] + np.float32(0.003)
+    for scale in (1.0, 2.0 ** -12, 37.0):
+        d = [(tr * np.float32(scale)).astype(np.float32), (qu * np.float32(scale)).astype(np.float32)]
+        ds = ctx.descset(d)
+        pairs = np.array([[0, 1], [1, 0]], np.int32)
+        for rg, ra in ((0.6, 0.85), (0.99, 0.9)):
+            res = ds.match_pairs(pairs, rg, ra, keep_knn=False)
+            na, ng = res.counts()
+            for p, (i, j) in enumerate(pairs):
+                ids_r, d_r = oracle.knn2(d[i], d[j])
+                code_r, na_r, ng_r = oracle.ratio_codes(ids_r, d_r, rg, ra)
+                np.testing.assert_array_equal(res.fetch(p)[0], code_r)
+                assert (na[p], ng[p]) == (na_r, ng_r)
+            res.close()
+        # the SLAM form shares the kernel: compare with the keep_knn form, which evaluates every candidate exactly
+        kp = [rng.uniform(-100, 100, (len(x), 2)).astype(np.float32) for x in d]
+        for i in range(2):
+            ds.upload_keypoints(i, kp[i])
+        F = np.tile(np.zeros((3, 3)), (2, 1, 1)); H = np.tile(np.eye(3), (2, 1, 1))
+        a = ds.match_pairs_slam(pairs, F, H, keep_knn=True, th_epipolar=1e9, th_distance=1e9)
+        b = ds.match_pairs_slam(pairs, F, H, keep_knn=False, th_epipolar=1e9, th_distance=1e9)
+        for p in range(2):
+            np.testing.assert_array_equal(a.fetch(p)[0], b.fetch(p)[0])
+        np.testing.assert_array_equal(a.counts()[1], b.counts()[1])
+        a.close(); b.close(); ds.close()
 
 
 def _prior_F_H(sc, i, j):
