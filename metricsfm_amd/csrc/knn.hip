@@ -371,6 +371,8 @@ __global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict_
   u32 aTl = 0x7fffffffu, bTl = 0x7fffffffu;
   const int n_tiles = (T.n_train + TT - 1) / TT;
   // staging: 64 rows x 8 chunks of 16 B = 512 chunks, 2 per thread; chunk' = chunk ^ ((row >> 1) & 7)
+  // (Round 5 measured k_knn2_f16's fetch here too - global loads without a branch, padding decided at the commit: 1 791 -> 1 736
+  //  Mmatches/s on 4 032 pairs, ten registers spilled around the loop at 128: not kept.)
   uint4 stage[2];
   int stage_cin = 0, stage_c = 0;
   auto fetch = [&](int tile) {
@@ -788,15 +790,37 @@ __device__ __forceinline__ void merge_window4(u32 (&g)[4], int (&gb)[4], u32 w0,
 // the interval of the smallest value lies strictly below everybody else's lower bound, the nearest row is known; the second
 // nearest DISTANCE then lies between the smallest lower bound and the smallest upper bound of the others, the float ratio is
 // monotone in both distances (float conversion and float division are monotone), and if `ratio < th` comes out the same at
-// both ends of its interval it is the exact answer: the code is written without a single exact evaluation (97 % of the
-// queries on 512-norm SIFT-like data).  Otherwise - and whenever the 2-NN arrays are kept - the candidates are evaluated by
-// the oracle's definition as before: 32 scattered 16-byte loads per lane and candidate, which was a fifth of the kernel's time.
-__device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, int q, bool qvalid, int h, const u32 (&gk)[4], const int (&gbase)[4],
-                                                 float ratio_good, float ratio_all, int32_t* __restrict__ code, int* __restrict__ ids,
-                                                 float* __restrict__ sqd, int* __restrict__ n_all, int* __restrict__ n_good,
-                                                 int* __restrict__ flagged, int* __restrict__ nf_group, int* __restrict__ n_flagged) {
-  u32 gv[4], ov[4];
-  int gi[4], oi[4];
+// both ends of its interval it is the exact answer: the code is written without a single exact evaluation (94 % of the
+// queries on 512-norm SIFT-like data, scripts/knn_f16_stats.py; 0.13 exact evaluations per query instead of 2.1).  Otherwise -
+// and whenever the 2-NN arrays are kept - the candidates are evaluated by the oracle's definition as before.
+// (the exact evaluations of a wave are pooled: every lane files its candidates of both query sets in a work list in LDS, the
+// wave walks the list sixty-four entries at a time - one lane per (query, row), all lanes busy - and every lane then reads its
+// own results back.  Per-slot evaluation `if (eval_j) exact_sqdist(...)` made the whole wave wait through up to eight rounds of
+// 128 dependent binary64 operations whenever one lane had a candidate in that slot.)
+#ifdef MSFM_KNN_F16_STATS   // developer counters (scripts/knn_f16_stats.py): valid queries, queries decided from intervals, exact evaluations, list rounds
+__device__ unsigned long long g_f16_stats[4];
+extern "C" __attribute__((visibility("default"))) int msfm_dbg_f16_stats(unsigned long long* out, int reset) {
+  if (reset) { static unsigned long long z[4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_stats), z, sizeof z); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f16_stats), 4 * sizeof(unsigned long long));
+}
+#endif
+struct EpiQuery {
+  u32 gv[4];
+  int gi[4];
+  bool eval[4];
+  int pos[4];
+  double unl_bound;   // lower bound (scaled exact distance) of every row outside the two lists
+  bool certain;
+  float fa, fb;
+  int id1;
+};
+
+__device__ __forceinline__ void epi_prepare(const PairTaskH& T, int q, bool qvalid, const u32 (&gk)[4], const int (&gbase)[4], bool keep_knn,
+                                            float ratio_good, float ratio_all, EpiQuery& Q) {
+  u32 ov[4];
+  int oi[4];
+  u32 (&gv)[4] = Q.gv;
+  int (&gi)[4] = Q.gi;
 #pragma unroll
   for (int j = 0; j < 4; j++) {   // key -> (value bits, train row); an empty slot stays out of range
     gv[j] = gk[j] & 0xffffff00u;
@@ -829,6 +853,7 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
     if (k2 < 0x7f800000u) unl = fmin(unl, (double)__uint_as_float(k2) * (1.0 + 3.0517578125e-5) + 2.01 * E);
   }
 #endif
+  Q.unl_bound = unl - G - E;
   // scaled-distance interval of a listed row: [val - G - E, val (1 + 2^-15) - G + E]  (val = key with its low byte cleared)
   // the two smallest values over both lists (both lanes of a query see the same eight entries: every decision below that
   // both take is taken alike)
@@ -846,7 +871,7 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
   bool certain = false;
   float fa = 0.f, fb = 1.f;
 #ifndef MSFM_KNN_F16_NOFASTCODE
-  if (!ids && v2 < 0x7f800000u) {
+  if (!keep_knn && v2 < 0x7f800000u) {
     const double inv_s2 = 1.0 / (double)T.s2;   // a power of two: exact
     const double x1 = (double)__uint_as_float(v1), x2 = (double)__uint_as_float(v2);
     // (the 1e-12: the oracle's 128 binary64 fused steps stay within 1.5e-14 of the real-number distance that E bounds)
@@ -863,6 +888,7 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
     }
   }
 #endif
+  Q.certain = certain; Q.fa = fa; Q.fb = fb; Q.id1 = id1;
   double h1 = inf, h2 = inf;  // the two smallest upper bounds over both lists
 #pragma unroll
   for (int j = 0; j < 8; j++) {
@@ -873,17 +899,34 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
       if (hi < h1) { h2 = h1; h1 = hi; } else if (hi < h2) h2 = hi;
     }
   }
-  const float* qv = T.qf32 + (size_t)(qvalid ? q : 0) * DIM;
+  // the candidates that can still be among the two nearest: lower bound <= second smallest upper bound
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    Q.eval[j] = qvalid && !certain && gi[j] < T.n_train && ((double)__uint_as_float(gv[j]) - G - E) <= h2;
+}
+
+// files the candidates of one query set in the wave's work list (positions by ballot + prefix count: deterministic)
+__device__ __forceinline__ void epi_file(EpiQuery& Q, int q, int2* __restrict__ ent, int& n) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(Q.eval[j]);
+    const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+    if (Q.eval[j]) ent[pos] = make_int2(Q.gi[j], q);
+    Q.pos[j] = pos;
+    n += __builtin_popcountll(m);
+  }
+}
+
+__device__ __forceinline__ void epi_finish(const PairTaskH& T, int pair, int q, bool qvalid, int h, const EpiQuery& Q, const double* __restrict__ res,
+                                           float ratio_good, float ratio_all, int32_t* __restrict__ code, int* __restrict__ ids,
+                                           float* __restrict__ sqd, int* __restrict__ n_all, int* __restrict__ n_good,
+                                           int* __restrict__ flagged, int* __restrict__ nf_group, int* __restrict__ n_flagged) {
+  const double inf = __builtin_inf();
   double d0 = inf, d1 = inf;
   int i0 = 0x7fffffff, i1 = 0x7fffffff;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const bool eval = qvalid && !certain && gi[j] < T.n_train && ((double)__uint_as_float(gv[j]) - G - E) <= h2;
-    if (eval) {
-      const double s = exact_sqdist(T.tf32 + (size_t)gi[j] * DIM, qv);
-      merge_top2(d0, i0, d1, i1, s, gi[j], inf, 0x7fffffff);
-    }
-  }
+  for (int j = 0; j < 4; j++)
+    if (Q.eval[j]) merge_top2(d0, i0, d1, i1, res[Q.pos[j]], Q.gi[j], inf, 0x7fffffff);
   {
     const double e0 = __shfl_xor(d0, 32, 64), e1 = __shfl_xor(d1, 32, 64);
     const int j0 = __shfl_xor(i0, 32, 64), j1 = __shfl_xor(i1, 32, 64);
@@ -891,12 +934,11 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
   }
   if (h != 0 || !qvalid) return;
   const size_t o = (size_t)T.out_off + q;
-  if (certain) {
-    code[o] = ratio_code(fa, fb, id1, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
+  if (Q.certain) {
+    code[o] = ratio_code(Q.fa, Q.fb, Q.id1, ratio_good, ratio_all, &n_all[pair], &n_good[pair]);
     return;
   }
-  const double bound = unl - G - E;
-  if (!(bound > d1 * (double)T.s2 * (1.0 + 1e-12))) {   // cannot certify: exact brute force later, filed under the train image's group
+  if (!(Q.unl_bound > d1 * (double)T.s2 * (1.0 + 1e-12))) {   // cannot certify: exact brute force later, filed under the train image's group
     flagged[T.group_off + atomicAdd(&nf_group[T.group], 1)] = (int)o;
     atomicAdd(n_flagged, 1);
     return;
@@ -908,7 +950,10 @@ __device__ __forceinline__ void finish_query_f16(const PairTaskH& T, int pair, i
 
 // 1 workgroup = 4 waves = 256 queries of one pair (two query sets of 32 per wave, every A fragment feeds two MFMAs);
 // train tiles of 64 rows double-buffered through XOR-swizzled LDS, as the integer kernels.
-__global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
+#ifndef MSFM_KNN_F16_WGS
+#define MSFM_KNN_F16_WGS 2
+#endif
+__global__ __launch_bounds__(256, MSFM_KNN_F16_WGS) void k_knn2_f16(const PairTaskH* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
                                                       float ratio_good, float ratio_all, int32_t* __restrict__ code, int* __restrict__ ids,
                                                       float* __restrict__ sqd, int* __restrict__ n_all, int* __restrict__ n_good,
                                                       int* __restrict__ flagged, int* __restrict__ nf_group, int* __restrict__ n_flagged,
@@ -944,25 +989,31 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
   u32 gva[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, gvb[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   int gia[4] = {0, 0, 0, 0}, gib[4] = {0, 0, 0, 0};   // window bases of the list entries
   const int n_tiles = (T.n_train + TT - 1) / TT;
-  uint4 stage[4];
+  i32x4 stage[4];   // (a native vector type: a struct copy out of address space 1 becomes a memcpy that keeps the array in scratch)
   float stage_n = 0.f;
+  typedef const i32x4 __attribute__((address_space(1)))* g_u4p;
+  typedef const float __attribute__((address_space(1)))* g_f32p;
+  const g_u4p th_g = (g_u4p)(uintptr_t)T.th;
+  const g_f32p tn_g = (g_f32p)(uintptr_t)T.tn2s;
   auto fetch = [&](int tile) {
     const int t0 = tile * TT;
+    // Round 5: global (not flat) loads without a branch around them - a row past the end reads the last row instead (its
+    // norm below makes it lose every comparison whatever its operands) - and nothing computed from a loaded value here: the
+    // `+ shift` of the norms used to put an `s_waitcnt vmcnt(0)` into wave 0 at the top of every tile.
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      stage[i] = make_uint4(0, 0, 0, 0);
-      if (t0 + row < T.n_train) stage[i] = *reinterpret_cast<const uint4*>(T.th + (size_t)(t0 + row) * DIM + ch * 8);
+      stage[i] = th_g[(unsigned)min(t0 + row, T.n_train - 1) * (unsigned)(DIM / 8) + (unsigned)ch];   // (32-bit offsets: scalar base + vector offset)
     }
-    if (tid < TT) stage_n = (t0 + tid < T.n_train) ? T.tn2s[t0 + tid] + T.shift : 3.0e38f;  // padding rows lose every comparison
+    if (tid < TT) stage_n = tn_g[(unsigned)min(t0 + tid, T.n_train - 1)];
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, int tile) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      *reinterpret_cast<uint4*>(&lds_a[buf][row * 256 + ((ch ^ (row & 15)) << 4)]) = stage[i];
+      *reinterpret_cast<i32x4*>(&lds_a[buf][row * 256 + ((ch ^ (row & 15)) << 4)]) = stage[i];
     }
-    if (tid < TT) lds_n[buf][tid] = stage_n;
+    if (tid < TT) lds_n[buf][tid] = (tile * TT + tid < T.n_train) ? stage_n + T.shift : 3.0e38f;  // padding rows lose every comparison
   };
   u32 keymask;
   asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keymask));
@@ -981,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
   }
 #endif
   fetch(0);
-  commit(0);
+  commit(0, 0);
   __syncthreads();
   int cur = 0;
   for (int tile = 0; tile < n_tiles; tile++) {
@@ -998,12 +1049,18 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
       }
       accb = acca;
       const int row = st * 32 + r;
+      // all eight operand reads of the step first (the compiler used to issue them two at a time, each pair followed by a
+      // full `s_waitcnt lgkmcnt(0)` in front of its four MFMAs)
+      f16x8 af[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         const int ch = 2 * ks + h;
-        const f16x8 a = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(la + row * 256 + ((ch ^ (row & 15)) << 4)));
-        acca = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqa[ks], acca, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqb[ks], accb, 0, 0, 0);
+        af[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(la + row * 256 + ((ch ^ (row & 15)) << 4)));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ks++) {
+        acca = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bqa[ks], acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bqb[ks], accb, 0, 0, 0);
       }
       const int wbase = ((tile & 3) * 2 + st) * 32;
 #ifndef MSFM_KNN_F16_NOFILTER
@@ -1077,7 +1134,7 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
       }
 #endif
     }
-    if (tile + 1 < n_tiles) commit(cur ^ 1);
+    if (tile + 1 < n_tiles) commit(cur ^ 1, tile + 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -1086,8 +1143,50 @@ __global__ __launch_bounds__(256, 2) void k_knn2_f16(const PairTaskH* __restrict
     if (vb && h == 0) code[(size_t)T.out_off + qb] = (int)gvb[0] + gib[1];
     return;
   }
-  finish_query_f16(T, pair, qa, va, h, gva, gia, ratio_good, ratio_all, code, ids, sqd, n_all, n_good, flagged, nf_group, n_flagged);
-  finish_query_f16(T, pair, qb, vb, h, gvb, gib, ratio_good, ratio_all, code, ids, sqd, n_all, n_good, flagged, nf_group, n_flagged);
+  // Epilogue.  Every wave is past its last read of the train tiles (the loop ends with a barrier): their 32 KB become four
+  // wave-private work lists - 512 (train row, query row) entries and 512 results each (a lane files at most eight candidates).
+  EpiQuery A, B;
+  epi_prepare(T, qa, va, gva, gia, ids != nullptr, ratio_good, ratio_all, A);
+  epi_prepare(T, qb, vb, gvb, gib, ids != nullptr, ratio_good, ratio_all, B);
+  if (debug_mode == 2) {   // timing experiment: main loop + interval decisions only
+    if (va && h == 0) code[(size_t)T.out_off + qa] = A.id1 + (int)A.certain;
+    if (vb && h == 0) code[(size_t)T.out_off + qb] = B.id1 + (int)B.certain;
+    return;
+  }
+  int2* ent = reinterpret_cast<int2*>(&lds_a[0][0] + wave * 8192);
+  double* res = reinterpret_cast<double*>(&lds_a[0][0] + wave * 8192 + 4096);
+  int n_ent = 0;
+  epi_file(A, qa, ent, n_ent);
+  epi_file(B, qb, ent, n_ent);
+#ifdef MSFM_KNN_F16_STATS
+  {
+    const int nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(va && h == 0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(vb && h == 0));
+    const int nc = __builtin_popcountll(__builtin_amdgcn_ballot_w64(va && h == 0 && A.certain)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(vb && h == 0 && B.certain));
+    if (lane == 0) { atomicAdd(&g_f16_stats[0], (unsigned long long)nv); atomicAdd(&g_f16_stats[1], (unsigned long long)nc);
+                     atomicAdd(&g_f16_stats[2], (unsigned long long)n_ent); atomicAdd(&g_f16_stats[3], (unsigned long long)((n_ent + 63) / 64)); }
+  }
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int e = lane; e < (debug_mode == 3 ? 0 : n_ent); e += 64) {   // (3: timing experiment without the exact evaluations)
+    const int2 x = ent[e];
+    const float* pa = T.tf32 + (size_t)x.x * DIM;
+    const float* pb = T.qf32 + (size_t)x.y * DIM;
+    // The float32 rows are cold (the sweep read the f16 forms): touch the four 128-byte lines of both rows at once, so that the
+    // evaluation pays one miss latency instead of one per batch of its loads (29 k -> ~8 k cycles per round of the list).
+    {
+      float t0, t1, t2, t3, t4, t5, t6, t7;
+      asm volatile("global_load_dword %0, %8, off\n\tglobal_load_dword %1, %8, off offset:128\n\tglobal_load_dword %2, %8, off offset:256\n\t"
+                   "global_load_dword %3, %8, off offset:384\n\tglobal_load_dword %4, %9, off\n\tglobal_load_dword %5, %9, off offset:128\n\t"
+                   "global_load_dword %6, %9, off offset:256\n\tglobal_load_dword %7, %9, off offset:384\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(pa), "v"(pb) : "memory");
+    }
+    res[e] = exact_sqdist(pa, pb);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  epi_finish(T, pair, qa, va, h, A, res, ratio_good, ratio_all, code, ids, sqd, n_all, n_good, flagged, nf_group, n_flagged);
+  epi_finish(T, pair, qb, vb, h, B, res, ratio_good, ratio_all, code, ids, sqd, n_all, n_good, flagged, nf_group, n_flagged);
 }
 
 // Exact brute force for the queries the lists could not certify.  The f16 kernel files every such query under the group

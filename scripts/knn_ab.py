@@ -25,6 +25,9 @@ ctx.synchronize()
 best = 1e9
 for _ in range(5):
     t0 = time.perf_counter(); res.rerun(); ctx.synchronize(); best = min(best, time.perf_counter() - t0)
+if %d:
+    ctx.profile(True); ctx.profile_reset(); res.rerun(); ctx.synchronize()
+    print("   ", {k: round(v["total_ms"], 3) for k, v in ctx.profile_get().items()}); ctx.profile(False)
 na, ng = res.counts()
 crc = 0
 for p in range(0, len(pairs), 97):
@@ -32,11 +35,12 @@ for p in range(0, len(pairs), 97):
 print("%%-10s %%8.1f Mmatches/s  (%%.2f ms)  all %%d good %%d crc %%08x" %% (%r, 1e-6 * len(pairs) * 4096 / best, 1e3 * best, na.sum(), ng.sum(), crc))
 '''
 flt = 1 if os.environ.get("KNN_AB_FLOAT") else 0
+prof = 1 if os.environ.get("KNN_AB_PROFILE") else 0
 for v in sys.argv[1:]:
     env = dict(os.environ, PYTHONPATH=ROOT)
     if v != "default":
         env["MSFM_LIB"] = os.path.join(ROOT, "metricsfm_amd", "libmsfm_%s.so" % v)
     else:
         env.pop("MSFM_LIB", None)
-    out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, flt, v)], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", CHILD % (ROOT, flt, prof, v)], env=env, capture_output=True, text=True, timeout=600)
     print(out.stdout.strip() or out.stderr[-800:])
