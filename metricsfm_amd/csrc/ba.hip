@@ -3111,7 +3111,7 @@ static int create_structures_device(msfm_ctx* ctx, const msfm_ba_problem* P, msf
       const int rc = ctx->allreduce(ctx->allreduce_user, dadj.p, adjm.size(), MSFM_REDUCE_MAX, (void*)s);
       if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce hook failed: %d", rc);
       DTRY(hipMemcpyAsync(adjm.data(), dadj.p, sizeof(double) * adjm.size(), hipMemcpyDeviceToHost, s));
-      DTRY(hipStreamSynchronize(s));
+      MSFM_TRY(msfm_stream_wait_bounded(ctx, s, "the all-reduce of the camera graph"));   // (bounded: a peer that failed never joins)
       for (size_t k = 0; k < adjm.size(); k++) adjb[k] = adjm[k] != 0.0;
     }
   }
@@ -3358,7 +3358,7 @@ static int create_structures_host(msfm_ctx* ctx, const msfm_ba_problem* P, msfm_
         const int rc = ctx->allreduce(ctx->allreduce_user, dadj.p, adjm.size(), MSFM_REDUCE_MAX, (void*)s);
         if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce hook failed: %d", rc);
         HIP_TRY(ctx, hipMemcpyAsync(adjm.data(), dadj.p, sizeof(double) * adjm.size(), hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+        MSFM_TRY(msfm_stream_wait_bounded(ctx, s, "the all-reduce of the camera graph"));
         for (size_t k = 0; k < adjm.size(); k++) adjb[k] = adjm[k] != 0.0;
       }
       adjb8.assign(adjb.begin(), adjb.end());
@@ -3726,7 +3726,7 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
       if (rc != 0) return msfm_set_error(ctx, MSFM_E_DEVICE, "all-reduce hook failed: %d", rc);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ind.data(), dind.p, sizeof(double) * ind.size(), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    MSFM_TRY(msfm_stream_wait_bounded(ctx, s, "the all-reduce of the block structure"));
     std::vector<int> ur, uc;
     for (int r = 0; r < ncb; r++)
       for (int c = 0; c <= r; c++)

@@ -77,8 +77,10 @@ __device__ __forceinline__ void msfm_reproj(const double* __restrict__ pose, con
     }
   }
   p0 += pose[3]; p1 += pose[4]; p2 += pose[5];
+  // (with Jacobians: Ceres' Jet division, value part f.a * (1 / g.a); without: the functor's plain division - one rounding
+  //  apart, as in the reference's two evaluation modes)
   const double iz = 1.0 / p2;
-  const double xp = p0 * iz, yp = p1 * iz;
+  const double xp = J ? p0 * iz : p0 / p2, yp = J ? p1 * iz : p1 / p2;
   const double f = cam[0], l1 = cam[1], l2 = cam[2];
   const double r2 = xp * xp + yp * yp;
   const double dist = 1.0 + r2 * (l1 + l2 * r2);

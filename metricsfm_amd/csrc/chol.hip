@@ -11,6 +11,7 @@
 // into the same launch.  The back substitution L^T z = w runs block by block with explicitly
 // inverted diagonal blocks (k_trinv64_full) so each step is a mat-vec.
 #include "common.h"
+#include <atomic>
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
@@ -818,9 +819,28 @@ __device__ __forceinline__ bool chain_alive(const ChainJob& jb, int b, int l) { 
 __device__ __forceinline__ bool chain_is_pub(const ChainJob& jb, int b, int l) { return b == min(l == 0 ? 0 : (4 * l) / 3, jb.ncw - 1); }
 __device__ __forceinline__ bool count_ready(unsigned v, unsigned base, unsigned need) { const unsigned d = v - base; return d < 4096u && d >= need; }
 
+// The nine workgroup barriers of a row owner's step, by NAME.  Wave 0 (chain_pivot_step) and waves 1-3 (chain_helper_step) run
+// different programs between the same barriers; s_barrier only counts arrivals, so a one-sided edit would pair barrier k of one
+// program with barrier k + 1 of the other and LDS tiles would be read before they are written - a wrong factor, not an error.
+// Both programs therefore spell every barrier as CHAIN_BAR(name), and the build with -DMSFM_CHAIN_BARCHECK
+// (metricsfm_amd/libmsfm_barcheck.so, tests/test_gpu_ba.py::test_chain_barriers_pair_up) makes every wave log (step, name) in
+// front of the barrier and compare the four logs behind it: a mismatch raises MSFM_FAIL_SYNC (-> MSFM_E_DEVICE) with note 90.
+enum { CB_S1 = 1, CB_S2, CB_P0, CB_A1, CB_P1, CB_A2, CB_P2, CB_A3, CB_P3 };
+#ifdef MSFM_CHAIN_BARCHECK
+#define CHAIN_BAR(name) do { \
+    if ((threadIdx.x & 63) == 0) barlog[threadIdx.x >> 6] = (l << 8) | (name); \
+    __syncthreads(); \
+    { const int want_ = (l << 8) | (name); \
+      if (barlog[0] != want_ || barlog[1] != want_ || barlog[2] != want_ || barlog[3] != want_) { \
+        chain_note(ctl.dbg, 90, l, (unsigned)(name), (unsigned)barlog[0], barlog[1] ^ barlog[2] ^ barlog[3]); atomicOr(fail, MSFM_FAIL_SYNC); } } \
+    __syncthreads(); \
+  } while (0)
+#else
+#define CHAIN_BAR(name) __syncthreads()
+#endif
 template <bool FULL>
 __device__ __forceinline__ void chain_pivot_step(const ChainJob& jb, const ChainCtl& ctl, coh_buf cH, int l, int n, int* fail, double* Bs, double* Ls,
-                                                 double* dinv, double* dvec, const double* d00s) {
+                                                 double* dinv, double* dvec, const double* d00s, int* barlog) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const int t0 = jb.begin + NB * l;
@@ -835,28 +855,28 @@ __device__ __forceinline__ void chain_pivot_step(const ChainJob& jb, const Chain
     p0_store(Bs, tid, pv);
   }
   CSTAMP(2);
-  __syncthreads();   // S1: L[t, t-1] and the block's tile (0, 0) are in LDS
+  CHAIN_BAR(CB_S1);   // L[t, t-1] and the block's tile (0, 0) are in LDS
   d4 D0;
 #pragma unroll
   for (int i = 0; i < 4; i++) D0[i] = d00s[4 * lane + i];
   if (upd) D0 = mm_nt_neg<16>(Bs, 0, Bs, 0, 0, lr, lk, D0);
   tile_st(Ls, 0, 0, lr, lk, D0);
-  __syncthreads();   // S2
+  CHAIN_BAR(CB_S2);
   CSTAMP(3);
   potrf16_v2<0, FULL>(Ls, dinv, dvec, ncol, lane, fail);
-  __syncthreads();
-  __syncthreads();  // A1
+  CHAIN_BAR(CB_P0);
+  CHAIN_BAR(CB_A1);
   if (FULL || 16 < ncol) potrf16_v2<1, FULL>(Ls, dinv, dvec, ncol, lane, fail);
   else potrf16_skip<1>(dinv, lane);
-  __syncthreads();
-  __syncthreads();  // A2
+  CHAIN_BAR(CB_P1);
+  CHAIN_BAR(CB_A2);
   if (FULL || 32 < ncol) potrf16_v2<2, FULL>(Ls, dinv, dvec, ncol, lane, fail);
   else potrf16_skip<2>(dinv, lane);
-  __syncthreads();
-  __syncthreads();  // A3
+  CHAIN_BAR(CB_P2);
+  CHAIN_BAR(CB_A3);
   if (FULL || 48 < ncol) potrf16_v2<3, FULL>(Ls, dinv, dvec, ncol, lane, fail);
   else potrf16_skip<3>(dinv, lane);
-  __syncthreads();
+  CHAIN_BAR(CB_P3);
   CSTAMP(4);
   RSTAMP(1);
 }
@@ -923,7 +943,7 @@ template <bool FULL>
 __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_buf cM, coh_buf cH, int ld, const ChainJob& jb, const ChainCtl& ctl,
                                                   const ChainWave& W, int l, int n,
                                                   double* __restrict__ Dinv, double* __restrict__ Ldiag, int* fail, double* Bs, double* Ls, double* dinv,
-                                                  double* d00s, ChainCarry& C) {
+                                                  double* d00s, ChainCarry& C, int* barlog) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const int t0 = jb.begin + NB * l, at = W.at;
@@ -965,12 +985,12 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
     for (int i = 0; i < 4; i++) d00s[4 * lane + i] = D00[i];
   }
   CSTAMP_H(5);
-  __syncthreads();   // S1
+  CHAIN_BAR(CB_S1);   // S1
 #define MSFM_KC(s) (16 * ((s) >> 2) + 4 * lk + ((s) & 3))
   // ---- column 0 of the updated diagonal block: one 16x16 tile per wave ----
   if (upd) D0 = mm_nt_neg<16>(Bs, 16 * wave, Bs, 0, 0, lr, lk, D0);
   tile_st(Ls, wave, 0, lr, lk, D0);
-  __syncthreads();   // S2
+  CHAIN_BAR(CB_S2);   // S2
   d4 X[4];
   // ---- B0 ----
   fetch_ahead();
@@ -980,10 +1000,10 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
 #pragma unroll
     for (int s = 0; s < 16; s++) T[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Bs[plr * LDT + MSFM_KC(s)], C.xr[s], T[0], 0, 0, 0);
   }
-  __syncthreads();
+  CHAIN_BAR(CB_P0);
   // ---- A1 ----
   tile_st(Ls, ta, 1, lr, lk, mm_nt_neg<4>(Ls, 16 * ta, Ls, 16, 0, lr, lk, tile_ld(Ls, ta, 1, lr, lk)));
-  __syncthreads();
+  CHAIN_BAR(CB_A1);
   // ---- B1 ----
   fetch_ahead();
   if (upd) D2 = mm_nt_neg<16>(Bs, 16 * tb2, Bs, 16 * tc, 0, lr, lk, D2);
@@ -1003,10 +1023,10 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
     for (int s = 0; s < 4; s++) T[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(16 + plr) * LDT + 4 * lk + s], X[0][s], T[1], 0, 0, 0);
   }
   if (is_pub) publish_subpanel(Ls, dinv, pub_lo, pub_out, 0, tid - 64, 192);
-  __syncthreads();
+  CHAIN_BAR(CB_P1);
   // ---- A2 ----
   if (wave != 3) tile_st(Ls, tb2, 2, lr, lk, mm_nt_neg<4>(Ls, 16 * tb2, Ls, 32, 16, lr, lk, tile_ld(Ls, tb2, 2, lr, lk)));
-  __syncthreads();
+  CHAIN_BAR(CB_A2);
   // ---- B2 ----
   fetch_ahead();
   if (wave == 3) tile_st(Ls, 3, 3, lr, lk, mm_nt_neg<4>(Ls, 48, Ls, 48, 16, lr, lk, tile_ld(Ls, 3, 3, lr, lk)));
@@ -1026,10 +1046,10 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
       for (int s = 0; s < 4; s++) T[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(32 + plr) * LDT + 16 * i2 + 4 * lk + s], X[i2][s], T[2], 0, 0, 0);
   }
   if (is_pub) publish_subpanel(Ls, dinv, pub_lo, pub_out, 1, tid - 64, 192);
-  __syncthreads();
+  CHAIN_BAR(CB_P2);
   // ---- A3 ----
   if (wave == 3) tile_st(Ls, 3, 3, lr, lk, mm_nt_neg<4>(Ls, 48, Ls, 48, 32, lr, lk, tile_ld(Ls, 3, 3, lr, lk)));
-  __syncthreads();
+  CHAIN_BAR(CB_A3);
   // ---- B3 ----
   fetch_ahead();
   if (own) {
@@ -1048,7 +1068,7 @@ __device__ __forceinline__ void chain_helper_step(double* __restrict__ M, coh_bu
       for (int s = 0; s < 4; s++) T[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ls[(48 + plr) * LDT + 16 * i2 + 4 * lk + s], X[i2][s], T[3], 0, 0, 0);
   }
   if (is_pub) publish_subpanel(Ls, dinv, pub_lo, pub_out, 2, tid - 64, 192);
-  __syncthreads();   // S9
+  CHAIN_BAR(CB_P3);   // S9
   // ---- tail: X_3 = T_3 Dinv_3^T; the rows go out: to the hand-off buffer first when they are the rows of the next diagonal
   //      block (everybody's next step waits for them), then to M for the bulk tiles ----
   if (own) {
@@ -1326,6 +1346,8 @@ __global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, i
   __shared__ double sm[80 + 64 * DV + 2 * 64 * LDT];
   __shared__ double d00s[256];
   __shared__ int task[40];   // three ticket slots of 12 words, the 'next is ready' word, the three tickets
+  __shared__ int barlog_s[4];   // (MSFM_CHAIN_BARCHECK: what every wave says it is waiting at)
+  int* const barlog = barlog_s;
   double* As = sm + 80 + 64 * DV;
   double* Bs = As + 64 * LDT;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1343,8 +1365,8 @@ __global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, i
 #endif
     if (wave == 0) {
       for (int l = 0; chain_alive(jb, b, l); l++) {
-        if (n - (jb.begin + NB * l) >= NB) chain_pivot_step<true>(jb, ctl, cH, l, n, fail, Bs, As, sm + 80, sm, d00s);
-        else chain_pivot_step<false>(jb, ctl, cH, l, n, fail, Bs, As, sm + 80, sm, d00s);
+        if (n - (jb.begin + NB * l) >= NB) chain_pivot_step<true>(jb, ctl, cH, l, n, fail, Bs, As, sm + 80, sm, d00s, barlog);
+        else chain_pivot_step<false>(jb, ctl, cH, l, n, fail, Bs, As, sm + 80, sm, d00s, barlog);
       }
     } else {
       ChainWave W;
@@ -1356,8 +1378,8 @@ __global__ __launch_bounds__(256) void k_chain(double* __restrict__ M, int ld, i
       for (int i = 0; i < 16; i++) C.xr[i] = 0.0;
       C.have_next = false; C.polled = false; C.fd = C.fo = 0u; C.flag_step = 0;
       for (int l = 0; chain_alive(jb, b, l); l++) {
-        if (n - (jb.begin + NB * l) >= NB) chain_helper_step<true>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C);
-        else chain_helper_step<false>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C);
+        if (n - (jb.begin + NB * l) >= NB) chain_helper_step<true>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C, barlog);
+        else chain_helper_step<false>(M, cM, cH, ld, jb, ctl, W, l, n, Dinv, Ldiag, fail, Bs, As, sm + 80, d00s, C, barlog);
       }
       if (C.flag_step > 0) chain_release_rows(jb, ctl, W.at, C.flag_step, lane);
     }
@@ -1830,8 +1852,10 @@ static PanelJob make_job(int j0, int t0, int a0, int nA64, int b0, int nrows_b /
 
 // Workgroups of `kernel` (256 threads, static LDS only) that the device of `ctx` keeps resident at the same time: a kernel
 // whose workgroups wait for each other inside one launch is used only up to this many (asked once per device and kernel).
-// The waits themselves only ever go to workgroups with a LOWER blockIdx, so with every workgroup resident no dispatch order
-// can starve them; the polls are bounded besides.
+// k_backsolve_chain's waits only ever go to workgroups with a LOWER blockIdx, so with every workgroup resident no dispatch
+// order can starve them.  k_chain is different: its row owners (the first blocks of the grid) also wait for tiles that BULK
+// workgroups - higher blockIdx - publish, so it needs every row owner AND at least one bulk workgroup resident; that is what
+// the `fits` rule of chain_build leaves room for.  Every poll is bounded besides (MSFM_FAIL_SYNC -> MSFM_E_DEVICE).
 template <class K>
 static int resident_workgroups(msfm_ctx* ctx, K kernel, int threads) {
   int per_cu = 0, cus = 0;
@@ -2088,7 +2112,13 @@ static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
     // (a device shared with other contexts that launch the same kernel at the same time - ranks are synchronised by the
     //  reduction in front of the factorisation - must hold the row owners of all of them, or none makes progress)
     const int share = std::max(1, ctx->device_share);
-    const bool fits = share == 1 ? wg <= ws->capacity / 2 : (long)wg * share <= 3L * ws->capacity / 4;
+    // One context per device: the row owners may take just under half of the resident workgroups.  Two independent PROCESSES
+    // that share a GPU without MSFM_DEVICE_SHARE set each see share == 1; with exactly half each, their row owners together
+    // could fill the device and leave no bulk workgroup of either resident - both would spin to the poll limit.  Two short of
+    // half, one bulk workgroup of one of the two launches always finds a slot, that launch drains (whoever holds the lowest
+    // open ticket can finish), and the other follows.  (A quarter, as the round-4 review suggested, would send systems of more
+    // than ~170 blocks - config 5 in full - back to the launch chain for a case the bounded polls already turn into an error.)
+    const bool fits = share == 1 ? wg <= ws->capacity / 2 - 2 : (long)wg * share <= 3L * ws->capacity / 4;
     L.usable = J.count > 0 && fits && (max_step_tasks == 0 || 3 * room >= max_step_tasks || force) && maxp < 4000;
     ws->launch.push_back(L);
   }
@@ -2096,6 +2126,7 @@ static int chain_build(msfm_chol_ws* ws, int n, const msfm_chol_plan* plan) {
   HIP_TRY(ctx, hipMemcpyAsync(ws->tasks.p, table.data(), sizeof(ChainTask) * table.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (the host table goes away on return; built once per plan)
   ws->sig = sig;
+  ws->dirty = true;   // a new plan: hand-off blocks of the old layout must not be read as published values
   return MSFM_OK;
 }
 
@@ -2130,6 +2161,9 @@ static int chain_launch(msfm_chol_ws* ws, const ChainLaunch& L, double* M, int n
   c.cornerflag = ws->flags.p + 8 * nt16 + nb * nb;
   c.ldc = ldc; c.corner_b0 = L.corner_b0;
   c.dbg = ws->tickets.p + 8;
+#ifdef MSFM_CHAIN_BARCHECK
+  if (getenv("MSFM_CHAIN_TRACE")) fprintf(stderr, "k_chain: n %d, %d row owners, %d bulk workgroups, %d steps\n", n, L.jobs.n_row_wg, L.jobs.n_bulk_wg, L.steps);
+#endif
   hipLaunchKernelGGL(k_chain, dim3(L.jobs.n_row_wg + L.jobs.n_bulk_wg), dim3(256), 0, ctx->stream, M, npad, n, Dinv, Ldiag, fail, L.jobs, c);
   return MSFM_OK;
 }
@@ -2276,9 +2310,14 @@ int msfm_chol_factor_solve(msfm_ctx* ctx, double* M, int npad, int n, double* wo
     KTimer t(ctx, "chol_backsolve");
     const int nblk = cdiv(n, NB);
     static const bool launches_env = getenv("MSFM_BACKSOLVE_LAUNCHES") != nullptr;   // the round-2 chain of launches, for comparison
-    static int chain_max[64] = {0};   // per device: min(MSFM_BACKSOLVE_CHAIN_MAX, resident workgroups of k_backsolve_chain), 0 = not asked yet
-    int& cmax = chain_max[ctx->device & 63];
-    if (cmax == 0) cmax = std::max(1, std::min(MSFM_BACKSOLVE_CHAIN_MAX, resident_workgroups(ctx, k_backsolve_chain, 256)));
+    // per device: min(MSFM_BACKSOLVE_CHAIN_MAX, resident workgroups of k_backsolve_chain), 0 = not asked yet (atomic: the
+    // per-rank host threads of msfm_multi come through here at the same time; both would store the same value)
+    static std::atomic<int> chain_max[64];
+    int cmax = chain_max[ctx->device & 63].load(std::memory_order_relaxed);
+    if (cmax == 0) {
+      cmax = std::max(1, std::min(MSFM_BACKSOLVE_CHAIN_MAX, resident_workgroups(ctx, k_backsolve_chain, 256)));
+      chain_max[ctx->device & 63].store(cmax, std::memory_order_relaxed);
+    }
     const bool chain = !launches_env && nblk <= cmax;
     if (!chain) hipLaunchKernelGGL(k_trinv64_full, dim3(nblk + cdiv(npad, 256)), dim3(256), 0, s, Ldiag, n, Dinv, Linv, nblk, M, npad, w, npad,
                                    (unsigned long long*)nullptr);

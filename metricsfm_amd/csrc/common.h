@@ -89,6 +89,11 @@ struct KTimer {
 // Device memory comes from a per-process cache of freed blocks (ctx.hip): a bundle adjustment of the incremental loop
 // allocates ~60 buffers / > 1 GB, and a fresh VRAM allocation costs far more than the hipMalloc call itself (the first
 // kernels that touch it wait 10-20 ms at config 3).  Blocks are returned only after their stream has been synchronised.
+// Host wait for a stream that carries a collective: bounded (MSFM_SYNC_TIMEOUT_S, default 120 s) - a peer rank that never
+// joins must surface as MSFM_E_DEVICE, not as a host thread inside hipStreamSynchronize for good (ctx.hip).
+int msfm_stream_wait_bounded(msfm_ctx* ctx, hipStream_t s, const char* what);
+// Single-process multi-GPU (multi.hip): the communicator of this context was aborted (ncclCommAbort frees it) - forget it.
+void msfm_ctx_forget_rccl(msfm_ctx* ctx);
 hipError_t msfm_pool_alloc(void** p, size_t bytes, size_t* capacity);
 void msfm_pool_free(void* p, size_t capacity);
 void msfm_pool_trim(int device);

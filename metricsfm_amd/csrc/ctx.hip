@@ -211,7 +211,9 @@ MSFM_API int msfm_ctx_set_allreduce(msfm_ctx* ctx, msfm_allreduce_fn fn, void* u
 // ---- native RCCL collective ------------------------------------------------------------
 // rccl.h is not included on purpose (the library must build and load where RCCL is absent); the few types used are declared
 // in rccl_iface.h and checked against the real header by a compile-time test.
+#include <chrono>
 #include <dlfcn.h>
+#include <thread>
 #include "rccl_iface.h"
 namespace {
 using RcclId = msfm_rccl::UniqueId;
@@ -286,6 +288,30 @@ int msfm_ctx_adopt_rccl(msfm_ctx* ctx, void* lib, void* comm, int rank, int worl
   if (!ctx->rccl_allreduce || !ctx->rccl_comm_destroy) return msfm_set_error(ctx, MSFM_E_DEVICE, "librccl lacks an entry point");
   ctx->rccl_comm = comm;
   return msfm_ctx_set_allreduce(ctx, rccl_hook, ctx, rank, world);
+}
+
+void msfm_ctx_forget_rccl(msfm_ctx* ctx) {
+  if (!ctx) return;
+  ctx->rccl_comm = nullptr;
+  ctx->allreduce = nullptr;
+  ctx->allreduce_user = nullptr;
+}
+
+int msfm_stream_wait_bounded(msfm_ctx* ctx, hipStream_t s, const char* what) {
+  static const double limit_s = [] { const char* e = getenv("MSFM_SYNC_TIMEOUT_S"); const double v = e ? atof(e) : 120.0; return v > 0 ? v : 120.0; }();
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long polls = 0;
+  for (;;) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return MSFM_OK;
+    if (q != hipErrorNotReady) HIP_TRY(ctx, q);
+    if ((++polls & 0xfful) == 0) {
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (dt > limit_s)
+        return msfm_set_error(ctx, MSFM_E_DEVICE, "%s did not complete within %.0f s (MSFM_SYNC_TIMEOUT_S): a peer rank may have left", what, limit_s);
+      if (dt > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(200));   // a short wait spins, a long one does not burn a core
+    }
+  }
 }
 
 MSFM_API int msfm_ctx_allreduce(msfm_ctx* ctx, double* buf_dev, size_t count, int op) {

@@ -12,6 +12,7 @@
 // Splits: points (with their observations) for the bundle adjustment, tracks for triangulation / reprojection, the idx1-major
 // pair list for matching - the partitions of metricsfm_amd/shard.py, restated.
 #include "common.h"
+#include <atomic>
 #include <condition_variable>
 #include <dlfcn.h>
 #include <memory>
@@ -64,6 +65,13 @@ struct msfm_multi {
   struct Hook { msfm_multi* mc; int rank; };
   std::vector<Hook> hooks;
   void* rccl_lib = nullptr;
+  // distinct devices: the communicators (owned by the contexts) and ncclCommAbort.  A rank that fails while its peers are inside
+  // ncclAllReduce - or behind it in a stream wait - would leave them there: the first failing rank aborts EVERY communicator
+  // (the collective kernels of the peers end, their bounded waits see an error), the multi context is then broken for good.
+  std::vector<void*> comms;
+  msfm_rccl::comm_abort_t comm_abort = nullptr;
+  std::mutex abort_m;
+  bool broken = false;
   std::string err;
 };
 
@@ -97,9 +105,26 @@ int fail(msfm_multi* mc, int code, const std::string& what) {
   return code;
 }
 
-// fn(rank) on one host thread per context; the first error wins, the other ranks are released from their barriers
+void abort_comms(msfm_multi* mc) {
+  std::lock_guard<std::mutex> lk(mc->abort_m);
+  if (mc->broken || mc->comms.empty()) return;
+  mc->broken = true;
+  for (void* c : mc->comms)
+    if (c && mc->comm_abort) (void)mc->comm_abort(c);
+}
+
+// (test hook) MSFM_MULTI_FAIL_RANK=r: rank r of the next collective-bearing call returns an error before it joins anything
+int injected_failure(msfm_multi* mc, int r) {
+  const char* e = getenv("MSFM_MULTI_FAIL_RANK");
+  if (!e || atoi(e) != r) return MSFM_OK;
+  return msfm_set_error(mc->ctx[r], MSFM_E_INVAL, "injected failure (MSFM_MULTI_FAIL_RANK)");
+}
+
+// fn(rank) on one host thread per context; the first error wins, the other ranks are released from their barriers (shared
+// device) or from their collectives (communicators aborted)
 template <class F>
-int on_all_ranks(msfm_multi* mc, F&& fn) {
+int on_all_ranks(msfm_multi* mc, F&& fn, bool collective = false) {
+  if (mc->broken) return fail(mc, MSFM_E_DEVICE, "the communicators of this multi context were aborted after a rank failed; create a new one");
   {
     std::lock_guard<std::mutex> lk(mc->local.m);
     mc->local.aborted = false;
@@ -107,15 +132,23 @@ int on_all_ranks(msfm_multi* mc, F&& fn) {
   }
   std::vector<int> rc(mc->n, MSFM_OK);
   std::vector<std::thread> th;
+  std::atomic<int> first_failed{-1};   // the rank whose error came FIRST is the cause; the ranks it released fail after it
   for (int r = 0; r < mc->n; r++)
     th.emplace_back([&, r] {
       (void)hipSetDevice(mc->device[r]);
       rc[r] = fn(r);
-      if (rc[r] != MSFM_OK) give_up(mc->local);
+      if (rc[r] != MSFM_OK) {
+        int none = -1;
+        first_failed.compare_exchange_strong(none, r);
+        give_up(mc->local);
+        if (collective && !mc->shared && mc->n > 1) abort_comms(mc);   // (calls without a collective leave the communicators alone)
+      }
     });
   for (auto& t : th) t.join();
-  for (int r = 0; r < mc->n; r++)
-    if (rc[r] != MSFM_OK) return fail(mc, rc[r], "rank " + std::to_string(r) + ": " + msfm_last_error(mc->ctx[r]));
+  if (mc->broken)   // ncclCommAbort has freed the communicators: the contexts must not destroy them again
+    for (msfm_ctx* c : mc->ctx) msfm_ctx_forget_rccl(c);
+  const int r = first_failed.load();
+  if (r >= 0) return fail(mc, rc[r], "rank " + std::to_string(r) + ": " + msfm_last_error(mc->ctx[r]));
   return MSFM_OK;
 }
 
@@ -169,12 +202,20 @@ MSFM_API int msfm_ctx_create_multi(int n_gpus, const int* devices, msfm_multi** 
     }
     auto init_all = mc->rccl_lib ? reinterpret_cast<msfm_rccl::comm_init_all_t>(dlsym(mc->rccl_lib, "ncclCommInitAll")) : nullptr;
     if (!init_all) { cleanup(); return MSFM_E_DEVICE; }
+    auto comm_destroy = reinterpret_cast<msfm_rccl::comm_destroy_t>(dlsym(mc->rccl_lib, "ncclCommDestroy"));
+    mc->comm_abort = reinterpret_cast<msfm_rccl::comm_abort_t>(dlsym(mc->rccl_lib, "ncclCommAbort"));
+    if (!comm_destroy || !mc->comm_abort) { cleanup(); return MSFM_E_DEVICE; }
     std::vector<void*> comms(n_gpus, nullptr);
     if (init_all(comms.data(), n_gpus, mc->device.data()) != msfm_rccl::SUCCESS) { cleanup(); return MSFM_E_DEVICE; }
     for (int r = 0; r < n_gpus; r++) {
       const int rc = msfm_ctx_adopt_rccl(mc->ctx[r], mc->rccl_lib, comms[r], r, n_gpus);   // the context owns (and destroys) its communicator
-      if (rc != MSFM_OK) { cleanup(); return rc; }
+      if (rc != MSFM_OK) {
+        for (int q = r; q < n_gpus; q++) (void)comm_destroy(comms[q]);   // the ones no context has taken over
+        cleanup();
+        return rc;
+      }
     }
+    mc->comms = comms;
   }
   *out = mc.release();
   return MSFM_OK;
@@ -252,8 +293,9 @@ MSFM_API int msfm_multi_ba_solve(msfm_multi* mc, msfm_ba_problem* P, const msfm_
       sm->iterations = summary->iterations ? its[r].data() : nullptr;
       sm->iterations_capacity = summary->iterations ? summary->iterations_capacity : 0;
     }
+    MSFM_TRY(injected_failure(mc, r));
     return msfm_ba_solve(mc->ctx[r], &S, opt, sm);
-  });
+  }, true);
   return rc;
 }
 

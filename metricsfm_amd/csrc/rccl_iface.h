@@ -17,6 +17,7 @@ typedef int (*comm_init_rank_t)(void** comm, int nranks, UniqueId id, int rank);
 typedef int (*comm_init_all_t)(void** comms, int ndev, const int* devlist);
 typedef int (*all_reduce_t)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, Stream stream);
 typedef int (*comm_destroy_t)(void* comm);
+typedef int (*comm_abort_t)(void* comm);
 typedef int (*group_start_t)();
 typedef int (*group_end_t)();
 typedef const char* (*error_string_t)(int);

@@ -258,8 +258,12 @@ ORC_API void orc_reproj_analytic(const double* pose, const double* cam, const do
     R[6] = -aa[1]; R[7] = aa[0]; R[8] = 1;
   }
   p[0] += pose[3]; p[1] += pose[4]; p[2] += pose[5];
+  // Ceres evaluates a residual block with Jets when Jacobians are asked for and with plain doubles otherwise
+  // (AutoDiffCostFunction::Evaluate).  The functor's `p[0] / p[2]` (reprojection_error_pose_cam_xyz.h:52-53) is then
+  // Jet / Jet, whose value part jet.h forms as f.a * (1.0 / g.a) (Ceres 1.13 jet.h, operator/ - the Dual<N> above does the
+  // same), or a true division: the linearisation pass and the trial-cost pass differ in that one rounding, and so do we.
   const double iz = 1.0 / p[2];
-  const double xp = p[0] * iz, yp = p[1] * iz;
+  const double xp = J ? p[0] * iz : p[0] / p[2], yp = J ? p[1] * iz : p[1] / p[2];
   const double f = cam[0], l1 = cam[1], l2 = cam[2];
   const double r2 = xp * xp + yp * yp;
   const double dist = 1.0 + r2 * (l1 + l2 * r2);

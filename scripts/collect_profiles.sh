@@ -16,9 +16,9 @@ echo "pmc write done"
 cd $R
 python3 scripts/pmc_to_json.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc > $O/pmc_summary.txt 2>&1 || echo "pmc post-processing failed"
 # the bench line comes after the counters so that it can attach them (same kernel sources: the hash inside matches)
-# matrix-pipe utilisation of the three MFMA kernels (SQ counter passes; writes gpurun_out/mfma/r04_mfma_util.json)
+# matrix-pipe utilisation of the three MFMA kernels (SQ counter passes; writes gpurun_out/mfma/r05_mfma_util.json)
 bash scripts/mfma_util.sh > $O/mfma_util.log 2>&1 || echo "mfma_util failed"
-cp gpurun_out/mfma/r04_mfma_util.json profiles/r04_mfma_util.json || true
+cp gpurun_out/mfma/r05_mfma_util.json profiles/r05_mfma_util.json || true
 echo "mfma util done"
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
 python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err

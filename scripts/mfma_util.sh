@@ -1,6 +1,6 @@
 #!/bin/bash
 # Matrix-pipe / vector-pipe utilisation of the three MFMA kernels (k_knn2_i8, k_knn2_f16, k_panel_v2) from the SQ counters:
-#   gpurun --timeout 900 -- 'bash scripts/mfma_util.sh'      then copy gpurun_out/mfma/r04_mfma_util.json into profiles/
+#   gpurun --timeout 900 -- 'bash scripts/mfma_util.sh'      then copy gpurun_out/mfma/r05_mfma_util.json into profiles/
 # One rocprofv3 --pmc pass per counter group and workload (counters only: no --kernel-trace / --stats beside --pmc), the
 # program directly after `--`.  Summarised by scripts/mfma_util_to_json.py.
 set -o pipefail
@@ -21,4 +21,4 @@ run knn_i8 python3 $R/scripts/knn_only.py 48
 run knn_f16 python3 $R/scripts/knn_float_only.py
 run ba python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-matching --no-extras
 cd $R
-python3 scripts/mfma_util_to_json.py $O $O/r04_mfma_util.json
+python3 scripts/mfma_util_to_json.py $O $O/r05_mfma_util.json

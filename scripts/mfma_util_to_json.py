@@ -1,4 +1,4 @@
-"""Summarises the SQ counter passes of scripts/mfma_util.sh into profiles/r04_mfma_util.json.
+"""Summarises the SQ counter passes of scripts/mfma_util.sh into profiles/r05_mfma_util.json.
 
 Per kernel (mean over its launches in each pass):
   cycles          = GRBM_GUI_ACTIVE / 8           (rocprofv3 sums the 8 XCDs; MI355X_MICROARCH.md "DVFS give-back")

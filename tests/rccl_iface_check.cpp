@@ -35,6 +35,7 @@ static_assert(abi_match<decltype(&ncclCommInitRank), msfm_rccl::comm_init_rank_t
 static_assert(abi_match<decltype(&ncclCommInitAll), msfm_rccl::comm_init_all_t>::value, "ncclCommInitAll");
 static_assert(abi_match<decltype(&ncclAllReduce), msfm_rccl::all_reduce_t>::value, "ncclAllReduce");
 static_assert(abi_match<decltype(&ncclCommDestroy), msfm_rccl::comm_destroy_t>::value, "ncclCommDestroy");
+static_assert(abi_match<decltype(&ncclCommAbort), msfm_rccl::comm_abort_t>::value, "ncclCommAbort");
 static_assert(abi_match<decltype(&ncclGroupStart), msfm_rccl::group_start_t>::value, "ncclGroupStart");
 static_assert(abi_match<decltype(&ncclGroupEnd), msfm_rccl::group_end_t>::value, "ncclGroupEnd");
 static_assert(abi_match<decltype(&ncclGetErrorString), msfm_rccl::error_string_t>::value, "ncclGetErrorString");

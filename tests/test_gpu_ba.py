@@ -389,6 +389,53 @@ def test_ba_partial_window_with_gps(ctx, oracle):
     assert r["num_reduced_params"] == 6 * 24 + 3
 
 
+_C5 = {}
+
+
+def _config5_window_scene():
+    """BASELINE config 5 at full size, the newest camera straight from EPnP (built once per session: 6 M observations)."""
+    if "sc" not in _C5:
+        sc = scene.config_scene(5, n_models=2000, rot_sigma=2e-4, trans_sigma=0.01, point_sigma=0.02)
+        scene.perturb_camera(sc, sc.n_cams - 1)
+        _C5["sc"] = sc
+    return _C5["sc"]
+
+
+def test_ba_config5_window_full_size_oracle_parity(ctx, oracle):
+    """BASELINE config 5 AT ITS OWN SIZE against the oracle (round 5; the test below holds the size-independent properties):
+    the partial bundle adjustment of the newest of 2000 aerial cameras over 1 M points / 6 M observations with GPS rows
+    (sfm_incremental.cc:917-1014 + slam_gps.cc:818-830).  The compact hand-over is exactly the residual blocks the reference's
+    loop adds (optimizer.cc:86-125) - 23 free cameras, ~20 k free points - which the CPU oracle solves in seconds: same accept /
+    reject sequence and termination within 20 LM iterations, costs to 1e-9, parameters to 1e-7.  The FULL hand-over (all 6 M rows; the library drops
+    the frozen x frozen ones itself) must then give the compact one's trajectory on the GPU."""
+    from metricsfm_amd import capi, window
+    sc = _config5_window_scene()
+    assert (sc.n_cams, sc.n_points, sc.n_obs) == (2000, 1000000, 6000000)
+    idx = sc.n_cams - 1
+    made = {}
+
+    def make():
+        arr, info = window.partial_bundle_adjustment_problem(sc, idx, gps=True, compact=True)
+        made["info"] = info
+        return arr
+    opts = dict(max_num_iterations=20, num_threads=oracle.host_cores())
+    r, r_ref, comp = check_parity(ctx, oracle, make, opts)
+    ci = made["info"]
+    n_win = int(ci["cam_mutable"].sum())
+    assert 5 < n_win < 200 and r["num_reduced_params"] == 9 * n_win and r["num_iterations"] >= 5 and r["num_successful_steps"] >= 5
+    assert len(comp.obs_cam) < sc.n_obs // 10 and len(ci["kept"]) < sc.n_points // 10
+    # the full hand-over on the GPU: same residual blocks, same trajectory (point blocks numbered differently: rounding only)
+    full, fi = window.partial_bundle_adjustment_problem(sc, idx, gps=True)
+    assert len(full.obs_cam) == sc.n_obs
+    rf = ctx.ba_solve(full, capi.default_options(**{k: v for k, v in opts.items() if k != "num_threads"}))
+    assert rf["num_residuals"] == r["num_residuals"] and rf["num_reduced_params"] == r["num_reduced_params"]
+    np.testing.assert_array_equal(rf["iterations"]["step_is_successful"], r["iterations"]["step_is_successful"])
+    np.testing.assert_allclose(rf["iterations"]["cost"], r["iterations"]["cost"], rtol=1e-10)
+    np.testing.assert_allclose(full.cam_pose, comp.cam_pose, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(full.cam_model, comp.cam_model, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(full.point[ci["kept"]], comp.point, rtol=0, atol=1e-8)
+
+
 def test_ba_config5_window_full_size(ctx):
     """BASELINE config 5 at full size (2000 aerial cameras / 1M points / 6M observations, GPS rows, one CameraModel per
     camera as with use_same_camera = false): the partial bundle adjustment of the newest camera.  Too large for the CPU
@@ -396,10 +443,9 @@ def test_ba_config5_window_full_size(ctx):
     monotone over accepted steps, every frozen block bit-untouched, and the free part converges to the noise floor."""
     from metricsfm_amd import capi, window
     # the model is in its adjusted state (pixel-level residual error left), the newest camera comes straight from EPnP
-    sc = scene.config_scene(5, n_models=2000, rot_sigma=2e-4, trans_sigma=0.01, point_sigma=0.02)
+    sc = _config5_window_scene()
     assert (sc.n_cams, sc.n_points, sc.n_obs) == (2000, 1000000, 6000000)
     idx = sc.n_cams - 1
-    scene.perturb_camera(sc, idx)
     arr, info = window.partial_bundle_adjustment_problem(sc, idx, gps=True)
     cm, pm, vis = info["cam_mutable"], info["pt_mutable"], info["visible"]
     assert vis[0] == idx and 5 < len(vis) < 200 and int(cm.sum()) == len(vis)
@@ -550,6 +596,39 @@ def test_ba_persistent_panel_chain_is_bit_identical_to_the_launch_chain(ctx, mon
     np.testing.assert_array_equal(res["launches"][1], res["chain"][1])
     for x, y in zip(res["launches"][2], res["chain"][2]):
         np.testing.assert_array_equal(x, y)
+
+
+def test_chain_barriers_pair_up():
+    """A row-owner workgroup of k_chain runs two programs - the pivot wave and three helper waves - between the SAME nine
+    barriers per 64-column step (chol.hip: CHAIN_BAR(name)).  libmsfm_barcheck.so is the library with every one of those barriers
+    logged per wave and compared behind the barrier (a mismatch -> MSFM_E_DEVICE).  Sweep of system sizes with the chain forced
+    (MSFM_CHAIN_FORCE=1): ragged last blocks with 1 .. 63 real columns, one to fifteen blocks, dense order and one bisection -
+    every solve must pass the check AND be bit-identical to one launch per panel (MSFM_CHOL_LAUNCHES=1)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "metricsfm_amd", "libmsfm_barcheck.so")
+    assert os.path.exists(lib), "libmsfm_barcheck.so not built (run __graft_entry__.build())"
+    code = ("import os, sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from metricsfm_amd import _abi as A, capi, scene\n"
+            "ctx = capi.Context(0)\n"
+            "for n_cams, dom in ((21, '0'), (22, '0'), (32, '0'), (43, '0'), (64, '0'), (75, '0'), (107, '0'), (150, '0'), (150, '1')):\n"
+            "    os.environ['MSFM_CHOL_DOMAINS'] = dom\n"
+            "    sc = scene.make_aerial_scene(n_cams, 30 * n_cams, seed=100 + n_cams)\n"
+            "    out = []\n"
+            "    for launches in (True, False):\n"
+            "        if launches: os.environ['MSFM_CHOL_LAUNCHES'] = '1'\n"
+            "        else: os.environ.pop('MSFM_CHOL_LAUNCHES', None)\n"
+            "        a = A.BaArrays.from_scene(sc)\n"
+            "        r = ctx.ba_solve(a, capi.default_options(max_num_iterations=4))\n"
+            "        out.append((r['iterations']['cost'].copy(), a.cam_pose.copy(), a.point.copy()))\n"
+            "    for x, y in zip(out[0], out[1]): assert np.array_equal(x, y), n_cams\n"
+            "print('ok')\n") % ROOT
+    env = dict(os.environ, MSFM_LIB=lib, MSFM_CHAIN_FORCE="1", MSFM_CHAIN_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    traced = [l for l in r.stderr.splitlines() if l.startswith("k_chain:")]
+    sizes = sorted({int(l.split()[2].rstrip(",")) for l in traced})
+    assert len(traced) >= 9 * 4 and len(sizes) >= 8, (len(traced), sizes)   # the persistent launch really ran at every size
 
 
 def test_ba_device_side_verdict_and_launch_ahead_are_bit_identical_to_the_host_order(ctx, monkeypatch):

@@ -124,3 +124,28 @@ def test_test_sfm_driver_with_several_contexts_in_one_process():
         assert got[5] == ref[5]                         # the same number of LM iterations
         for a, b in zip(got[:5], ref[:5]):
             assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), (n, got, ref)
+
+
+def test_test_sfm_driver_on_distinct_gpus():
+    """`host/test_sfm --gpus N` WITHOUT --share-device: one context per GPU, ncclCommInitAll between them (skipped on a one-GPU
+    box).  Same bars as the shared-device run above."""
+    import re
+    import torch
+    n = min(torch.cuda.device_count(), 4)
+    if n < 2:
+        pytest.skip("needs 2 GPUs")
+    exe = os.path.join(ROOT, "host", "test_sfm")
+
+    def run(args):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "test_sfm ok" in out.stdout, out.stdout + out.stderr
+        lines = out.stdout.splitlines()
+        final = [float(x) for x in next(l for l in lines if l.startswith("ba_final")).split()[1:]]
+        stages = [l for l in lines if re.match(r"(matching|verification|tracks|triangulation|seed pair|localisation):", l)]
+        return final, stages
+
+    ref, stages_ref = run([])
+    got, stages = run(["--gpus", str(n)])
+    assert stages == stages_ref and got[5] == ref[5]
+    for a, b in zip(got[:5], ref[:5]):
+        assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), (got, ref)

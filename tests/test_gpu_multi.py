@@ -81,3 +81,108 @@ def test_multi_refuses_mixed_device_lists():
     with pytest.raises(capi.MsfmError) as e:
         capi.MultiContext(3, devices=[0, 0, 1])
     assert e.value.code == A.MSFM_E_INVAL
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+
+
+def test_a_failing_rank_releases_its_peers(ctx, monkeypatch):
+    """A rank that returns early (here: an injected failure in front of msfm_ba_solve, MSFM_MULTI_FAIL_RANK) must not leave
+    its peers waiting for it: on a shared device the host barriers of the in-process reduction are released (give_up); the
+    call returns the failing rank's error instead of hanging, and the multi context works again afterwards."""
+    import time
+    sc = scene.make_aerial_scene(40, 2000, seed=9)
+    mc = capi.MultiContext(3, devices=[0, 0, 0])
+    monkeypatch.setenv("MSFM_MULTI_FAIL_RANK", "1")
+    t0 = time.time()
+    with pytest.raises(capi.MsfmError) as e:
+        mc.ba_solve(A.BaArrays.from_scene(sc), capi.default_options(max_num_iterations=4))
+    assert time.time() - t0 < 60 and "rank 1" in str(e.value) and "injected" in str(e.value)
+    monkeypatch.delenv("MSFM_MULTI_FAIL_RANK")
+    a1, an = A.BaArrays.from_scene(sc), A.BaArrays.from_scene(sc)
+    r1 = ctx.ba_solve(a1, capi.default_options(max_num_iterations=4))
+    rn = mc.ba_solve(an, capi.default_options(max_num_iterations=4))
+    np.testing.assert_allclose(rn["iterations"]["cost"], r1["iterations"]["cost"], rtol=1e-9)
+    mc.close()
+
+
+# ---- real RCCL (ncclCommInitAll over xGMI): needs at least two GPUs; skipped on the one-GPU test box -------------------------
+# (round 5: first contact with RCCL at more than one rank is a test, not bench.py --gpus 8)
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_multi_rccl_ba_solve_on_distinct_devices(n):
+    """msfm_ctx_create_multi with DISTINCT devices: one communicator per device from ncclCommInitAll, every rank's LM loop in its
+    own host thread calling ncclAllReduce on its own stream.  Same scene and bars as the shared-device test above."""
+    if _n_devices() < n:
+        pytest.skip("needs %d GPUs" % n)
+    sc = scene.make_aerial_scene(168, 6000, seed=5, gps_sigma=0.5)
+    cm = np.ones(sc.n_cams, np.uint8); cm[::7] = 0
+    pm = np.ones(sc.n_points, np.uint8); pm[::11] = 0
+    kw = dict(gps_xyz=sc.gps_xyz, gps_weight=float(sc.n_obs // sc.n_cams), cam_mutable=cm, pt_mutable=pm)
+    opts = capi.default_options(max_num_iterations=10)
+    c0 = capi.Context(0)
+    a1 = A.BaArrays.from_scene(sc, **kw)
+    r1 = c0.ba_solve(a1, opts)
+    mc = capi.MultiContext(n, devices=list(range(n)))
+    an = A.BaArrays.from_scene(sc, **kw)
+    rn = mc.ba_solve(an, opts)
+    assert rn["num_iterations"] == r1["num_iterations"] >= 5
+    np.testing.assert_array_equal(rn["iterations"]["step_is_successful"], r1["iterations"]["step_is_successful"])
+    np.testing.assert_allclose(rn["iterations"]["cost"], r1["iterations"]["cost"], rtol=1e-8)
+    for name in ("cam_pose", "cam_model", "point"):
+        assert _rel(getattr(an, name), getattr(a1, name)) < 1e-7, name
+    an2 = A.BaArrays.from_scene(sc, **kw)
+    rn2 = mc.ba_solve(an2, opts)     # RCCL's ring order is fixed for a communicator: the same bits twice
+    np.testing.assert_array_equal(rn2["iterations"]["cost"], rn["iterations"]["cost"])
+    mc.close(); c0.close()
+
+
+def test_multi_rccl_tracks_and_matching_on_distinct_devices():
+    if _n_devices() < 2:
+        pytest.skip("needs 2 GPUs")
+    n = min(_n_devices(), 4)
+    sc = scene.add_features(scene.config_scene(1), 700)
+    R, t, c, fk = scene.cameras_for_tracks(sc)
+    order = np.argsort(sc.obs_pt, kind="stable")
+    k = np.bincount(sc.obs_pt, minlength=sc.n_points)
+    off = np.concatenate([[0], np.cumsum(k)]).astype(np.int32)
+    tr = A.TrackArrays(off, sc.obs_cam[order], sc.obs_xy[order], R, t, c, fk)
+    c0 = capi.Context(0)
+    X1, mse1, ok1 = c0.triangulate_midpoint(tr, 7.0, np.deg2rad(3.0))
+    mc = capi.MultiContext(n, devices=list(range(n)))
+    Xn, msen, okn = mc.triangulate_midpoint(tr, 7.0, np.deg2rad(3.0))
+    for a, b in ((X1, Xn), (mse1, msen), (ok1, okn)):
+        np.testing.assert_array_equal(a, b)
+    descs = [d.copy() for d in sc.desc[:6]]
+    pairs = np.array([(i, j) for i in range(6) for j in range(6) if i != j], np.int32)
+    ds = c0.descset(descs)
+    res = ds.match_pairs(pairs, 0.6, 0.85)
+    na1, ng1 = res.counts()
+    codes, nan_, ngn = mc.match_pairs(descs, pairs, 0.6, 0.85)
+    np.testing.assert_array_equal(na1, nan_); np.testing.assert_array_equal(ng1, ngn)
+    for p in range(len(pairs)):
+        np.testing.assert_array_equal(res.fetch(p)[0], codes[p])
+    res.close(); ds.close(); mc.close(); c0.close()
+
+
+def test_multi_rccl_failing_rank_aborts_the_communicators(monkeypatch):
+    """The distinct-device form of the test above: the peers of a failing rank sit in ncclAllReduce (or behind it in a bounded
+    stream wait); the failing rank's thread calls ncclCommAbort on every communicator, the call returns an error within the
+    wait bound, and the multi context refuses further work (its communicators are gone)."""
+    import time
+    if _n_devices() < 2:
+        pytest.skip("needs 2 GPUs")
+    sc = scene.make_aerial_scene(40, 2000, seed=9)
+    mc = capi.MultiContext(2, devices=[0, 1])
+    monkeypatch.setenv("MSFM_MULTI_FAIL_RANK", "1")
+    monkeypatch.setenv("MSFM_SYNC_TIMEOUT_S", "30")
+    t0 = time.time()
+    with pytest.raises(capi.MsfmError):
+        mc.ba_solve(A.BaArrays.from_scene(sc), capi.default_options(max_num_iterations=4))
+    assert time.time() - t0 < 90
+    monkeypatch.delenv("MSFM_MULTI_FAIL_RANK")
+    with pytest.raises(capi.MsfmError) as e:
+        mc.ba_solve(A.BaArrays.from_scene(sc), capi.default_options(max_num_iterations=4))
+    assert "aborted" in str(e.value)
+    mc.close()

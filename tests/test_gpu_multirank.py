@@ -112,3 +112,24 @@ def test_bench_starts_its_own_ranks():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 4 and r["value"] > 0 and r["roofline"]["frac"] > 0
     assert r["triangulation"]["midpoint"]["tracks"] == 20000
+
+
+def test_bench_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` the way the driver's scaling run starts it (its own torch.distributed.run child, backend
+    nccl = RCCL, one rank per GPU, ncclAllReduce inside libmsfm): skipped on a one-GPU box.  The line must name RCCL as the
+    collective, report two ranks and a positive rate."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MSFM_SYNC_TIMEOUT_S="60")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-extras", "--no-matching"], env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["value"] > 0
+    assert "RCCL" in r["config"]["collective"]
