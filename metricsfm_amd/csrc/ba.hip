@@ -311,8 +311,6 @@ struct PointPtrs {
   // (k_publish_scalars) accepted that step - else the launch ends at once - and spec[1] = the new trust-region radius.
   const double* spec;
   int keep_T;   // MSFM_KEEP_T=1: store every T record as rounds 1-3 did (comparison)
-  double* jac;  // MSFM_STORE_JAC=1 (A/B, round 5): the 26 doubles of every row (r, Jc, Jm, Jp; component-major over the rows) for k_backsub
-  size_t jac_n;
   int tu_direct;   // (MSFM_TU_DIRECT=0: T.u through the lane exchange as well)
 };
 
@@ -366,14 +364,6 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
     if (i < l) {
       double r0, r1, jcs[12], jms[6], jps[6];
       const double ci = obs_linearize(P.B, i, r0, r1, jcs, jms, jps);
-      if (P.jac) {   // (A/B: store instead of linearising again in k_backsub)
-        double* jr = P.jac + i;
-        jr[0] = r0; jr[P.jac_n] = r1;
-#pragma unroll
-        for (int k = 0; k < 12; k++) jr[(2 + k) * P.jac_n] = jcs[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { jr[(14 + k) * P.jac_n] = jms[k]; jr[(20 + k) * P.jac_n] = jps[k]; }
-      }
 #pragma unroll
       for (int k = 0; k < 12; k++) park[k * 256 + tid] = jcs[k];
 #pragma unroll
@@ -1396,8 +1386,6 @@ struct BackPtrs {
   int Nc;                  // the first Nc threads of the launch also prepare the candidate cameras' rotations
   const double* cam_c;     // (final before this launch: k_update_params)
   double* rot_c;
-  const double* jac;   // MSFM_STORE_JAC=1: the rows as k_point stored them (nullptr: linearised again)
-  size_t jac_n;
 };
 
 // 8 lanes per point, lane = observation, single pass: besides y = sum Jp^T (r + q) with
@@ -1420,16 +1408,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       // rows of frozen blocks come out as zeros, so no branches
       const int cb = P.B.o_cb[i], mb = P.B.o_mb[i];
       double jc[12], jm[6], jp[6], zc[6], zm[3], r0, r1;
-      if (P.jac) {
-        const double* jr = P.jac + i;
-        r0 = jr[0]; r1 = jr[P.jac_n];
-#pragma unroll
-        for (int k = 0; k < 12; k++) jc[k] = jr[(2 + k) * P.jac_n];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { jm[k] = jr[(14 + k) * P.jac_n]; jp[k] = jr[(20 + k) * P.jac_n]; }
-      } else {
-        obs_linearize(P.B, i, r0, r1, jc, jm, jp);
-      }
+      obs_linearize(P.B, i, r0, r1, jc, jm, jp);
       __builtin_amdgcn_sched_barrier(0);   // the step is fetched after the row is formed: nine registers less before
       const double* zcp = P.z + 6 * (cb >= 0 ? cb : 0);
       const double* zmp = P.z + 6 * P.ncb + 3 * (mb >= 0 ? mb : 0);
@@ -1694,7 +1673,6 @@ struct msfm_ba {
   DevBuf<double> scale_c, scale_m, scale_p, diag_c, diag_m, diag_p;
   DevBuf<int> pt_first, pm_first, pm_mb;
   DevBuf<double> ptL, ptg;
-  DevBuf<double> jacrow;   // MSFM_STORE_JAC=1 (A/B): [26][A]
   // ftf jobs
   int n_fchunks = 0;
   DevBuf<int> f_start, f_end, cam_chunk_first;
@@ -3772,7 +3750,6 @@ int ba_create_impl(msfm_ctx* ctx, const msfm_ba_problem* P, bool bulk_on_device,
   AL(scale_c, 6 * (size_t)ncb); AL(scale_m, 3 * (size_t)nmb); AL(scale_p, 3 * (size_t)npb);
   AL(diag_c, 6 * (size_t)ncb); AL(diag_m, 3 * (size_t)nmb); AL(diag_p, 3 * (size_t)npb);
   AL(ptL, 6 * (size_t)npb); AL(ptg, 3 * (size_t)npb);
-  { const char* e = getenv("MSFM_STORE_JAC"); if (e && atoi(e) != 0) AL(jacrow, 26 * (size_t)std::max(1, A)); }
   AL(f_partial, (size_t)ba->n_fchunks * PSTRIDE); AL(camftf, (size_t)ncb * PSTRIDE); AL(modelsum, 12 * (size_t)nmb);
   AL(M, (size_t)ba->npad * ba->npad); AL(Linv, (size_t)ba->npad * 144); /* 16x16 inverses + full 64x64 block inverses + diagonal blocks of L */ AL(w, ba->npad); AL(z, ba->npad + 8); AL(zsys, 2 * ((size_t)ba->npad + 8));   /* two solution buffers that alternate from solve to solve (k_backsolve_chain) */
   AL(g_r, 3 * (size_t)ncb); AL(g_J, 3 * (size_t)ncb);
@@ -3975,7 +3952,6 @@ static void launch_point(msfm_ba* ba, const msfm_ba_options* opt, double radius,
   Q.fold_pass = F.pass.p; Q.fold_stream = F.stream.p; Q.fold_partial = F.partial.p;
   Q.fold_mc_partial = (F.on && F.mc_on) ? F.mc_partial.p : nullptr;
   Q.spec = spec;
-  Q.jac = (ba->jacrow.p && mode != 1) ? ba->jacrow.p : nullptr; Q.jac_n = (size_t)std::max(1, ba->A);
   { static const bool keep = getenv("MSFM_KEEP_T") != nullptr && atoi(getenv("MSFM_KEEP_T")) != 0; Q.keep_T = keep ? 1 : 0; }
   { static const bool d = !(getenv("MSFM_TU_DIRECT") != nullptr && atoi(getenv("MSFM_TU_DIRECT")) == 0); Q.tu_direct = d ? 1 : 0; }
   hipLaunchKernelGGL(k_point, dim3(ba->nblk_pt), dim3(256), 0, ctx->stream, Q, ba->gmax_buf.p);
@@ -4283,7 +4259,6 @@ static int run_solve(msfm_ba* ba, const msfm_ba_options* opt) {
       Q.npb = npb; Q.ncb = ncb; Q.pt_first = ba->pt_first.p; Q.pb_pt = ba->pb_pt.p;
       Q.ptL = ba->ptL.p; Q.z = ba->z.p; Q.pt_c = ba->pt_c.p; Q.cm_Xc = ba->cm_Xc.p;
       Q.Nc = ba->Nc; Q.cam_c = ba->cam_c.p; Q.rot_c = ba->rot_c.p;
-      Q.jac = ba->jacrow.p; Q.jac_n = (size_t)std::max(1, ba->A);
       hipLaunchKernelGGL(k_backsub, dim3(nbp), dim3(256), 0, s, Q, ba->partial.p, ba->partial2.p + off, ba->partial3.p + off);
       off += nbp; moff += nbp;
     } else {
