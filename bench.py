@@ -472,6 +472,22 @@ def main():
         attach_util(out["matching_float"]["roofline"], "knn_f16")
         del fdescs
 
+    # ------------------------------------------------------------------ the reference's CALL PATTERN for bundle adjustment (round 5)
+    # IncrementalSfM::Run solves a fresh problem per added image (sfm_incremental.cc:146-190): neither the resident rate above nor
+    # one one-shot call is that.  scripts/ba_incremental.py replays it: config 2's cameras one at a time (partial BA per camera, a
+    # full one every 5th), and - on the config 5 window run - the windows of its twenty newest cameras one after the other.
+    if not args.no_extras and rank == 0 and world == 1:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import ba_incremental
+            if win:
+                out["ba_incremental_windows"] = ba_incremental.windows(ctx, 20, 20, sc)
+            else:
+                out["ba_incremental"] = ba_incremental.sequence(ctx, 2)
+            log("incremental call pattern measured")
+        except Exception as e:   # a side leg must not take the headline line down
+            out["ba_incremental_error"] = repr(e)
+
     # ------------------------------------------------------------------ triangulation / reprojection leg (A4, A5, A11)
     if not args.no_extras and not win:
         R, t, c, fk = scene.cameras_for_tracks(sc)
