@@ -415,7 +415,9 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
       if (sub == 0) {
         if (!ok) atomicOr(P.fail, 2);
         double* L = P.ptL + 6 * (size_t)pb;
-        L[0] = l00; L[1] = l10; L[2] = l11; L[3] = l20; L[4] = l21; L[5] = l22;
+        // (the diagonal as reciprocals: the back substitution multiplies - six binary64 divisions, ~170 instructions that one lane in
+        //  eight needs and the whole wave waits for, were a ninth of k_backsub's instruction stream)
+        L[0] = i00; L[1] = l10; L[2] = i11; L[3] = l20; L[4] = l21; L[5] = i22;
         // (g itself is not stored: the back substitution forms it again from the rows)
         const double* sp = P.B.scale_p + 3 * (size_t)pb;
         gmax = fmax(fabs(g0 / sp[0]), fmax(fabs(g1 / sp[1]), fabs(g2 / sp[2])));
@@ -1406,21 +1408,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int i = base + sub;
     if (i < l) {
       // rows of frozen blocks come out as zeros, so no branches
-      const int cb = P.B.o_cb[i], mb = P.B.o_mb[i];
-      double jc[12], jm[6], jp[6], zc[6], zm[3], r0, r1;
-      obs_linearize(P.B, i, r0, r1, jc, jm, jp);
-      __builtin_amdgcn_sched_barrier(0);   // the step is fetched after the row is formed: nine registers less before
-      const double* zcp = P.z + 6 * (cb >= 0 ? cb : 0);
-      const double* zmp = P.z + 6 * P.ncb + 3 * (mb >= 0 ? mb : 0);
+      double jp[6], r0, r1, q0, q1;
+#ifdef MSFM_BACKSUB_DIRECTIONAL
+      // Round 5, measured and NOT the default: q = -(J_c z_c + J_m z_m) as the directional derivative of the row's residual along
+      // the (unscaled) camera / intrinsics step instead of eighteen Jacobian columns contracted with it (msfm_reproj_dir): the
+      // same corrected, scaled quantities to rounding (every parity test green), 164 binary64 operations per row less (710 -> 546
+      // in the kernel's stream) - and the kernel SLOWER, 101 -> 117 us at config 3 (1 077 -> 1 056 iterations/s): the step and
+      // the scales now stand in front of the projection instead of behind it, one more level in the chain of dependent gathers
+      // of a kernel that waits for memory at three waves per SIMD.  A frozen block has a zero scale, hence a zero step.
+      {
+        const BaPtrs& B = P.B;
+        const int c = B.o_cam[i], m = B.o_model[i], p = B.o_pt[i];
+        const int cb = B.o_cb[i], mb = B.o_mb[i], pbk = B.o_pb[i];
+        double pose[6], rc[4], cm[3], X[3];
 #pragma unroll
-      for (int j = 0; j < 6; j++) zc[j] = zcp[j];
+        for (int j = 0; j < 6; j++) pose[j] = B.cam[6 * (size_t)c + j];
 #pragma unroll
-      for (int j = 0; j < 3; j++) zm[j] = zmp[j];
-      double q0 = 0.0, q1 = 0.0;
+        for (int j = 0; j < 4; j++) rc[j] = B.rot[4 * (size_t)c + j];
 #pragma unroll
-      for (int j = 0; j < 6; j++) { q0 -= jc[j] * zc[j]; q1 -= jc[6 + j] * zc[j]; }
+        for (int j = 0; j < 3; j++) { cm[j] = B.model[3 * (size_t)m + j]; X[j] = B.pt[3 * (size_t)p + j]; }
+        const double* zcp = P.z + 6 * (cb >= 0 ? cb : 0);
+        const double* zmp = P.z + 6 * P.ncb + 3 * (mb >= 0 ? mb : 0);
+        double zw[3], zt[3], zmv[3], sp[3];
 #pragma unroll
-      for (int j = 0; j < 3; j++) { q0 -= jm[j] * zm[j]; q1 -= jm[3 + j] * zm[j]; }
+        for (int j = 0; j < 3; j++) {
+          zw[j] = cb >= 0 ? B.scale_c[6 * cb + j] * zcp[j] : 0.0;
+          zt[j] = cb >= 0 ? B.scale_c[6 * cb + 3 + j] * zcp[3 + j] : 0.0;
+          zmv[j] = mb >= 0 ? B.scale_m[3 * mb + j] * zmp[j] : 0.0;
+          sp[j] = pbk >= 0 ? B.scale_p[3 * (size_t)pbk + j] : 0.0;
+        }
+        double r[2], Jp[6], d[2];
+        msfm_reproj_dir(pose, rc, cm, X, B.o_x[i], B.o_y[i], B.o_w[i], zw, zt, zmv, r, Jp, d);
+        double rho0, rho1;
+        msfm_huber(B.huber, r[0] * r[0] + r[1] * r[1], rho0, rho1);
+        const double sq = sqrt(rho1);
+        r0 = sq * r[0]; r1 = sq * r[1];
+        q0 = -(sq * d[0]); q1 = -(sq * d[1]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const double spj = sq * sp[j]; jp[j] = spj * Jp[j]; jp[3 + j] = spj * Jp[3 + j]; }
+      }
+#else
+      {
+        const int cb = P.B.o_cb[i], mb = P.B.o_mb[i];
+        double jc[12], jm[6], zc[6], zm[3];
+        obs_linearize(P.B, i, r0, r1, jc, jm, jp);
+        __builtin_amdgcn_sched_barrier(0);   // the step is fetched after the row is formed: nine registers less before
+        const double* zcp = P.z + 6 * (cb >= 0 ? cb : 0);
+        const double* zmp = P.z + 6 * P.ncb + 3 * (mb >= 0 ? mb : 0);
+#pragma unroll
+        for (int j = 0; j < 6; j++) zc[j] = zcp[j];
+#pragma unroll
+        for (int j = 0; j < 3; j++) zm[j] = zmp[j];
+        q0 = 0.0; q1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { q0 -= jc[j] * zc[j]; q1 -= jc[6 + j] * zc[j]; }
+#pragma unroll
+        for (int j = 0; j < 3; j++) { q0 -= jm[j] * zm[j]; q1 -= jm[3 + j] * zm[j]; }
+      }
+#endif
       const double a0 = jp[0], a1 = jp[1], a2 = jp[2], b0 = jp[3], b1 = jp[4], b2 = jp[5];
       V00 += a0 * a0 + b0 * b0; V10 += a1 * a0 + b1 * b0; V11 += a1 * a1 + b1 * b1;
       V20 += a2 * a0 + b2 * b0; V21 += a2 * a1 + b2 * b1; V22 += a2 * a2 + b2 * b2;
@@ -1435,14 +1480,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   double mcc = 0.0, dx2 = 0.0, x2 = 0.0, cand0 = 0.0, cand1 = 0.0, cand2 = 0.0;
   if (act && sub == 0) {
     const double* L = P.ptL + 6 * (size_t)pb;
-    const double l00 = L[0], l10 = L[1], l11 = L[2], l20 = L[3], l21 = L[4], l22 = L[5];
+    const double i00 = L[0], l10 = L[1], i11 = L[2], l20 = L[3], l21 = L[4], i22 = L[5];   // (1 / l00, 1 / l11, 1 / l22: k_point)
     // (L L^T) y' = y,  y = g + h
-    double q0 = (g0 + h0) / l00;
-    double q1 = ((g1 + h1) - l10 * q0) / l11;
-    double q2 = ((g2 + h2) - l20 * q0 - l21 * q1) / l22;
-    q2 = q2 / l22;
-    q1 = (q1 - l21 * q2) / l11;
-    q0 = (q0 - l10 * q1 - l20 * q2) / l00;
+    double q0 = (g0 + h0) * i00;
+    double q1 = ((g1 + h1) - l10 * q0) * i11;
+    double q2 = ((g2 + h2) - l20 * q0 - l21 * q1) * i22;
+    q2 = q2 * i22;
+    q1 = (q1 - l21 * q2) * i11;
+    q0 = (q0 - l10 * q1 - l20 * q2) * i00;
     const double s0 = -q0, s1 = -q1, s2 = -q2;  // step (scaled space)
     const double* sc = P.B.scale_p + 3 * (size_t)pb;
     const size_t p = P.pb_pt[pb];

@@ -106,6 +106,77 @@ __device__ __forceinline__ void msfm_reproj(const double* __restrict__ pose, con
   J[8] = weight * f * r2 * r2 * xp; J[12 + 8] = weight * f * r2 * r2 * yp;
 }
 
+// The row as the BACK SUBSTITUTION needs it (round 5): the residual, the point block of the Jacobian and the row's product with a
+// GIVEN camera / intrinsics step - J_c zeta_c + J_m zeta_m as the directional derivative of the residual along (zeta_w, zeta_t,
+// zeta_m) instead of the twelve + six Jacobian columns contracted afterwards.  The rotation part is the derivative of the
+// evaluated formula along zeta_w (the same terms msfm_reproj forms per column j, with e_j replaced by zeta_w: about a third of
+// the operations), the rest is shared with msfm_reproj line for line.  r, Jp (2 x 3, times weight) and d = J_c zeta_c + J_m zeta_m
+// (2, times weight) come out unscaled and uncorrected like msfm_reproj's.
+__device__ __forceinline__ void msfm_reproj_dir(const double* __restrict__ pose, const double* __restrict__ rc, const double* __restrict__ cam,
+                                                const double* __restrict__ xyz, double ox, double oy, double weight, const double (&zw)[3],
+                                                const double (&zt)[3], const double (&zm)[3], double* r, double* Jp, double* d) {
+  const double a0 = pose[0], a1 = pose[1], a2 = pose[2];
+  const double X0 = xyz[0], X1 = xyz[1], X2 = xyz[2];
+  double p0, p1, p2, dp0, dp1, dp2;
+  double R[9];
+  if (rc[0] != 0.0) {
+    const double s = rc[1], c = rc[2], ti = rc[3];
+    const double w0 = a0 * ti, w1 = a1 * ti, w2 = a2 * ti;
+    const double wx0 = w1 * X2 - w2 * X1, wx1 = w2 * X0 - w0 * X2, wx2 = w0 * X1 - w1 * X0;
+    const double wdx = w0 * X0 + w1 * X1 + w2 * X2;
+    const double omc = 1.0 - c;
+    const double tmp = wdx * omc;
+    p0 = X0 * c + wx0 * s + w0 * tmp;
+    p1 = X1 * c + wx1 * s + w1 * tmp;
+    p2 = X2 * c + wx2 * s + w2 * tmp;
+    // along zeta_w: d theta = w . zeta, d w = (zeta - w (w . zeta)) / theta
+    const double dth = w0 * zw[0] + w1 * zw[1] + w2 * zw[2];
+    const double dw0 = (zw[0] - w0 * dth) * ti, dw1 = (zw[1] - w1 * dth) * ti, dw2 = (zw[2] - w2 * dth) * ti;
+    const double dwx0 = dw1 * X2 - dw2 * X1, dwx1 = dw2 * X0 - dw0 * X2, dwx2 = dw0 * X1 - dw1 * X0;
+    const double dwdx = dw0 * X0 + dw1 * X1 + dw2 * X2;
+    const double dc = -s * dth, ds = c * dth;
+    const double dtmp = dwdx * omc - wdx * dc;
+    dp0 = X0 * dc + dwx0 * s + wx0 * ds + dw0 * tmp + w0 * dtmp;
+    dp1 = X1 * dc + dwx1 * s + wx1 * ds + dw1 * tmp + w1 * dtmp;
+    dp2 = X2 * dc + dwx2 * s + wx2 * ds + dw2 * tmp + w2 * dtmp;
+    R[0] = c + w0 * w0 * omc;      R[1] = w0 * w1 * omc - w2 * s; R[2] = w1 * s + w0 * w2 * omc;
+    R[3] = w2 * s + w0 * w1 * omc; R[4] = c + w1 * w1 * omc;      R[5] = -w0 * s + w1 * w2 * omc;
+    R[6] = -w1 * s + w0 * w2 * omc; R[7] = w0 * s + w1 * w2 * omc; R[8] = c + w2 * w2 * omc;
+  } else {
+    p0 = X0 + (a1 * X2 - a2 * X1);
+    p1 = X1 + (a2 * X0 - a0 * X2);
+    p2 = X2 + (a0 * X1 - a1 * X0);
+    dp0 = zw[1] * X2 - zw[2] * X1;     // d(w x X) along zeta_w
+    dp1 = zw[2] * X0 - zw[0] * X2;
+    dp2 = zw[0] * X1 - zw[1] * X0;
+    R[0] = 1;   R[1] = -a2; R[2] = a1;
+    R[3] = a2;  R[4] = 1;   R[5] = -a0;
+    R[6] = -a1; R[7] = a0;  R[8] = 1;
+  }
+  p0 += pose[3]; p1 += pose[4]; p2 += pose[5];
+  dp0 += zt[0]; dp1 += zt[1]; dp2 += zt[2];
+  const double iz = 1.0 / p2;
+  const double xp = p0 * iz, yp = p1 * iz;   // (the linearisation pass: Jet division, as msfm_reproj with J)
+  const double f = cam[0], l1 = cam[1], l2 = cam[2];
+  const double r2 = xp * xp + yp * yp;
+  const double dist = 1.0 + r2 * (l1 + l2 * r2);
+  r[0] = weight * (f * dist * xp - ox);
+  r[1] = weight * (f * dist * yp - oy);
+  const double dd = l1 + 2.0 * l2 * r2;
+  const double uxp = f * (dist + 2.0 * xp * xp * dd), uyp = f * 2.0 * xp * yp * dd;
+  const double vxp = uyp, vyp = f * (dist + 2.0 * yp * yp * dd);
+  const double up[3] = {uxp * iz, uyp * iz, -(uxp * xp + uyp * yp) * iz};
+  const double vp[3] = {vxp * iz, vyp * iz, -(vxp * xp + vyp * yp) * iz};
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    Jp[j] = weight * (up[0] * R[j] + up[1] * R[3 + j] + up[2] * R[6 + j]);
+    Jp[3 + j] = weight * (vp[0] * R[j] + vp[1] * R[3 + j] + vp[2] * R[6 + j]);
+  }
+  const double fr2 = f * r2;
+  d[0] = weight * ((up[0] * dp0 + up[1] * dp1 + up[2] * dp2) + xp * (dist * zm[0] + fr2 * zm[1] + fr2 * r2 * zm[2]));
+  d[1] = weight * ((vp[0] * dp0 + vp[1] * dp1 + vp[2] * dp2) + yp * (dist * zm[0] + fr2 * zm[1] + fr2 * r2 * zm[2]));
+}
+
 // ceres::HuberLoss(a) (constructed at optimizer.cc:84): rho0 = rho(s), rho1 = rho'(s).
 __device__ __forceinline__ void msfm_huber(double a, double s, double& rho0, double& rho1) {
   const double b = a * a;
