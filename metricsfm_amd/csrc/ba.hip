@@ -307,7 +307,6 @@ struct PointPtrs {
   const unsigned* fold_stream;
   double* fold_partial;
   double* fold_mc_partial;   // intrinsics x camera products of the same workgroups (one intrinsics block only; nullptr: gather path)
-  double* fold_tu_partial;   // [diagonal slot rank][6]: sum of T.u over the slot's records (round 5; nullptr: T.u goes to memory per row)
   // A launch enqueued BEFORE the host has seen the step it follows (msfm_ba_run): spec[0] != 0 if the device-side decision
   // (k_publish_scalars) accepted that step - else the launch ends at once - and spec[1] = the new trust-region radius.
   const double* spec;
@@ -322,9 +321,7 @@ struct PointPtrs {
 // (obs_linearize: the row data is read coalesced, the parameters come from cache), the per-point sums are 3-step
 // reductions inside the 8-lane group, and every lane then finishes its own observation's T = (Jc^T Jp) L^-T.
 // 256 threads = 32 points.  Tracks of up to 8 views keep their rows in registers; longer ones linearise them again.
-#define FOLD_OVF 46   // second-round records (rows 8..15 of a point) a workgroup can park beside the 256 first-round ones (round 5: 51 -> 46;
-                      // the five records' space holds u of the workgroup's points - LDS is allocated in 1 280-byte granules here and 768
-                      // bytes more made it two workgroups per CU instead of three: k_point 0.30 -> 0.42 ms)
+#define FOLD_OVF 51   // second-round records (rows 8..15 of a point) a workgroup can park beside the 256 first-round ones
 #define FOLD_NREC (256 + FOLD_OVF)   // records of 2 x 10 doubles (two 16-byte aligned halves of 9) in the 48 KB row park
 #define FOLD_WORDS 1024      // words (slot headers + entries) of one pass, staged in LDS
 #define FOLD_PASS_SLOTS 128  // slots of one pass at most: four threads per slot, two rounds
@@ -335,16 +332,13 @@ __device__ long long g_fold_stamps[8192][8];
 #else
 #define FSTAMP(i) do {} while (0)
 #endif
-__device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restrict__ gmax_partial, double* sh, double* park, unsigned* ent_s, double* u_s) {
+__device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restrict__ gmax_partial, double* sh, double* park, unsigned* ent_s) {
   const int tid = threadIdx.x, sub = tid & 7;
   const int pb = blockIdx.x * 32 + (tid >> 3);
   const bool act = pb < P.npb;
   // FoldTables: the slot headers and entries of the workgroup's first pass start on their way into LDS now (one
   // global_load_lds_dwordx4 per wave and 256 words; nothing waits for them before the fold phase at the end)
   const bool fold = P.fold_wg != nullptr && P.mode != 1 && P.fold_wg[blockIdx.x] != 0;
-  // Round 5: in a folding workgroup whose intrinsics x camera products fold too, the per-camera sums of T.u are formed in the
-  // camera-diagonal slots as well (48 bytes per row less written here, and less read by k_sums)
-  const bool tu_folded = fold && P.fold_mc_partial != nullptr && P.fold_tu_partial != nullptr;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   auto stage = [&](int off, int words) {
     if (256 * wv < words)
@@ -477,9 +471,8 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
 #pragma unroll
       for (int k = 0; k < 18; k++) Tk[k] = T[k];
       if (!need_T && P.tu_direct) {
-        // (only T.u leaves the workgroup: 48 contiguous bytes per row, stored from the lane that formed them - no exchange;
-        //  with tu_folded not even that: the diagonal slots sum it below)
-        if (cp >= 0 && !tu_folded) {
+        // (only T.u leaves the workgroup: 48 contiguous bytes per row, stored from the lane that formed them - no exchange)
+        if (cp >= 0) {
           double2* Tu2 = reinterpret_cast<double2*>(P.Tu + 6 * (size_t)cp);
 #pragma unroll
           for (int k = 0; k < 3; k++) Tu2[k] = make_double2(tu[2 * k], tu[2 * k + 1]);
@@ -542,8 +535,6 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
       if (fold) {
         __syncthreads();   // every lane has consumed its parked row data: the park becomes the record store
         if (cpk >= 0) rec_st(tid, Tk);
-        // (u of the workgroup's points behind the records - only now: the space was the last component plane of the parked rows)
-        if (tu_folded && sub == 0) { u_s[3 * (tid >> 3)] = u0; u_s[3 * (tid >> 3) + 1] = u1; u_s[3 * (tid >> 3) + 2] = u2; }
       }
       auto tm_finish = [&](int e, double (&W)[9]) {
 #pragma unroll
@@ -652,7 +643,7 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
           // (rows 0 and 1 of the 3 x 6 product with the threads that hold rows 0..2 of record i, row 2 with the other two)
           const bool mcd = sl < n_diag;
           const int ma0 = ra ? 2 : 0;
-          double acc[9], accm[6], acct[3] = {0.0, 0.0, 0.0};
+          double acc[9], accm[6];
 #pragma unroll
           for (int k = 0; k < 9; k++) acc[k] = 0.0;
 #pragma unroll
@@ -686,17 +677,7 @@ __device__ __forceinline__ void k_point_body(const PointPtrs& P, double* __restr
 #pragma unroll
                 for (int c = 0; c < 3; c++)
                   accm[a * 3 + c] += tm[a * 3] * tj[c * 3] + tm[a * 3 + 1] * tj[c * 3 + 1] + tm[a * 3 + 2] * tj[c * 3 + 2];
-              if (tu_folded && ra == 0) {   // rows 3 rb .. 3 rb + 2 of T_rec . u_point, summed over the camera's records in point order
-                const double* up = u_s + 3 * (r0 >> 3);
-                const double w0 = up[0], w1 = up[1], w2 = up[2];
-#pragma unroll
-                for (int c = 0; c < 3; c++) acct[c] += tj[c * 3] * w0 + tj[c * 3 + 1] * w1 + tj[c * 3 + 2] * w2;
-              }
             }
-          }
-          if (mcd && tu_folded && ra == 0) {
-            double* ot = P.fold_tu_partial + (size_t)rnk * 6 + 3 * rb;
-            ot[0] = acct[0]; ot[1] = acct[1]; ot[2] = acct[2];
           }
           if (mcd) {
             double* om = P.fold_mc_partial + (size_t)rnk * 18;
@@ -731,9 +712,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ double park[24 * 256];
   __shared__ __attribute__((aligned(16))) unsigned ent_s[FOLD_WORDS];
   if (P.spec && P.spec[0] == 0.0) return;   // enqueued ahead of a step that was not accepted
-  // (u = L^-1 g of the workgroup's 32 points, for the sums of T.u in the diagonal fold slots: behind the record store)
-  static_assert(2 * FOLD_NREC * 10 + 96 <= 24 * 256, "the record store and u must fit the row park");
-  k_point_body(P, gmax_partial, sh, park, ent_s, park + 2 * FOLD_NREC * 10);
+  k_point_body(P, gmax_partial, sh, park, ent_s);
 }
 
 // The static inputs of a row in camera-major order (k_ftf): built once per problem from the resident row arrays.
@@ -1289,30 +1268,12 @@ __device__ __forceinline__ void asm_mm(int b, const int* __restrict__ blk_row, c
 
 // rhs of the camera columns + intrinsics blocks that have no (point, intrinsics) entries.
 // camftf is already global (summed over ranks), so only the lead rank contributes it.
-// (round 5: the sums of T.u that k_point formed in its diagonal fold slots - one 6-vector per (workgroup, camera), in workgroup
-//  order, sixteen loads in flight - are local to the rank: every rank subtracts its own, the exchange of the rhs row adds them up)
 __device__ __forceinline__ void asm_rhs_cam(int i, int ncb, const double* __restrict__ camftf, const int* __restrict__ cb_off,
-                                            const int* __restrict__ tu_range, const double* __restrict__ tu_partial,
                                             double* __restrict__ M, int ld, int n, int lead) {
   if (i >= 6 * ncb) return;
   const int cb = i / 6, a = i % 6;
   const double* f = camftf + (size_t)cb * PSTRIDE;
-  double folded = 0.0;
-  if (tu_range) {
-    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-    int sl = tu_range[2 * cb];
-    const int f1 = tu_range[2 * cb + 1];
-    for (; sl + 15 < f1; sl += 16) {
-      double v[16];
-#pragma unroll
-      for (int j = 0; j < 16; j++) v[j] = tu_partial[(size_t)(sl + j) * 6 + a];
-#pragma unroll
-      for (int j = 0; j < 16; j += 4) { q0 += v[j]; q1 += v[j + 1]; q2 += v[j + 2]; q3 += v[j + 3]; }
-    }
-    for (; sl < f1; sl++) q0 += tu_partial[(size_t)sl * 6 + a];
-    folded = (q0 + q1) + (q2 + q3);
-  }
-  M[(size_t)n * ld + cb_off[cb] + a] = (lead ? f[F_JCR + a] - f[F_TU + a] : 0.0) - folded;
+  M[(size_t)n * ld + cb_off[cb] + a] = lead ? f[F_JCR + a] - f[F_TU + a] : 0.0;
 }
 
 // The four assembly passes in one launch of 64-thread workgroups: [0, n_cc) camera-camera blocks, then intrinsics-camera
@@ -1325,8 +1286,6 @@ struct AsmArgs {
   const double* cc_fold_partial;
   const int* mc_fold_range;
   const double* mc_fold_partial;
-  const int* tu_range;          // sums of T.u from the diagonal fold slots (nullptr: all of it is in camftf)
-  const double* tu_partial;
   const int *cc_row, *cc_col, *cc_first, *mc_row, *mc_col, *mc_first, *mm_row, *mm_col, *mm_first, *cb_mb, *cb_off;
   const double *cc_partial, *mc_partial, *mm_partial, *camftf, *diag_c, *modelsum, *diag_m;
   double radius;
@@ -1345,7 +1304,7 @@ __global__ __launch_bounds__(64) void k_asm_all(AsmArgs a) {
   b -= a.n_mc;
   if (b < a.n_mm) { asm_mm(b, a.mm_row, a.mm_col, a.mm_first, a.mm_partial, a.modelsum, a.diag_m, a.radius, a.mo, a.n, a.M, a.ld, a.lead); return; }
   b -= a.n_mm;
-  if (b < a.n_rhs) { asm_rhs_cam(b * 64 + (int)threadIdx.x, a.ncb, a.camftf, a.cb_off, a.tu_range, a.tu_partial, a.M, a.ld, a.n, a.lead); return; }
+  if (b < a.n_rhs) { asm_rhs_cam(b * 64 + (int)threadIdx.x, a.ncb, a.camftf, a.cb_off, a.M, a.ld, a.n, a.lead); return; }
   b -= a.n_rhs;
   const int i = b * 64 + (int)threadIdx.x;   // identity on the padding columns (k_pad_diag)
   if (i < a.n_padcol) a.M[(size_t)a.padcol[i] * a.ld + a.padcol[i]] = 1.0;
@@ -1721,10 +1680,6 @@ struct FoldTables {
   long long mc_entries_folded = 0;
   DevBuf<int> mc_range, mc_live_chunk;
   DevBuf<double> mc_partial;
-  // sums of T.u per diagonal slot (round 5): [n_diag][6]; the diagonal slots of camera block cb have the ranks tu_range[2 cb] .. [2 cb + 1]
-  bool tu_on = false;
-  DevBuf<double> tu_partial;
-  DevBuf<int> tu_range;
 };
 
 struct PairJobs {
@@ -2908,13 +2863,6 @@ __global__ __launch_bounds__(256) void k_fold_count_marked(int n, const int* __r
   __syncthreads();
   if (threadIdx.x == 0) { const int t = part[0] + part[1] + part[2] + part[3]; if (t) atomicAdd(count, t); }
 }
-// rows (camera-major positions) of points in folding workgroups: -2 - point block instead of the point block
-__global__ __launch_bounds__(256) void k_fold_mark_tu(int ncr, const int* __restrict__ wg_fold, int* __restrict__ cpos_pb) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= ncr) return;
-  const int pb = cpos_pb[e];
-  if (pb >= 0 && wg_fold[pb >> 5]) cpos_pb[e] = -2 - pb;
-}
 __global__ __launch_bounds__(256) void k_fold_mark_mc(int n, const uint8_t* __restrict__ folded, int* __restrict__ pa, const int* __restrict__ pb) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < n && pa[e] >= 0 && folded[pb[e]]) pa[e] = ~pa[e];
@@ -3117,21 +3065,6 @@ static int build_fold_device(msfm_ctx* ctx, msfm_ba* ba) {
       }
       F.mc_on = true;
       F.mc_all = F.mc_n_live == 0;
-      // Round 5: the per-camera sums of T.u from the same diagonal slots.  Rows of folding workgroups are taken out of the
-      // per-row path: their camera-major position no longer names a point block (cpos_pb < 0: k_sums' row part skips T.u there).
-      static const bool tu_off = getenv("MSFM_NO_FOLD_TU") != nullptr;
-      if (!tu_off) {
-        DTRY(F.tu_partial.alloc((size_t)F.n_diag * 6));
-        DTRY(hipMemsetAsync(F.tu_partial.p, 0, sizeof(double) * 6 * (size_t)F.n_diag, s));
-        DTRY(F.tu_range.alloc(2 * (size_t)std::max(1, ncb)));
-        DevBuf<int> iota;
-        DTRY(iota.alloc((size_t)std::max(1, ncb)));
-        hipLaunchKernelGGL(k_iota, dim3(cdiv(std::max(1, ncb), 256)), dim3(256), 0, s, ncb, iota.p);
-        hipLaunchKernelGGL(k_fold_mc_range, dim3(cdiv(std::max(1, ncb), 256)), dim3(256), 0, s, ncb, NS, iota.p, slot_key2_s.p, F.tu_range.p);
-        hipLaunchKernelGGL(k_fold_mark_tu, dim3(cdiv(std::max(1, ba->NCR), 256)), dim3(256), 0, s, ba->NCR, F.wg_fold.p, ba->cpos_pb.p);
-        DTRY(hipStreamSynchronize(s));   // (iota goes out of scope)
-        F.tu_on = true;
-      }
     }
   }
   flap("intrinsics x camera");
@@ -4063,7 +3996,6 @@ static void launch_point(msfm_ba* ba, const msfm_ba_options* opt, double radius,
   Q.fold_wg = F.on ? F.wg_fold.p : nullptr; Q.fold_ovf_off = F.ovf_off.p; Q.fold_wg_pass_first = F.wg_pass_first.p; Q.fold_slot_rank = F.slot_rank.p;
   Q.fold_pass = F.pass.p; Q.fold_stream = F.stream.p; Q.fold_partial = F.partial.p;
   Q.fold_mc_partial = (F.on && F.mc_on) ? F.mc_partial.p : nullptr;
-  Q.fold_tu_partial = (F.on && F.mc_on && F.tu_on) ? F.tu_partial.p : nullptr;
   Q.spec = spec;
   { static const bool keep = getenv("MSFM_KEEP_T") != nullptr && atoi(getenv("MSFM_KEEP_T")) != 0; Q.keep_T = keep ? 1 : 0; }
   { static const bool d = !(getenv("MSFM_TU_DIRECT") != nullptr && atoi(getenv("MSFM_TU_DIRECT")) == 0); Q.tu_direct = d ? 1 : 0; }
@@ -4249,8 +4181,6 @@ static int run_assemble(msfm_ba* ba, const msfm_ba_options* opt, double radius, 
       const bool fmc = ba->fold.on && ba->fold.mc_on;
       aa.mc_first = (fmc && ba->fold.mc_all) ? nullptr : ba->mc.blk_chunk_first.p;
       aa.mc_fold_range = fmc ? ba->fold.mc_range.p : nullptr; aa.mc_fold_partial = ba->fold.mc_partial.p;
-      const bool ftu = fmc && ba->fold.tu_on;
-      aa.tu_range = ftu ? ba->fold.tu_range.p : nullptr; aa.tu_partial = ba->fold.tu_partial.p;
     }
     aa.mm_row = ba->mm.blk_row.p; aa.mm_col = ba->mm.blk_col.p; aa.mm_first = ba->mm.blk_chunk_first.p; aa.mm_partial = ba->mm.partial.p;
     aa.cb_mb = ba->cb_mb.p; aa.cb_off = ba->cb_off.p; aa.camftf = ba->camftf.p; aa.diag_c = ba->diag_c.p; aa.modelsum = ba->modelsum.p;
