@@ -68,6 +68,40 @@ for r in range(rounds):
         h = min(n2, n1) // 2
         d2[:h] = d1[:h]   # planted duplicates: ties by index
     same("knn2", ctx.knn2(d1, d2), O.knn2(d1, d2, fast=True), seed)
+    # matching on float descriptors (round 5): the codes-only form decides most codes from certified distance intervals, the
+    # keep-arrays form evaluates every candidate - both against the oracle's binary64 definition.  Random magnitudes, near
+    # duplicates (ratios near 0 and 0 / 0), second-nearest rows planted near the two thresholds, random threshold pairs.
+    fr = np.random.default_rng(seed + 17)
+    m1, m2 = int(fr.integers(2, 900)), int(fr.integers(1, 600))
+    mag = float(fr.choice([2.0 ** -9, 1.0, 512.0, 3.0e4]))
+    f1 = d1[fr.integers(0, n1, m1)] + fr.normal(0, 0.3, (m1, 128))
+    f2 = d2[fr.integers(0, n2, m2)] + fr.normal(0, 0.3, (m2, 128))
+    f1 = (mag * f1 / np.maximum(1e-9, np.linalg.norm(f1, axis=1, keepdims=True))).astype(np.float32)
+    f2 = (mag * f2 / np.maximum(1e-9, np.linalg.norm(f2, axis=1, keepdims=True))).astype(np.float32)
+    for k in range(min(m2, m1 - 1, 24)):          # query k near train row k, a planted second row at ratio ~ th
+        th = (0.6, 0.85)[k & 1]
+        u = fr.standard_normal(128); u *= 0.04 * mag / np.linalg.norm(u)
+        w = fr.standard_normal(128); w -= w.dot(u) / u.dot(u) * u; w /= np.linalg.norm(w)
+        q = f1[k].astype(np.float64) + u
+        f2[k] = q.astype(np.float32)
+        f1[m1 - 1 - k] = (q + np.sqrt(u.dot(u) / th * (1 + (k - 12) * 2e-8)) * w).astype(np.float32)
+    if r % 3 == 0 and m2 > 30:
+        f2[25:30] = f1[:5]                          # exact duplicates
+    rg_, ra_ = [(0.6, 0.85), (0.99, 0.9), (0.5, 0.5)][r % 3]
+    ds = ctx.descset([f1, f2])
+    pr = np.array([[0, 1]], np.int32)
+    ids_o, d_o = O.knn2(f1, f2)
+    code_o, na_o, ng_o = O.ratio_codes(ids_o, d_o, rg_, ra_)
+    for keep in (False, True):
+        res = ds.match_pairs(pr, rg_, ra_, keep_knn=keep)
+        code, ids, dist = res.fetch(0)
+        na, ng = res.counts()
+        outs_g, outs_o = [code, np.array([na[0], ng[0]])], [code_o, np.array([na_o, ng_o])]
+        if keep:
+            outs_g += [ids, dist]; outs_o += [ids_o, d_o]
+        same("float match keep=%d mag=%g" % (keep, mag), outs_g, outs_o, seed)
+        res.close()
+    ds.close()
     # bundle adjustment on a small random scene
     if r % 4 == 0:
         sc = scene.make_ring_scene(int(rng.integers(4, 14)), int(rng.integers(50, 400)), seed=seed)
