@@ -73,6 +73,8 @@ for r in range(rounds):
     # duplicates (ratios near 0 and 0 / 0), second-nearest rows planted near the two thresholds, random threshold pairs.
     fr = np.random.default_rng(seed + 17)
     m1, m2 = int(fr.integers(2, 900)), int(fr.integers(1, 600))
+    if r % 6 == 5:
+        m1, m2 = int(fr.integers(900, 5000)), int(fr.integers(300, 1500))   # several 256-row windows, more than one workgroup of queries
     mag = float(fr.choice([2.0 ** -9, 1.0, 512.0, 3.0e4]))
     f1 = d1[fr.integers(0, n1, m1)] + fr.normal(0, 0.3, (m1, 128))
     f2 = d2[fr.integers(0, n2, m2)] + fr.normal(0, 0.3, (m2, 128))
@@ -86,7 +88,7 @@ for r in range(rounds):
         f2[k] = q.astype(np.float32)
         f1[m1 - 1 - k] = (q + np.sqrt(u.dot(u) / th * (1 + (k - 12) * 2e-8)) * w).astype(np.float32)
     if r % 3 == 0 and m2 > 30:
-        f2[25:30] = f1[:5]                          # exact duplicates
+        f2[25:25 + min(5, m1)] = f1[:min(5, m1)]    # exact duplicates
     rg_, ra_ = [(0.6, 0.85), (0.99, 0.9), (0.5, 0.5)][r % 3]
     ds = ctx.descset([f1, f2])
     pr = np.array([[0, 1]], np.int32)
