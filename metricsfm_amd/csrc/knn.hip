@@ -798,12 +798,24 @@ __device__ __forceinline__ void merge_window4(u32 (&g)[4], int (&gb)[4], u32 w0,
 // own results back.  Per-slot evaluation `if (eval_j) exact_sqdist(...)` made the whole wave wait through up to eight rounds of
 // 128 dependent binary64 operations whenever one lane had a candidate in that slot.)
 #ifdef MSFM_KNN_F16_STATS   // developer counters (scripts/knn_f16_stats.py): valid queries, queries decided from intervals, exact evaluations, list rounds
-__device__ unsigned long long g_f16_stats[4];
+__device__ unsigned long long g_f16_stats[8];
 extern "C" __attribute__((visibility("default"))) int msfm_dbg_f16_stats(unsigned long long* out, int reset) {
-  if (reset) { static unsigned long long z[4]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_stats), z, sizeof z); }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f16_stats), 4 * sizeof(unsigned long long));
+  if (reset) { static unsigned long long z[8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_f16_stats), z, sizeof z); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f16_stats), 8 * sizeof(unsigned long long));
 }
 #endif
+// Is the outcome of the ratio tests the same for every pair of distances d0 in [lo0, hi0], d1 in [lo1, hi1] (hi0 < lo1)?  The
+// float distances the exact path would form lie in [(float)lo, (float)hi] (rounding is monotone), its float ratio in
+// [r_lo, r_hi] (float division is monotone in both operands); the 1e-30 guard keeps zeros, subnormal ratios and 0 / 0 on the
+// exact path.  fa / fb: a point of the interval (any gives the certain outcome).
+__device__ __forceinline__ bool ratio_certain(double lo0, double hi0, double lo1, double hi1, float ratio_good, float ratio_all, float& fa, float& fb) {
+  const float f_lo0 = (float)lo0, f_hi0 = (float)hi0, f_lo1 = (float)lo1, f_hi1 = (float)hi1;
+  if (!(lo0 > 1e-30 && hi0 < lo1 && f_hi1 < 3.0e38f)) return false;
+  const float r_lo = f_lo0 / f_hi1, r_hi = f_hi0 / f_lo1;
+  fa = f_hi0; fb = f_lo1;
+  if (ratio_good < 0.f) return (r_lo > ratio_all) == (r_hi > ratio_all);
+  return ((r_lo < ratio_good) == (r_hi < ratio_good)) && ((r_lo < ratio_all) == (r_hi < ratio_all));
+}
 struct EpiQuery {
   u32 gv[4];
   int gi[4];
@@ -877,15 +889,7 @@ __device__ __forceinline__ void epi_prepare(const PairTaskH& T, int q, bool qval
     // (the 1e-12: the oracle's 128 binary64 fused steps stay within 1.5e-14 of the real-number distance that E bounds)
     const double lo0 = (x1 - G - E) * inv_s2 * (1.0 - 1e-12), hi0 = (x1 * (1.0 + 3.0517578125e-5) - G + E) * inv_s2 * (1.0 + 1e-12);
     const double lo1 = (fmin(x2, unl) - G - E) * inv_s2 * (1.0 - 1e-12), hi1 = (x2 * (1.0 + 3.0517578125e-5) - G + E) * inv_s2 * (1.0 + 1e-12);
-    // the float distances the exact path would form lie in [(float)lo, (float)hi] (rounding is monotone); the 1e-30 guard keeps
-    // zeros, subnormal ratios and 0 / 0 on the exact path
-    const float f_lo0 = (float)lo0, f_hi0 = (float)hi0, f_lo1 = (float)lo1, f_hi1 = (float)hi1;
-    if (lo0 > 1e-30 && hi0 < lo1 && f_hi1 < 3.0e38f) {
-      const float r_lo = f_lo0 / f_hi1, r_hi = f_hi0 / f_lo1;   // the float ratio of the exact path lies in [r_lo, r_hi]
-      if (ratio_good < 0.f) certain = (r_lo > ratio_all) == (r_hi > ratio_all);
-      else certain = ((r_lo < ratio_good) == (r_hi < ratio_good)) && ((r_lo < ratio_all) == (r_hi < ratio_all));
-      fa = f_hi0; fb = f_lo1;   // any point of the interval gives the certain outcome
-    }
+    certain = ratio_certain(lo0, hi0, lo1, hi1, ratio_good, ratio_all, fa, fb);
   }
 #endif
   Q.certain = certain; Q.fa = fa; Q.fb = fb; Q.id1 = id1;
@@ -915,6 +919,47 @@ __device__ __forceinline__ void epi_file(EpiQuery& Q, int q, int2* __restrict__ 
     Q.pos[j] = pos;
     n += __builtin_popcountll(m);
   }
+}
+
+// Second look at the queries the f16 intervals could not decide (codes-only matching): their candidates' distances evaluated in
+// binary32 by the whole wave (r32[], below) are within 2e-6 of the real value - (x - y) rounded once, squared and accumulated by
+// four fused steps per lane and five tree steps: eleven roundings of 2^-24, three times covered - against E / d^2 ~ 1.6e-3 of the
+// f16 product.  With b0 < b1 the two smallest of them: the nearest row is known if the intervals do not touch, the second nearest
+// DISTANCE lies in b1's interval whichever row it belongs to (every other evaluated candidate is no smaller, the listed rows that
+// were not evaluated and the unlisted rows are bounded away as in the exact path), and the ratio's interval is 8e-6 wide instead
+// of 6e-3: all but ~0.3 % of these queries are decided here (0.126 -> 0.0003 exact evaluations per query on 512-norm SIFT-like data,
+// the wave's round of 128 dependent binary64 operations runs in 0.8 % of the waves instead of 97 %).  On that data the kernel's time
+// did not change (18.75 ms either way on 4 032 pairs: the round was hidden behind the CU's other workgroup); the pass is kept for
+// data whose ratios crowd a threshold, where the f16 intervals decide little (-DMSFM_KNN_F16_NOREFINE: without it).
+__device__ __forceinline__ void epi_refine(const PairTaskH& T, EpiQuery& Q, const float* __restrict__ r32, float ratio_good, float ratio_all) {
+  float b0 = __builtin_inff(), b1 = __builtin_inff();
+  int j0 = 0x7fffffff, j1 = 0x7fffffff;
+  auto ins = [&](float v, int id) {
+    const bool lt0 = v < b0 || (v == b0 && id < j0), lt1 = v < b1 || (v == b1 && id < j1);
+    const float nb1 = lt0 ? b0 : (lt1 ? v : b1);
+    const int nj1 = lt0 ? j0 : (lt1 ? id : j1);
+    b0 = lt0 ? v : b0; j0 = lt0 ? id : j0; b1 = nb1; j1 = nj1;
+  };
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (Q.eval[j]) { ins(r32[Q.pos[j]], Q.gi[j]); any = true; }
+  {
+    const float p0 = __shfl_xor(b0, 32, 64), p1 = __shfl_xor(b1, 32, 64);
+    const int q0 = __shfl_xor(j0, 32, 64), q1 = __shfl_xor(j1, 32, 64);
+    ins(p0, q0); ins(p1, q1);
+    const int any_other = __shfl_xor((int)any, 32, 64);   // (unconditionally: `any || shuffle` would skip the exchange in the lanes that have candidates)
+    any = any || any_other != 0;
+  }
+  if (Q.certain || !any || !(b1 < 3.0e38f)) return;
+  const double eps = 2e-6;
+  const double lo0 = (double)b0 * (1.0 - eps), hi0 = (double)b0 * (1.0 + eps), lo1 = (double)b1 * (1.0 - eps), hi1 = (double)b1 * (1.0 + eps);
+  if (!(Q.unl_bound > hi1 * (double)T.s2 * (1.0 + 1e-12))) return;   // a row outside the lists might be the second nearest: exact path / slow path
+  float fa = 0.f, fb = 1.f;
+  if (!ratio_certain(lo0, hi0, lo1, hi1, ratio_good, ratio_all, fa, fb)) return;
+  Q.certain = true; Q.fa = fa; Q.fb = fb; Q.id1 = j0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) Q.eval[j] = false;
 }
 
 __device__ __forceinline__ void epi_finish(const PairTaskH& T, int pair, int q, bool qvalid, int h, const EpiQuery& Q, const double* __restrict__ res,
@@ -1168,20 +1213,51 @@ __global__ __launch_bounds__(256, MSFM_KNN_F16_WGS) void k_knn2_f16(const PairTa
 #endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
+#ifndef MSFM_KNN_F16_NOREFINE
+  if (!ids && n_ent > 0) {
+    // binary32 distances of every filed (train row, query row) by the whole wave: lanes 0-31 fetch the train row, lanes 32-63 the
+    // query row, sixteen coalesced bytes each; eight entries' loads in flight at a time (the float32 rows are cold: the sweep read
+    // the f16 forms)
+    float* r32 = reinterpret_cast<float*>(res);
+    for (int e0 = 0; e0 < n_ent; e0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int2 x = ent[min(e0 + j, n_ent - 1)];
+        const float* src = (h ? T.qf32 + (size_t)x.y * DIM : T.tf32 + (size_t)x.x * DIM) + 4 * r;
+        v[j] = *reinterpret_cast<const f32x4*>(src);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (e0 + j < n_ent) {   // (uniform over the wave)
+          const float d0 = v[j].x - __shfl_xor(v[j].x, 32, 64), d1 = v[j].y - __shfl_xor(v[j].y, 32, 64);
+          const float d2 = v[j].z - __shfl_xor(v[j].z, 32, 64), d3 = v[j].w - __shfl_xor(v[j].w, 32, 64);
+          float sum = d0 * d0;
+          sum = __builtin_fmaf(d1, d1, sum); sum = __builtin_fmaf(d2, d2, sum); sum = __builtin_fmaf(d3, d3, sum);
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+          if (lane == 0) r32[e0 + j] = sum;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    epi_refine(T, A, r32, ratio_good, ratio_all);
+    epi_refine(T, B, r32, ratio_good, ratio_all);
+    __builtin_amdgcn_wave_barrier();   // (every lane has read its binary32 values: the exact round reuses the space)
+    n_ent = 0;
+    epi_file(A, qa, ent, n_ent);
+    epi_file(B, qb, ent, n_ent);
+#ifdef MSFM_KNN_F16_STATS
+    if (lane == 0) { atomicAdd(&g_f16_stats[4], (unsigned long long)n_ent); atomicAdd(&g_f16_stats[5], (unsigned long long)((n_ent + 63) / 64)); }
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+#endif
   for (int e = lane; e < (debug_mode == 3 ? 0 : n_ent); e += 64) {   // (3: timing experiment without the exact evaluations)
     const int2 x = ent[e];
-    const float* pa = T.tf32 + (size_t)x.x * DIM;
-    const float* pb = T.qf32 + (size_t)x.y * DIM;
-    // The float32 rows are cold (the sweep read the f16 forms): touch the four 128-byte lines of both rows at once, so that the
-    // evaluation pays one miss latency instead of one per batch of its loads (29 k -> ~8 k cycles per round of the list).
-    {
-      float t0, t1, t2, t3, t4, t5, t6, t7;
-      asm volatile("global_load_dword %0, %8, off\n\tglobal_load_dword %1, %8, off offset:128\n\tglobal_load_dword %2, %8, off offset:256\n\t"
-                   "global_load_dword %3, %8, off offset:384\n\tglobal_load_dword %4, %9, off\n\tglobal_load_dword %5, %9, off offset:128\n\t"
-                   "global_load_dword %6, %9, off offset:256\n\tglobal_load_dword %7, %9, off offset:384\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7) : "v"(pa), "v"(pb) : "memory");
-    }
-    res[e] = exact_sqdist(pa, pb);
+    res[e] = exact_sqdist(T.tf32 + (size_t)x.x * DIM, T.qf32 + (size_t)x.y * DIM);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
