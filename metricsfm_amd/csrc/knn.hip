@@ -1318,15 +1318,28 @@ __global__ __launch_bounds__(256) void k_exact_flagged(const PairTaskH* __restri
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int k = 0; k < 4; k++) { lv[j][k] = 0xffffffffu; li[j][k] = 0x7fffffff; }
+    // (round 5: the next block of train rows is on its way from memory while this one is worked on - a sweep is one workgroup
+    //  walking a whole image, 64 blocks whose load latency used to stand in front of each of them: it is what a per-train-image
+    //  call of a few hundred pairs waits for at the end)
+    f32x4 stg[8];
+    auto fetch_rows = [&](int t0) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int e = tid + 256 * i, row = e >> 5, c4 = e & 31;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        stg[i] = zero;
+        if (t0 + row < T.n_train) stg[i] = *reinterpret_cast<const f32x4*>(T.tf32 + (size_t)(t0 + row) * DIM + 4 * c4);
+      }
+    };
+    fetch_rows(0);
     for (int t0 = 0; t0 < T.n_train; t0 += 64) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 8; i++) {
         const int e = tid + 256 * i, row = e >> 5, c4 = e & 31;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t0 + row < T.n_train) v = *reinterpret_cast<const float4*>(T.tf32 + (size_t)(t0 + row) * DIM + 4 * c4);
-        *reinterpret_cast<float4*>(&rows[row * XROW + 4 * c4]) = v;
+        *reinterpret_cast<f32x4*>(&rows[row * XROW + 4 * c4]) = stg[i];
       }
+      if (t0 + 64 < T.n_train) fetch_rows(t0 + 64);
       __syncthreads();
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll 4
