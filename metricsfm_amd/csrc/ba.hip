@@ -2252,9 +2252,34 @@ static BaScratch& ba_scratch(msfm_ctx* ctx) {
 // =======================================================================================
 namespace devsetup {
 
+// Exclusive scan of a SHORT array by one workgroup in one launch (round 5): the set-up of a window-sized problem is ~190 launches
+// of a few microseconds each, fifteen of them scans of a few thousand integers for which rocPRIM's look-back scan is two launches
+// and a temporary.  Integer sums: the result is the same whatever the grouping.
+template <class T>
+__global__ __launch_bounds__(1024) void k_scan_small(const T* __restrict__ in, T* __restrict__ out, int n) {
+  __shared__ T part[1024];
+  const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);
+  T sum = T(0);
+  for (int i = lo; i < hi; i++) sum += in[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const T v = t >= off ? part[t - off] : T(0);
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  T run = part[t] - sum;
+  for (int i = lo; i < hi; i++) { const T v = in[i]; out[i] = run; run += v; }
+}
+#define MSFM_SCAN_SMALL_MAX 65536
 template <class T>
 static hipError_t excl_scan(const T* in, T* out, size_t n, hipStream_t s, DevBuf<char>& tmp) {
   if (n == 0) return hipSuccess;
+  if (n <= MSFM_SCAN_SMALL_MAX && in != out) {
+    hipLaunchKernelGGL((k_scan_small<T>), dim3(1), dim3(1024), 0, s, in, out, (int)n);
+    return hipGetLastError();
+  }
   size_t bytes = 0;
   hipError_t e = rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), s);
   if (e != hipSuccess) return e;
