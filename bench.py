@@ -98,8 +98,10 @@ def spawn_ranks(n_gpus, argv=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (30 / 3 since round 5: a run starts with one evaluation + the Jacobi scaling, ~0.4 ms that ten timed iterations carried as 4 %
+    #  of their time and thirty carry as 1.3 %; the reference caps a solve at 100 iterations, test_sfm.cc:35-36)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=3, help="BASELINE config number (3 = headline)")
     ap.add_argument("--window", action="store_true", help="config 5: the partial bundle adjustment of the newest camera")
     ap.add_argument("--match-images", type=int, default=0, help="images in the matching legs (0 = every image of the scene)")
@@ -206,12 +208,22 @@ def main():
     assert res["num_iterations"] == args.steps, res["termination"]
 
     # profiled pass (HIP events per kernel class on the ctx stream) for the roofline figures
-    ba.upload(*start)
-    ctx.profile(True)
-    ctx.profile_reset()
-    res_p = ba.run(fixed_iteration_options(args.steps))
-    ba_stats = ctx.profile_get()
-    ctx.profile(False)
+    # (two passes, per kernel class the one with the smaller total: the event pairs around every launch make the pass sensitive to
+    #  whatever else the box does - one collection of round 5 read 360 us for a kernel that rocprofv3 and the other passes put at 300)
+    ba_stats = None
+    for _ in range(2):
+        ba.upload(*start)
+        ctx.profile(True)
+        ctx.profile_reset()
+        res_p = ba.run(fixed_iteration_options(args.steps))
+        st = ctx.profile_get()
+        ctx.profile(False)
+        if ba_stats is None:
+            ba_stats = st
+        else:
+            for k, v in st.items():
+                if k not in ba_stats or (v["launches"] == ba_stats[k]["launches"] and v["total_ms"] < ba_stats[k]["total_ms"]):
+                    ba_stats[k] = v
 
     # the same K iterations as ONE msfm_ba_solve call on the host arrays (what replaces ceres::Solve in the reference):
     # index-structure setup + upload + K iterations + download, on the warm GPU; reported beside `value`, never as it
