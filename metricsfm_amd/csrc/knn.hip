@@ -996,7 +996,7 @@ __device__ __forceinline__ void epi_finish(const PairTaskH& T, int pair, int q, 
 // 1 workgroup = 4 waves = 256 queries of one pair (two query sets of 32 per wave, every A fragment feeds two MFMAs);
 // train tiles of 64 rows double-buffered through XOR-swizzled LDS, as the integer kernels.
 #ifndef MSFM_KNN_F16_WGS
-#define MSFM_KNN_F16_WGS 2
+#define MSFM_KNN_F16_WGS 3   // (round 5: three workgroups per CU since the tile fetch needs no staging registers: 875 -> 960 Mmatches/s on 4 032 pairs)
 #endif
 __global__ __launch_bounds__(256, MSFM_KNN_F16_WGS) void k_knn2_f16(const PairTaskH* __restrict__ tasks, const int* __restrict__ tile_first, int n_pairs,
                                                       float ratio_good, float ratio_all, int32_t* __restrict__ code, int* __restrict__ ids,
@@ -1034,31 +1034,27 @@ __global__ __launch_bounds__(256, MSFM_KNN_F16_WGS) void k_knn2_f16(const PairTa
   u32 gva[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, gvb[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   int gia[4] = {0, 0, 0, 0}, gib[4] = {0, 0, 0, 0};   // window bases of the list entries
   const int n_tiles = (T.n_train + TT - 1) / TT;
-  i32x4 stage[4];   // (a native vector type: a struct copy out of address space 1 becomes a memcpy that keeps the array in scratch)
+  // Round 5: the train tile goes from memory straight into LDS (global_load_lds_dwordx4: 1 KB per wave instruction, sixteen bytes
+  // per lane, no staging registers and no ds_write): the XOR swizzle of the tile is applied on the SOURCE side - LDS position
+  // (row, slot s) holds the row's 16-byte chunk s ^ (row & 15), so the lane that fills slot s fetches that chunk.  A row past the
+  // end reads the last row (its norm makes it lose every comparison).  Sixteen registers less: three workgroups per CU fit.
   float stage_n = 0.f;
-  typedef const i32x4 __attribute__((address_space(1)))* g_u4p;
   typedef const float __attribute__((address_space(1)))* g_f32p;
-  const g_u4p th_g = (g_u4p)(uintptr_t)T.th;
   const g_f32p tn_g = (g_f32p)(uintptr_t)T.tn2s;
-  auto fetch = [&](int tile) {
+  auto fetch = [&](int tile, int buf) {
     const int t0 = tile * TT;
-    // Round 5: global (not flat) loads without a branch around them - a row past the end reads the last row instead (its
-    // norm below makes it lose every comparison whatever its operands) - and nothing computed from a loaded value here: the
-    // `+ shift` of the norms used to put an `s_waitcnt vmcnt(0)` into wave 0 at the top of every tile.
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      stage[i] = th_g[(unsigned)min(t0 + row, T.n_train - 1) * (unsigned)(DIM / 8) + (unsigned)ch];   // (32-bit offsets: scalar base + vector offset)
+      const int piece = 4 * wave + i, row = 4 * piece + (lane >> 4), slot = lane & 15;
+      const unsigned short* src = T.th + (size_t)min(t0 + row, T.n_train - 1) * DIM + ((slot ^ (row & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(&lds_a[buf][piece * 1024]), 16, 0, 0);
     }
     if (tid < TT) stage_n = tn_g[(unsigned)min(t0 + tid, T.n_train - 1)];
   };
   auto commit = [&](int buf, int tile) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      *reinterpret_cast<i32x4*>(&lds_a[buf][row * 256 + ((ch ^ (row & 15)) << 4)]) = stage[i];
-    }
     if (tid < TT) lds_n[buf][tid] = (tile * TT + tid < T.n_train) ? stage_n + T.shift : 3.0e38f;  // padding rows lose every comparison
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's own LDS-DMA pieces have landed (s_barrier does not wait for them)
   };
   u32 keymask;
   asm volatile("v_mov_b32 %0, 0xffffff00" : "=v"(keymask));
@@ -1076,12 +1072,12 @@ __global__ __launch_bounds__(256, MSFM_KNN_F16_WGS) void k_knn2_f16(const PairTa
     mB = __uint_as_float(__float_as_uint((float)(2.05 * Eb)) + 1u);
   }
 #endif
-  fetch(0);
+  fetch(0, 0);
   commit(0, 0);
   __syncthreads();
   int cur = 0;
   for (int tile = 0; tile < n_tiles; tile++) {
-    if (tile + 1 < n_tiles) fetch(tile + 1);
+    if (tile + 1 < n_tiles) fetch(tile + 1, cur ^ 1);
     const unsigned char* la = lds_a[cur];
     const float* ln = lds_n[cur];
 #pragma unroll
@@ -1094,18 +1090,12 @@ __global__ __launch_bounds__(256, MSFM_KNN_F16_WGS) void k_knn2_f16(const PairTa
       }
       accb = acca;
       const int row = st * 32 + r;
-      // all eight operand reads of the step first (the compiler used to issue them two at a time, each pair followed by a
-      // full `s_waitcnt lgkmcnt(0)` in front of its four MFMAs)
-      f16x8 af[8];
 #pragma unroll
       for (int ks = 0; ks < 8; ks++) {
         const int ch = 2 * ks + h;
-        af[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(la + row * 256 + ((ch ^ (row & 15)) << 4)));
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ks++) {
-        acca = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bqa[ks], acca, 0, 0, 0);
-        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bqb[ks], accb, 0, 0, 0);
+        const f16x8 a = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(la + row * 256 + ((ch ^ (row & 15)) << 4)));
+        acca = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqa[ks], acca, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bqb[ks], accb, 0, 0, 0);
       }
       const int wbase = ((tile & 3) * 2 + st) * 32;
 #ifndef MSFM_KNN_F16_NOFILTER
