@@ -58,6 +58,7 @@ struct msfm_descset {
   std::vector<int> f16_exp;                         // log2 of the scale an image's f16 forms were made with (INT_MIN: none)
   float vabs_max = 0.f;                             // largest |value| uploaded so far
   DevBuf<unsigned> vmax_dev, n2smax_dev;            // [1], [2 n_images]: n2s maxima, then rerr maxima
+  DevBuf<signed char> zero_row;          // 128 zero bytes (k_knn2_i8 reads them for train rows past the end)
   DevBuf<int> nonint;                    // OR of "not integer in [0,255]" over all uploads
   int h_nonint = 0;
   // bumped by every upload: a match result remembers the generation its device pointer tables were built at and
@@ -325,6 +326,7 @@ struct PairTask8 {
   const int* tpar;
   const int* qbeta;
   int n_train, n_query, out_off;
+  const signed char* zero_row;   // 128 zero bytes: what the tile fetch reads for rows past the end
 };
 
 __device__ __forceinline__ void flush_window8(u32& k0, u32& k1, u32& D0, int& I0, u32& D1, int& I1, int base) {
@@ -371,17 +373,19 @@ __global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict_
   u32 aTl = 0x7fffffffu, bTl = 0x7fffffffu;
   const int n_tiles = (T.n_train + TT - 1) / TT;
   // staging: 64 rows x 8 chunks of 16 B = 512 chunks, 2 per thread; chunk' = chunk ^ ((row >> 1) & 7)
-  // (Round 5 measured k_knn2_f16's fetch here too - global loads without a branch, padding decided at the commit: 1 791 -> 1 736
-  //  Mmatches/s on 4 032 pairs, ten registers spilled around the loop at 128: not kept.)
-  uint4 stage[2];
+  // Round 5: the train tile goes from memory straight into LDS (global_load_lds_dwordx4, as in k_knn2_f16: the XOR swizzle on the
+  // source side; a row past the end reads a row of zeros - its operands must be zero, or its sum could leave the 23 bits a key
+  // has for it).  (The same fetch through registers without a branch, padding decided at the commit, had measured slower here:
+  // 1 791 -> 1 736 Mmatches/s, ten registers spilled around the loop at 128.)
   int stage_cin = 0, stage_c = 0;
-  auto fetch = [&](int tile) {
+  auto fetch = [&](int tile, int buf) {
     const int t0 = tile * TT;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-      stage[i] = make_uint4(0, 0, 0, 0);
-      if (t0 + row < T.n_train) stage[i] = *reinterpret_cast<const uint4*>(T.train + (size_t)(t0 + row) * DIM + ch * 16);
+      const int piece = 2 * wave + i, row = 8 * piece + (lane >> 3), slot = lane & 7;
+      const signed char* src = (t0 + row < T.n_train ? T.train + (size_t)(t0 + row) * DIM : T.zero_row) + ((slot ^ ((row >> 1) & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(&lds_a[buf][piece * 1024]), 16, 0, 0);
     }
     if (tid < TT) {
       const bool in = t0 + tid < T.n_train;
@@ -390,14 +394,10 @@ __global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict_
     }
   };
   auto commit = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(&lds_a[buf][row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)]) = stage[i];
-    }
     if (tid < TT) { lds_cin[buf][tid] = stage_cin; lds_c[buf][tid] = stage_c; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave's own LDS-DMA pieces have landed (s_barrier does not wait for them)
   };
-  fetch(0);
+  fetch(0, 0);
   commit(0);
   __syncthreads();
   int cur = 0;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, 4) void k_knn2_i8(const PairTask8* __restrict_
   // tile after next staged ahead as well) 6.8-8.2 ms against 6.2, and letting the two accumulator sets of a lane take turns
   // (b selected under a's MFMAs; 168-178 registers) 6.7-6.9 ms.  What did pay: top2_insert without branches (above).
   for (int tile = 0; tile < n_tiles; tile++) {
-    if (tile + 1 < n_tiles) fetch(tile + 1);
+    if (tile + 1 < n_tiles) fetch(tile + 1, cur ^ 1);
     const unsigned char* la = lds_a[cur];
 #pragma unroll
     for (int st = 0; st < 2; st++) {
@@ -1420,6 +1420,7 @@ MSFM_API int msfm_descset_create(msfm_ctx* ctx, int n_images, int dim, msfm_desc
   s->f16_exp.assign(n_images, INT_MIN);
   s->ti8.assign(n_images, nullptr); s->qi8.assign(n_images, nullptr); s->tcin.assign(n_images, nullptr); s->tpar.assign(n_images, nullptr); s->qbeta.assign(n_images, nullptr);
   if (s->vmax_dev.alloc(1) != hipSuccess || s->n2smax_dev.alloc(2 * (size_t)n_images) != hipSuccess || s->nonint.alloc(1) != hipSuccess ||
+      s->zero_row.alloc(256) != hipSuccess || hipMemsetAsync(s->zero_row.p, 0, 256, ctx->stream) != hipSuccess ||
       hipMemsetAsync(s->nonint.p, 0, sizeof(int), ctx->stream) != hipSuccess || hipMemsetAsync(s->vmax_dev.p, 0, sizeof(unsigned), ctx->stream) != hipSuccess) {
     delete s;
     return msfm_set_error(ctx, MSFM_E_NOMEM, "descset alloc");
@@ -1712,7 +1713,7 @@ static int match_pairs_impl(msfm_descset* s, const int* pairs, int n_pairs, floa
     R->nq.push_back(nq);
     tile_first[p] = (int)tiles;
     tasks[p] = PairTask{s->bf16[a]->p, nq ? s->bf16[b]->p : nullptr, s->norm[a]->p, nq ? s->norm[b]->p : nullptr, s->count[a], nq, (int)off};
-    tasks8[p] = PairTask8{s->ti8[a]->p, nq ? s->qi8[b]->p : nullptr, s->tcin[a]->p, s->tpar[a]->p, nq ? s->qbeta[b]->p : nullptr, s->count[a], nq, (int)off};
+    tasks8[p] = PairTask8{s->ti8[a]->p, nq ? s->qi8[b]->p : nullptr, s->tcin[a]->p, s->tpar[a]->p, nq ? s->qbeta[b]->p : nullptr, s->count[a], nq, (int)off, s->zero_row.p};
     tasksf[p] = PairTaskF{s->f32[a]->p, nq ? s->f32[b]->p : nullptr, s->count[a], nq, (int)off};
     pair_off[p] = (int)off;
     if (certified) {
