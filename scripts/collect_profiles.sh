@@ -21,7 +21,7 @@ bash scripts/mfma_util.sh > $O/mfma_util.log 2>&1 || echo "mfma_util failed"
 cp gpurun_out/mfma/r05_mfma_util.json profiles/r05_mfma_util.json || true
 echo "mfma util done"
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
-python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
+python3 bench.py > $O/bench.json 2> $O/bench.err
 echo "bench done"; tail -c 300 $O/bench.json
 python3 bench.py --config 5 --window --steps 20 --warmup 3 > $O/bench_c5_window.json 2> $O/bench_c5_window.err
 echo "config 5 window done"
